@@ -1,0 +1,187 @@
+"""Host-side assembly of one reference view's problem: the Python mirror of what runGipuma()
+puts into GlobalState before it calls runcuda() (reference main.cpp:829-968), and the
+runcuda()-shaped entry point on top of the C-ABI.
+
+Names follow the reference: AlgorithmParameters (algorithmparameters.h:19-85), GlobalState
+(globalstate.h:24-45), runcuda (gipuma.h:2).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from .cameras import disparity_range
+
+
+class AlgorithmParameters:
+    """Defaults of reference algorithmparameters.h:21-51 (only the fields the path reads, plus the
+    host-side view-selection knobs)."""
+
+    def __init__(self, **kw):
+        self.box_hsize = 19
+        self.box_vsize = 19
+        self.tau_color = 10.0
+        self.tau_gradient = 2.0
+        self.alpha = 0.9
+        self.gamma = 10.0
+        self.iterations = 8
+        self.good_factor = 1.5
+        self.n_best = 2
+        self.cost_comb = abi.COMB_BEST_N
+        self.depthMin = -1.0
+        self.depthMax = -1.0
+        self.min_angle = 5.0
+        self.max_angle = 45.0
+        self.max_views = 9
+        self.min_disparity = 0.0
+        self.max_disparity = 256.0
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise TypeError("unknown AlgorithmParameters field %r" % k)
+            setattr(self, k, v)
+
+    def set_blocksize(self, b):
+        """--blocksize= must be odd and sets both sizes (main.cpp:269-276)."""
+        if b % 2 == 0:
+            raise ValueError("blocksize must be odd")
+        self.box_hsize = self.box_vsize = b
+
+    def to_c(self):
+        p = abi.Params()
+        p.box_hsize, p.box_vsize = self.box_hsize, self.box_vsize
+        p.iterations, p.n_best, p.cost_comb = self.iterations, self.n_best, self.cost_comb
+        p.alpha, p.tau_color, p.tau_gradient = self.alpha, self.tau_color, self.tau_gradient
+        p.gamma, p.good_factor = self.gamma, self.good_factor
+        p.min_disparity, p.max_disparity = self.min_disparity, self.max_disparity
+        return p
+
+
+class GlobalState:
+    """Everything runcuda() reads: cameras, selected views, parameters and the images.
+
+    images: list of 2-D float32 arrays (0..255, main.cpp:941), index 0 = reference view; or, with
+    ``device_ptrs``, raw device addresses of such planes already resident in HBM.
+    """
+
+    def __init__(self, images, camera_set, selected, params, seed=1, device_ptrs=None,
+                 rows=None, cols=None, pitch=None, device_id=0, stream=None, flags=0):
+        self.params = params
+        self.cameras = camera_set
+        self.selected = list(selected)
+        if len(self.selected) > abi.MAX_VIEWS:
+            raise ValueError("at most %d selected views (gipuma.cu:736)" % abi.MAX_VIEWS)
+        if device_ptrs is None:
+            self.images = [np.ascontiguousarray(im, dtype=np.float32) for im in images]
+            self.rows, self.cols = self.images[0].shape
+            self.pitch = self.cols
+            ptrs = [im.ctypes.data for im in self.images]
+        else:
+            self.images = images  # keep whatever owns the device memory alive
+            self.rows, self.cols, self.pitch = rows, cols, pitch or cols
+            ptrs = list(device_ptrs)
+            flags |= abi.FLAG_IMAGES_ON_DEVICE
+        n = len(ptrs)
+        if n != camera_set.n:
+            raise ValueError("need one camera per image")
+        # depth range -> camera 0 and the disparity range (main.cpp:898-906)
+        cam0 = camera_set.c_array[0]
+        cam0.depth_min, cam0.depth_max = params.depthMin, params.depthMax
+        params.min_disparity, params.max_disparity = disparity_range(
+            camera_set.f, cam0.baseline, params.depthMin, params.depthMax)
+        self._img_ptrs = (C.c_void_p * n)(*ptrs)
+        self._sel = (C.c_int32 * max(1, len(self.selected)))(*self.selected)
+        d = abi.Desc()
+        d.abi_version = abi.ABI_VERSION
+        d.rows, d.cols, d.channels, d.pitch = self.rows, self.cols, 1, self.pitch
+        d.n_images = n
+        d.images = C.cast(self._img_ptrs, C.POINTER(C.c_void_p))
+        d.cameras = C.cast(camera_set.c_array, C.POINTER(abi.Camera))
+        d.n_selected = len(self.selected)
+        d.selected = C.cast(self._sel, C.POINTER(C.c_int32))
+        d.params = params.to_c()
+        d.seed = seed
+        d.device_id = device_id
+        d.stream = stream
+        d.flags = flags
+        self.desc = d
+
+    @property
+    def n_pixels(self):
+        return self.rows * self.cols
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def runcuda(gs, timing=False):
+    """The reference's ``int runcuda(GlobalState&)`` (gipuma.h:2) on the HIP path.
+
+    Returns (norm4, cost[, Timing]): norm4[y, x] = (n_world.xyz, depth), cost[y, x], as the
+    reference leaves them in gs.lines (gipuma.cu:1080-1103, main.cpp:976-985)."""
+    lib = abi.load_library()
+    norm4 = np.empty((gs.rows, gs.cols, 4), dtype=np.float32)
+    cost = np.empty((gs.rows, gs.cols), dtype=np.float32)
+    t = abi.Timing()
+    rc = lib.gipuma_hip_run(C.byref(gs.desc), _fptr(norm4), _fptr(cost), C.byref(t))
+    abi.check(lib, rc, "gipuma_hip_run")
+    return (norm4, cost, t) if timing else (norm4, cost)
+
+
+class Session:
+    """One reference view resident on the GPU: the launches of gipuma<T>() (gipuma.cu:1825-1960)
+    one call at a time."""
+
+    def __init__(self, gs):
+        self.lib = abi.load_library()
+        self.gs = gs
+        self.h = C.c_void_p()
+        abi.check(self.lib, self.lib.gipuma_hip_create(C.byref(gs.desc), C.byref(self.h)),
+                  "gipuma_hip_create")
+
+    def close(self):
+        if self.h:
+            self.lib.gipuma_hip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def init_planes(self):
+        abi.check(self.lib, self.lib.gipuma_hip_init_planes(self.h), "gipuma_hip_init_planes")
+
+    def sweep(self, iteration, colour, stages=abi.STAGE_ALL):
+        abi.check(self.lib, self.lib.gipuma_hip_sweep(self.h, iteration, colour, stages),
+                  "gipuma_hip_sweep")
+
+    def finalize(self):
+        abi.check(self.lib, self.lib.gipuma_hip_finalize(self.h), "gipuma_hip_finalize")
+
+    def solve(self, timing=True):
+        t = abi.Timing()
+        abi.check(self.lib, self.lib.gipuma_hip_solve(self.h, C.byref(t) if timing else None),
+                  "gipuma_hip_solve")
+        return t
+
+    def eval_cost(self, planes):
+        planes = np.ascontiguousarray(planes, dtype=np.float32)
+        out = np.empty((self.gs.rows, self.gs.cols), dtype=np.float32)
+        abi.check(self.lib, self.lib.gipuma_hip_eval_cost(self.h, _fptr(planes), _fptr(out)),
+                  "gipuma_hip_eval_cost")
+        return out
+
+    def get_state(self):
+        norm4 = np.empty((self.gs.rows, self.gs.cols, 4), dtype=np.float32)
+        cost = np.empty((self.gs.rows, self.gs.cols), dtype=np.float32)
+        abi.check(self.lib, self.lib.gipuma_hip_get_state(self.h, _fptr(norm4), _fptr(cost)),
+                  "gipuma_hip_get_state")
+        return norm4, cost
+
+    def set_state(self, norm4, cost):
+        norm4 = np.ascontiguousarray(norm4, dtype=np.float32)
+        cost = np.ascontiguousarray(cost, dtype=np.float32)
+        abi.check(self.lib, self.lib.gipuma_hip_set_state(self.h, _fptr(norm4), _fptr(cost)),
+                  "gipuma_hip_set_state")

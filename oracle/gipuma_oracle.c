@@ -1,0 +1,708 @@
+/*
+ * gipuma_oracle.c -- CPU restatement of Gipuma's red-black PatchMatch loop (reference
+ * gipuma.cu).  TEST INFRASTRUCTURE ONLY: see gipuma_oracle.h for who may load it and for the
+ * pin status.
+ *
+ * Plain C99, fp32 throughout, built with -ffp-contract=off so the only fused multiply-adds
+ * are the ones spelled fmaf().  Each function cites the reference lines it restates.
+ *
+ * Numerical model (where the reference's own arithmetic is not reproducible on any CPU, the
+ * model is stated here once and used by BOTH this oracle and the HIP kernels):
+ *   M1  bilinear sampling: the reference samples float textures with cudaFilterModeLinear at
+ *       (x+0.5, y+0.5) (main.cpp:644-648, gipuma.cu:251-253), i.e. hardware 1.8 fixed-point
+ *       weights.  gfx950 has no texture unit; the model is an exact fp32 lerp
+ *       t0 + a*(t1-t0) (one fmaf) of the texels floor(x), floor(x)+1 with clamp-to-edge
+ *       texel addressing, a = x - floor(x).  The +-1 gradient taps (gipuma.cu:251-252) reuse
+ *       the centre tap's a/b and move the texel window by whole texels.
+ *   M2  expf / rsqrtf / division are approximate in the reference build (--use_fast_math,
+ *       CMakeLists.txt:23).  Model: exp is go_exp() below (Cephes-style, ~1 ulp), rsqrtf(x) is
+ *       1/sqrtf(x), x/z and y/z of the warped point are x*(1/z), y*(1/z) with an IEEE 1/z.
+ *   M3  nvcc contracts a*b+c to FMA at will; the model fixes the contractions in the per-sample
+ *       loop (homography application, lerps, dis, cost accumulation) as explicit fmaf() and
+ *       leaves everything evaluated once per hypothesis unfused, in source order.
+ *   M4  random numbers: the reference's cuRAND state is never initialised; the
+ *       model is a stateless counter hash keyed by (seed, phase, x, y, draw) -> (0,1].
+ */
+#include "gipuma_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define GO_MAXCOST 1000.0f /* config.h:22 */
+#define GO_WIN_INCREMENT 2 /* gipuma.cu:28 */
+
+/* ------------------------------------------------------------------------------------------
+ * M4: counter-based uniform in (0,1], standing in for curand_uniform (gipuma.cu:138-141)
+ * ---------------------------------------------------------------------------------------- */
+static inline uint32_t go_mix(uint32_t h)
+{
+    h ^= h >> 16;
+    h *= 0x7feb352dU;
+    h ^= h >> 15;
+    h *= 0x846ca68bU;
+    h ^= h >> 16;
+    return h;
+}
+
+static inline uint32_t go_rand_u32(uint32_t seed, uint32_t phase, uint32_t x, uint32_t y,
+                                   uint32_t draw)
+{
+    uint32_t h = go_mix(seed + 0x9E3779B9U);
+    h = go_mix(h ^ (phase + 0x85EBCA6BU));
+    h = go_mix(h ^ (y + 0xC2B2AE35U));
+    h = go_mix(h ^ (x + 0x27D4EB2FU));
+    h = go_mix(h ^ (draw + 0x165667B1U));
+    return h;
+}
+
+static inline float go_uniform(uint32_t seed, uint32_t phase, uint32_t x, uint32_t y,
+                               uint32_t draw)
+{
+    const uint32_t h = go_rand_u32(seed, phase, x, y, draw);
+    return (float)((h >> 8) + 1U) * 5.9604644775390625e-8f; /* 2^-24: (0,1] exactly */
+}
+
+float gipuma_oracle_uniform(uint32_t seed, uint32_t phase, uint32_t x, uint32_t y, uint32_t draw)
+{
+    return go_uniform(seed, phase, x, y, draw);
+}
+
+/* phase ids: init = 0; sweep (iteration, colour) = 1 + 2*iteration + colour */
+static inline uint32_t go_phase(int iteration, int colour)
+{
+    return 1U + 2U * (uint32_t)iteration + (uint32_t)colour;
+}
+
+/* curand_between, gipuma.cu:138-141 */
+static inline float go_between(float u, float lo, float hi) { return u * (hi - lo) + lo; }
+
+/* ------------------------------------------------------------------------------------------
+ * M2: exp for the adaptive support weight (weight_cu, gipuma.cu:186-193).  x <= 0 in use.
+ * ---------------------------------------------------------------------------------------- */
+static inline float go_exp(float x)
+{
+    if (!(x >= -86.0f)) return 0.0f; /* also NaN */
+    if (x > 86.0f) x = 86.0f;
+    const float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    const float e = fmaf(p, r * r, r) + 1.0f;
+    union { float f; int32_t i; } b;
+    b.f = e;
+    b.i += ((int32_t)n) << 23;
+    return b.f;
+}
+
+float gipuma_oracle_exp(float x) { return go_exp(x); }
+
+/* ------------------------------------------------------------------------------------------
+ * small vector / matrix helpers, literal operation order of config.h
+ * ---------------------------------------------------------------------------------------- */
+/* matvecmul4, config.h:163-176:  (m0*x + m1*y) + m2*z */
+static inline void go_matvec(const float *m, const float v[3], float out[3])
+{
+    out[0] = m[0] * v[0] + m[1] * v[1] + m[2] * v[2];
+    out[1] = m[3] * v[0] + m[4] * v[1] + m[5] * v[2];
+    out[2] = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+}
+
+/* matmul_cu, config.h:205-241 */
+static inline void go_matmul(const float *a, const float *b, float *o)
+{
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++)
+            o[3 * r + c] = a[3 * r] * b[c] + a[3 * r + 1] * b[c + 3] + a[3 * r + 2] * b[c + 6];
+}
+
+/* dot4, config.h:36-38 */
+static inline float go_dot(const float a[3], const float b[3])
+{
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+
+/* normalize_cu, gipuma.cu:113-120 (rsqrtf -> M2) */
+static inline void go_normalize(float v[3])
+{
+    const float ns = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    const float inv = 1.0f / sqrtf(ns);
+    v[0] *= inv;
+    v[1] *= inv;
+    v[2] *= inv;
+}
+
+/* getViewVector_cu + get3Dpoint_cu1, gipuma.cu:80-89, 122-130 */
+static inline void go_view_vector(const gipuma_hip_camera *cam, int x, int y, float v[3])
+{
+    float pt[3];
+    pt[0] = (float)x - cam->P_col34[0];
+    pt[1] = (float)y - cam->P_col34[1];
+    pt[2] = 1.0f - cam->P_col34[2];
+    go_matvec(cam->M_inv, pt, v);
+    v[0] = v[0] - cam->C[0];
+    v[1] = v[1] - cam->C[1];
+    v[2] = v[2] - cam->C[2];
+    go_normalize(v);
+}
+
+void gipuma_oracle_view_vector(const gipuma_hip_camera *cam, int x, int y, float v[3])
+{
+    go_view_vector(cam, x, y, v);
+}
+
+/* vecOnHemisphere_cu, gipuma.cu:131-137 */
+static inline void go_on_hemisphere(float v[3], const float view[3])
+{
+    const float dp = go_dot(v, view);
+    if (dp > 0.0f) {
+        v[0] = -v[0];
+        v[1] = -v[1];
+        v[2] = -v[2];
+    }
+}
+
+/* getD_cu, gipuma.cu:96-111 */
+static inline float go_plane_d(const gipuma_hip_camera *cam, const float n[3], int x, int y,
+                               float depth)
+{
+    float pt[3], X[3];
+    pt[0] = depth * (float)x - cam->P_col34[0];
+    pt[1] = depth * (float)y - cam->P_col34[1];
+    pt[2] = depth - cam->P_col34[2];
+    go_matvec(cam->M_inv, pt, X);
+    return -(go_dot(n, X));
+}
+
+float gipuma_oracle_plane_d(const gipuma_hip_camera *cam, const float n[3], int x, int y,
+                            float depth)
+{
+    return go_plane_d(cam, n, x, y, depth);
+}
+
+/* getDisparity_cu / getDepthFromPlane3_cu, gipuma.cu:694-715 */
+static inline float go_depth_from_plane(const gipuma_hip_camera *cam, const float pl[4], int x,
+                                        int y)
+{
+    const float d = pl[3];
+    if (d != d) return 1000.0f;
+    return -d * cam->fx /
+           ((pl[0] * ((float)x - cam->K[2])) + (pl[1] * ((float)y - cam->K[5])) * cam->alpha +
+            pl[2] * cam->fx);
+}
+
+float gipuma_oracle_depth_from_plane(const gipuma_hip_camera *cam, const float plane[4], int x,
+                                     int y)
+{
+    return go_depth_from_plane(cam, plane, x, y);
+}
+
+/* disparityDepthConversion_cu, gipuma.cu:66-68 */
+static inline float go_disp_depth(float f, float baseline, float d) { return f * baseline / d; }
+
+/* getHomography_cu, gipuma.cu:339-356:  H = K_to * ((R_to - t_to n^T / d) * K_ref^-1) */
+static inline void go_homography(const gipuma_hip_camera *ref, const gipuma_hip_camera *to,
+                                 const float n[3], float dpl, float H[9])
+{
+    float tmp[9], tmp2[9];
+    /* outer_product4, config.h:85-94 */
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) tmp[3 * r + c] = to->t[r] * n[c];
+    /* matdivide, config.h:139-148 */
+    for (int k = 0; k < 9; k++) tmp[k] = tmp[k] / dpl;
+    /* matmatsub2, config.h:127-136 */
+    for (int k = 0; k < 9; k++) tmp[k] = to->R[k] - tmp[k];
+    go_matmul(tmp, ref->K_inv, tmp2);
+    go_matmul(to->K, tmp2, H);
+}
+
+void gipuma_oracle_homography(const gipuma_hip_camera *ref, const gipuma_hip_camera *to,
+                              const float n[3], float dpl, float H[9])
+{
+    go_homography(ref, to, n, dpl, H);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * M1: image access
+ * ---------------------------------------------------------------------------------------- */
+static inline int go_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* point sample with clamp-to-edge: tex2D(tex, i+0.5, j+0.5) of config.h:245-248 for integer
+ * (i,j); also what the shared-memory tile holds (gipuma.cu:1393-1402) */
+static inline float go_texel(const float *img, int rows, int cols, int pitch, int x, int y)
+{
+    x = go_clampi(x, 0, cols - 1);
+    y = go_clampi(y, 0, rows - 1);
+    return img[(size_t)y * (size_t)pitch + (size_t)x];
+}
+
+static inline float go_lerp(float a, float t0, float t1) { return fmaf(a, t1 - t0, t0); }
+
+/* The five bilinear taps of pmCostComputation_shared (gipuma.cu:251-253) at source position
+ * (x,y): out = { centre, x+1, x-1, y+1, y-1 }.  Model M1. */
+static inline void go_sample5(const float *img, int rows, int cols, int pitch, float x, float y,
+                              float out[5])
+{
+    const float fx0 = floorf(x), fy0 = floorf(y);
+    const float a = x - fx0, b = y - fy0;
+    /* keep the float->int conversion defined for huge / non-finite coordinates */
+    const int ix = (int)fminf(fmaxf(fx0, -2.0f), (float)cols);
+    const int iy = (int)fminf(fmaxf(fy0, -2.0f), (float)rows);
+    float t[4][4];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) t[r][c] = go_texel(img, rows, cols, pitch, ix - 1 + c, iy - 1 + r);
+    const float C0 = go_lerp(a, t[0][1], t[0][2]);
+    const float L1 = go_lerp(a, t[1][0], t[1][1]);
+    const float C1 = go_lerp(a, t[1][1], t[1][2]);
+    const float R1 = go_lerp(a, t[1][2], t[1][3]);
+    const float L2 = go_lerp(a, t[2][0], t[2][1]);
+    const float C2 = go_lerp(a, t[2][1], t[2][2]);
+    const float R2 = go_lerp(a, t[2][2], t[2][3]);
+    const float C3 = go_lerp(a, t[3][1], t[3][2]);
+    out[0] = go_lerp(b, C1, C2);
+    out[1] = go_lerp(b, R1, R2);
+    out[2] = go_lerp(b, L1, L2);
+    out[3] = go_lerp(b, C2, C3);
+    out[4] = go_lerp(b, C0, C1);
+}
+
+void gipuma_oracle_sample5(const float *img, int rows, int cols, int pitch, float x, float y,
+                           float out[5])
+{
+    go_sample5(img, rows, cols, pitch, x, y, out);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * patch cost of one view: pmCost_shared + pmCostComputation_shared, gipuma.cu:585-680, 223-277
+ * (pmCost/pmCostComputation, :455-518/:278-320, used by the init kernel, are the same function
+ * of the images -- SURVEY 3.4)
+ * ---------------------------------------------------------------------------------------- */
+static float go_view_cost(const gipuma_hip_desc *d, int view, int px, int py, const float pl[4])
+{
+    const gipuma_hip_params *ap = &d->params;
+    const int rows = d->rows, cols = d->cols, pitch = d->pitch;
+    const float *ref = d->images[0];
+    const float *src = d->images[view];
+    const int hRad = (ap->box_hsize - 1) / 2; /* gipuma.cu:1474 (init uses box/2, same for odd) */
+    const int vRad = (ap->box_vsize - 1) / 2;
+    const float alpha = ap->alpha, tau_color = ap->tau_color, tau_gradient = ap->tau_gradient;
+    const float gamma = ap->gamma;
+    const float oma = 1.f - alpha;
+
+    float H[9];
+    go_homography(&d->cameras[0], &d->cameras[view], pl, pl[3], H);
+
+    const float centre = go_texel(ref, rows, cols, pitch, px, py);
+    float cost = 0.0f;
+    for (int i = -hRad; i < hRad + 1; i += GO_WIN_INCREMENT) {
+        const float qx = (float)(px + i);
+        /* M3: H*(qx,qy,1) as fmaf(h1, qy, fmaf(h0, qx, h2)) (matvecmul4noz, config.h:150-162) */
+        const float X0 = fmaf(H[0], qx, H[2]);
+        const float Y0 = fmaf(H[3], qx, H[5]);
+        const float Z0 = fmaf(H[6], qx, H[8]);
+        for (int j = -vRad; j < vRad + 1; j += GO_WIN_INCREMENT) {
+            const int ix = px + i, iy = py + j;
+            const float qy = (float)iy;
+            /* weight_cu, gipuma.cu:186-193 */
+            const float leftValue = go_texel(ref, rows, cols, pitch, ix, iy);
+            const float colorDis = fabsf(leftValue - centre);
+            const float w = go_exp(-colorDis / gamma);
+            /* getCorrespondingPoint_cu, gipuma.cu:207-217 (M2: multiply by 1/z) */
+            const float X = fmaf(H[1], qy, X0);
+            const float Y = fmaf(H[4], qy, Y0);
+            const float Z = fmaf(H[7], qy, Z0);
+            const float rz = 1.0f / Z;
+            const float sx = X * rz, sy = Y * rz;
+            /* pmCostComputation_shared, gipuma.cu:251-274 */
+            float s[5];
+            go_sample5(src, rows, cols, pitch, sx, sy, s);
+            const float gx2 = s[1] - s[2];
+            const float gy2 = s[3] - s[4];
+            const float colDiff = fabsf(leftValue - s[0]);
+            const float up = go_texel(ref, rows, cols, pitch, ix, iy - 1);
+            const float down = go_texel(ref, rows, cols, pitch, ix, iy + 1);
+            const float left = go_texel(ref, rows, cols, pitch, ix - 1, iy);
+            const float right = go_texel(ref, rows, cols, pitch, ix + 1, iy);
+            const float gx1 = right - left;
+            const float gy1 = down - up;
+            const float gradX = gx1 - gx2;
+            const float gradY = gy1 - gy2;
+            const float gradDis = fminf((fabsf(gradX) + fabsf(gradY)) * 0.0625f, tau_gradient);
+            const float colDis = fminf(colDiff, tau_color);
+            const float dis = fmaf(alpha, gradDis, oma * colDis);
+            cost = fmaf(w, dis, cost);
+        }
+    }
+    return cost;
+}
+
+float gipuma_oracle_view_cost(const gipuma_hip_desc *d, int view, int x, int y,
+                              const float plane[4])
+{
+    return go_view_cost(d, view, x, y, plane);
+}
+
+/* sort_small, gipuma.cu:684-693 */
+static void go_sort_small(float *v, int n)
+{
+    for (int i = 1; i < n; i++) {
+        const float tmp = v[i];
+        int j;
+        for (j = i; j >= 1 && tmp < v[j - 1]; j--) v[j] = v[j - 1];
+        v[j] = tmp;
+    }
+}
+
+/* the combination half of pmCostMultiview_cu, gipuma.cu:769-805 */
+static float go_aggregate(const float *view_costs, int n, int cost_comb, int n_best,
+                          float good_factor)
+{
+    float cv[GIPUMA_HIP_MAX_VIEWS];
+    int numValid = 0;
+    for (int i = 0; i < n; i++) {
+        float c = view_costs[i];
+        if (c < GO_MAXCOST)
+            numValid++;
+        else
+            c = GO_MAXCOST;
+        cv[i] = c;
+    }
+    go_sort_small(cv, n);
+    int numBest = numValid;
+    if (cost_comb == GIPUMA_COMB_BEST_N) numBest = numBest < n_best ? numBest : n_best;
+    if (cost_comb == GIPUMA_COMB_GOOD) numBest = n;
+    const float costThresh = (n > 0 ? cv[0] : 0.0f) * good_factor;
+    int numConsidered = 0;
+    float cost = 0.0f;
+    for (int i = 0; i < numBest; i++) {
+        numConsidered++;
+        float c = cv[i];
+        if (cost_comb == GIPUMA_COMB_GOOD) c = fminf(c, costThresh);
+        cost = cost + c;
+    }
+    cost = cost / ((float)numConsidered);
+    if (numConsidered < 1) cost = GO_MAXCOST;
+    if (cost != cost || cost > GO_MAXCOST || cost < 0) cost = GO_MAXCOST;
+    return cost;
+}
+
+float gipuma_oracle_aggregate(const float *view_costs, int n, int cost_comb, int n_best,
+                              float good_factor)
+{
+    return go_aggregate(view_costs, n, cost_comb, n_best, good_factor);
+}
+
+/* pmCostMultiview_cu, gipuma.cu:720-806 */
+static float go_multiview_cost(const gipuma_hip_desc *d, int px, int py, const float pl[4])
+{
+    float cv[GIPUMA_HIP_MAX_VIEWS];
+    const int n = d->n_selected;
+    for (int i = 0; i < n; i++) cv[i] = go_view_cost(d, d->selected[i], px, py, pl);
+    return go_aggregate(cv, n, d->params.cost_comb, d->params.n_best, d->params.good_factor);
+}
+
+float gipuma_oracle_multiview_cost(const gipuma_hip_desc *d, int x, int y, const float plane[4])
+{
+    return go_multiview_cost(d, x, y, plane);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * per-pixel stages
+ * ---------------------------------------------------------------------------------------- */
+/* gipuma_init_cu2, gipuma.cu:996-1051 */
+static void go_init_pixel(const gipuma_hip_desc *d, int x, int y, float *norm4, float *cost)
+{
+    const gipuma_hip_camera *cam = &d->cameras[0];
+    const size_t center = (size_t)y * (size_t)d->cols + (size_t)x;
+    uint32_t draw = 0;
+    float view[3];
+    go_view_vector(cam, x, y, view);
+    /* curand_between(mind, maxd), gipuma.cu:1028 */
+    float disp = go_between(go_uniform(d->seed, 0, (uint32_t)x, (uint32_t)y, draw++),
+                            d->params.min_disparity, d->params.max_disparity);
+    /* rndUnitVectorSphereMarsaglia_cu, gipuma.cu:148-164 */
+    float rx = 1.0f, ry = 1.0f, sum = 2.0f;
+    while (sum >= 1.0f) {
+        rx = go_between(go_uniform(d->seed, 0, (uint32_t)x, (uint32_t)y, draw++), -1.0f, 1.0f);
+        ry = go_between(go_uniform(d->seed, 0, (uint32_t)x, (uint32_t)y, draw++), -1.0f, 1.0f);
+        sum = rx * rx + ry * ry;
+    }
+    const float sq = sqrtf(1.0f - sum);
+    float pl[4];
+    pl[0] = 2.0f * rx * sq;
+    pl[1] = 2.0f * ry * sq;
+    pl[2] = 1.0f - 2.0f * sum;
+    go_on_hemisphere(pl, view);
+    const float depth = go_disp_depth(cam->f, cam->baseline, disp);
+    pl[3] = go_plane_d(cam, pl, x, y, depth);
+    memcpy(norm4 + 4 * center, pl, sizeof pl);
+    cost[center] = go_multiview_cost(d, x, y, pl);
+}
+
+typedef struct {
+    float pl[4];
+    float cost;
+    float depth; /* disp_now of the reference kernels (it is a depth) */
+} go_pixel_state;
+
+/* spatialPropagation_cu, gipuma.cu:832-874 */
+static void go_try_neighbour(const gipuma_hip_desc *d, int x, int y, const float *norm4,
+                             size_t nb, go_pixel_state *st)
+{
+    const gipuma_hip_camera *cam = &d->cameras[0];
+    float cand[4];
+    memcpy(cand, norm4 + 4 * nb, sizeof cand);
+    const float depth_before = go_depth_from_plane(cam, cand, x, y);
+    const float cost_before = go_multiview_cost(d, x, y, cand);
+    if (depth_before >= cam->depth_min && depth_before <= cam->depth_max) {
+        if (cost_before < st->cost) {
+            st->depth = depth_before;
+            memcpy(st->pl, cand, sizeof cand);
+            st->cost = cost_before;
+        }
+    }
+}
+
+/* the neighbour tests of gipuma_checkerboard_spatialPropClose_cu (:1560-1582, distance 1)
+ * and ..._spatialPropFar_cu (:1437-1462, distance 5): up, down, left, right */
+static void go_propagate(const gipuma_hip_desc *d, int x, int y, const float *norm4, int dist,
+                         go_pixel_state *st)
+{
+    const int rows = d->rows, cols = d->cols;
+    const size_t center = (size_t)y * (size_t)cols + (size_t)x;
+    if (y > dist - 1) go_try_neighbour(d, x, y, norm4, center - (size_t)dist * (size_t)cols, st);
+    if (y < rows - dist) go_try_neighbour(d, x, y, norm4, center + (size_t)dist * (size_t)cols, st);
+    if (x > dist - 1) go_try_neighbour(d, x, y, norm4, center - (size_t)dist, st);
+    if (x < cols - dist) go_try_neighbour(d, x, y, norm4, center + (size_t)dist, st);
+}
+
+/* planeRefinement_cu + getRndDispAndUnitVector_cu, gipuma.cu:928-994, 890-927 */
+static void go_refine(const gipuma_hip_desc *d, int x, int y, uint32_t phase, go_pixel_state *st)
+{
+    const gipuma_hip_camera *cam = &d->cameras[0];
+    const gipuma_hip_params *ap = &d->params;
+    float view[3];
+    go_view_vector(cam, x, y, view);
+    float deltaN = 1.0f;
+    uint32_t draw = 0;
+    const float maxdisp = ap->max_disparity / 2.0f;
+    for (float deltaZ = maxdisp; deltaZ >= 0.01f; deltaZ = deltaZ / 10.0f) {
+        /* getRndDispAndUnitVector_cu */
+        const float disp = go_disp_depth(cam->f, cam->baseline, st->depth);
+        const float minDelta = -fminf(deltaZ, ap->min_disparity + disp); /* sic: '+', :909 */
+        const float maxDelta = fminf(deltaZ, ap->max_disparity - disp);
+        const float u0 = go_uniform(d->seed, phase, (uint32_t)x, (uint32_t)y, draw++);
+        const float u1 = go_uniform(d->seed, phase, (uint32_t)x, (uint32_t)y, draw++);
+        const float u2 = go_uniform(d->seed, phase, (uint32_t)x, (uint32_t)y, draw++);
+        const float u3 = go_uniform(d->seed, phase, (uint32_t)x, (uint32_t)y, draw++);
+        const float dz = go_between(u0, minDelta, maxDelta);
+        float dispOut = fminf(fmaxf(disp + dz, ap->min_disparity), ap->max_disparity);
+        const float depthOut = go_disp_depth(cam->f, cam->baseline, dispOut);
+        float cand[4];
+        cand[0] = st->pl[0] + go_between(u1, -deltaN, deltaN);
+        cand[1] = st->pl[1] + go_between(u2, -deltaN, deltaN);
+        cand[2] = st->pl[2] + go_between(u3, -deltaN, deltaN);
+        go_normalize(cand);
+        go_on_hemisphere(cand, view);
+        /* planeRefinement_cu body */
+        cand[3] = go_plane_d(cam, cand, x, y, depthOut);
+        const float c = go_multiview_cost(d, x, y, cand);
+        if (c < st->cost) {
+            st->cost = c;
+            st->depth = depthOut;
+            memcpy(st->pl, cand, sizeof cand);
+        }
+        deltaN = deltaN / 4.0f;
+    }
+}
+
+int gipuma_oracle_refine_schedule(float max_disparity, float *delta_z, float *delta_n, int cap)
+{
+    int k = 0;
+    float deltaN = 1.0f;
+    for (float deltaZ = max_disparity / 2.0f; deltaZ >= 0.01f; deltaZ = deltaZ / 10.0f) {
+        if (k < cap) {
+            delta_z[k] = deltaZ;
+            delta_n[k] = deltaN;
+        }
+        k++;
+        deltaN = deltaN / 4.0f;
+    }
+    return k;
+}
+
+/* one pixel of one colour kernel: read state, run the requested stages, write back
+ * (gipuma.cu:1527-1530 read, :1585-1587 write) */
+static void go_sweep_pixel(const gipuma_hip_desc *d, int x, int y, float *norm4, float *cost,
+                           uint32_t phase, unsigned stages)
+{
+    const size_t center = (size_t)y * (size_t)d->cols + (size_t)x;
+    go_pixel_state st;
+    memcpy(st.pl, norm4 + 4 * center, sizeof st.pl);
+    st.cost = cost[center];
+    st.depth = go_depth_from_plane(&d->cameras[0], st.pl, x, y);
+    if (stages & GIPUMA_STAGE_CLOSE) go_propagate(d, x, y, norm4, 1, &st);
+    if (stages & GIPUMA_STAGE_FAR) go_propagate(d, x, y, norm4, 5, &st);
+    if (stages & GIPUMA_STAGE_REFINE) {
+        /* the refine kernel re-derives disp_now from the stored plane, gipuma.cu:1660 */
+        st.depth = go_depth_from_plane(&d->cameras[0], st.pl, x, y);
+        go_refine(d, x, y, phase, &st);
+    }
+    cost[center] = st.cost;
+    memcpy(norm4 + 4 * center, st.pl, sizeof st.pl);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * whole-image passes
+ * ---------------------------------------------------------------------------------------- */
+static int go_check(const gipuma_hip_desc *d)
+{
+    if (!d || d->abi_version != GIPUMA_HIP_ABI_VERSION) return GIPUMA_HIP_ERR_ARG;
+    if (d->rows < 1 || d->cols < 1 || d->channels != 1 || d->pitch < d->cols)
+        return GIPUMA_HIP_ERR_ARG;
+    if (d->n_images < 1 || !d->images || !d->cameras) return GIPUMA_HIP_ERR_ARG;
+    if (d->n_selected < 0 || d->n_selected > GIPUMA_HIP_MAX_VIEWS) return GIPUMA_HIP_ERR_ARG;
+    for (int i = 0; i < d->n_selected; i++)
+        if (d->selected[i] < 0 || d->selected[i] >= d->n_images) return GIPUMA_HIP_ERR_ARG;
+    if (d->params.box_hsize < 1 || d->params.box_vsize < 1 || !(d->params.box_hsize & 1) ||
+        !(d->params.box_vsize & 1))
+        return GIPUMA_HIP_ERR_ARG;
+    return 0;
+}
+
+int gipuma_oracle_init_planes(const gipuma_hip_desc *d, float *norm4, float *cost)
+{
+    int rc = go_check(d);
+    if (rc) return rc;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < d->rows; y++)
+        for (int x = 0; x < d->cols; x++) go_init_pixel(d, x, y, norm4, cost);
+    return 0;
+}
+
+int gipuma_oracle_sweep(const gipuma_hip_desc *d, float *norm4, float *cost, int iteration,
+                        int colour, unsigned stages, int unfused)
+{
+    int rc = go_check(d);
+    if (rc) return rc;
+    const uint32_t phase = go_phase(iteration, colour);
+    /* black <=> (x+y) even, gipuma.cu:1730-1734; every pixel of a colour only reads pixels of
+     * the other colour (distance 1 and 5 are odd), so the pixel order is free */
+    if (unfused) {
+        static const unsigned order[3] = {GIPUMA_STAGE_CLOSE, GIPUMA_STAGE_FAR,
+                                          GIPUMA_STAGE_REFINE};
+        for (int k = 0; k < 3; k++) {
+            if (!(stages & order[k])) continue;
+#pragma omp parallel for schedule(dynamic, 4)
+            for (int y = 0; y < d->rows; y++)
+                for (int x = (y + colour) & 1; x < d->cols; x += 2)
+                    go_sweep_pixel(d, x, y, norm4, cost, phase, order[k]);
+        }
+    } else {
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int y = 0; y < d->rows; y++)
+            for (int x = (y + colour) & 1; x < d->cols; x += 2)
+                go_sweep_pixel(d, x, y, norm4, cost, phase, stages);
+    }
+    return 0;
+}
+
+/* gipuma_compute_disp, gipuma.cu:1080-1103 */
+int gipuma_oracle_finalize(const gipuma_hip_desc *d, float *norm4, const float *cost)
+{
+    int rc = go_check(d);
+    if (rc) return rc;
+    const gipuma_hip_camera *cam = &d->cameras[0];
+#pragma omp parallel for
+    for (int y = 0; y < d->rows; y++)
+        for (int x = 0; x < d->cols; x++) {
+            const size_t center = (size_t)y * (size_t)d->cols + (size_t)x;
+            float pl[4], out[4];
+            memcpy(pl, norm4 + 4 * center, sizeof pl);
+            go_matvec(cam->R_orig_inv, pl, out);
+            if (cost[center] != GO_MAXCOST)
+                out[3] = go_depth_from_plane(cam, pl, x, y);
+            else
+                out[3] = 0;
+            memcpy(norm4 + 4 * center, out, sizeof out);
+        }
+    return 0;
+}
+
+int gipuma_oracle_eval_cost(const gipuma_hip_desc *d, const float *planes, float *cost_out)
+{
+    int rc = go_check(d);
+    if (rc) return rc;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < d->rows; y++)
+        for (int x = 0; x < d->cols; x++) {
+            const size_t center = (size_t)y * (size_t)d->cols + (size_t)x;
+            cost_out[center] = go_multiview_cost(d, x, y, planes + 4 * center);
+        }
+    return 0;
+}
+
+/* gipuma<T>(), gipuma.cu:1906-1944 */
+int gipuma_oracle_run(const gipuma_hip_desc *d, float *norm4, float *cost, int unfused)
+{
+    int rc = gipuma_oracle_init_planes(d, norm4, cost);
+    if (rc) return rc;
+    for (int it = 0; it < d->params.iterations; it++) {
+        gipuma_oracle_sweep(d, norm4, cost, it, GIPUMA_BLACK, GIPUMA_STAGE_ALL, unfused);
+        gipuma_oracle_sweep(d, norm4, cost, it, GIPUMA_RED, GIPUMA_STAGE_ALL, unfused);
+    }
+    return gipuma_oracle_finalize(d, norm4, cost);
+}
+
+static double go_now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int gipuma_oracle_time(const gipuma_hip_desc *d, int n_iter_timed, double *sec_init,
+                       double *sec_sweeps)
+{
+    int rc = go_check(d);
+    if (rc) return rc;
+    const size_t np = (size_t)d->rows * (size_t)d->cols;
+    float *norm4 = (float *)malloc(np * 4 * sizeof(float));
+    float *cost = (float *)malloc(np * sizeof(float));
+    if (!norm4 || !cost) {
+        free(norm4);
+        free(cost);
+        return GIPUMA_HIP_ERR_ARG;
+    }
+    double t0 = go_now();
+    gipuma_oracle_init_planes(d, norm4, cost);
+    double t1 = go_now();
+    for (int it = 0; it < n_iter_timed; it++) {
+        gipuma_oracle_sweep(d, norm4, cost, it, GIPUMA_BLACK, GIPUMA_STAGE_ALL, 0);
+        gipuma_oracle_sweep(d, norm4, cost, it, GIPUMA_RED, GIPUMA_STAGE_ALL, 0);
+    }
+    double t2 = go_now();
+    if (sec_init) *sec_init = t1 - t0;
+    if (sec_sweeps) *sec_sweeps = t2 - t1;
+    free(norm4);
+    free(cost);
+    return 0;
+}
+
+int gipuma_oracle_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
