@@ -1,0 +1,486 @@
+// gipuma_hip.hip -- C-ABI (include/gipuma_hip.h) over the gfx950 kernels in pm_device.h.
+//
+// Host side of what the reference does in gipuma<T>() (gipuma.cu:1825-1960): validate, make the
+// problem resident in HBM, launch init / red-black sweeps / finalize on one HIP stream, time with
+// HIP events.  Differences from the reference that are deliberate:
+//   * one launch per colour (close+far+refine fused, result-identical, see sweep_kernel) and no
+//     host synchronisation between launches (the reference calls cudaDeviceSynchronize after
+//     each of its 6 launches per iteration, gipuma.cu:1916-1936);
+//   * cameras are packed once into one POD block read through scalar loads, instead of the
+//     ~3600 managed allocations the reference dereferences on the device (camera.h:45-51);
+//   * no per-pixel RNG state array (48 B/pixel, gipuma.cu:1840): the RNG is counter based.
+#include "../../include/gipuma_hip.h"
+#include "pm_device.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, const char *a = "", const char *b = "")
+{
+    char buf[512];
+    snprintf(buf, sizeof buf, fmt, a, b);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_OK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return fail(GIPUMA_HIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+}  // namespace
+
+struct gipuma_hip_session {
+    int device = 0;
+    int rows = 0, cols = 0, n_sel = 0, iterations = 0;
+    pm::Problem hp{};
+    pm::Problem *dp = nullptr;
+    float4 *norm4 = nullptr;
+    float *cost = nullptr;
+    std::vector<float *> owned;  // device copies of host images
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool lut = false;        // reference image integer valued in [0,255] -> weight table
+    bool combine_reg = false;
+    bool unfused = false;
+    int box = 0;             // specialised window size, 0 = runtime
+    unsigned tune = 0;
+    size_t lds_sweep = 0, lds_dense = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+namespace {
+
+using pm::Tune;
+
+typedef void (*sweep_fn)(const pm::Problem *, float4 *, float *, int, uint32_t, unsigned, unsigned);
+typedef void (*init_fn)(const pm::Problem *, float4 *, float *, unsigned);
+
+template <int BOX>
+sweep_fn pick_sweep_box(bool lut, bool creg)
+{
+    if (lut) return creg ? pm::sweep_kernel<BOX, true, true, true> : pm::sweep_kernel<BOX, true, false, true>;
+    return creg ? pm::sweep_kernel<BOX, false, true, true> : pm::sweep_kernel<BOX, false, false, true>;
+}
+
+sweep_fn pick_sweep(const gipuma_hip_session *s)
+{
+    if (s->tune & Tune::kNoInterior) {  // A/B switch, generic window only
+        if (s->box == 15 && s->lut && s->combine_reg) return pm::sweep_kernel<15, true, true, false>;
+        return s->lut ? pm::sweep_kernel<0, true, false, false> : pm::sweep_kernel<0, false, false, false>;
+    }
+    switch (s->box) {
+    case 11: return pick_sweep_box<11>(s->lut, s->combine_reg);
+    case 15: return pick_sweep_box<15>(s->lut, s->combine_reg);
+    case 25: return pick_sweep_box<25>(s->lut, s->combine_reg);
+    default: return pick_sweep_box<0>(s->lut, s->combine_reg);
+    }
+}
+
+template <bool GEN>
+init_fn pick_init(const gipuma_hip_session *s)
+{
+    switch (s->box) {
+    case 11: return s->lut ? pm::init_kernel<11, true, false, GEN> : pm::init_kernel<11, false, false, GEN>;
+    case 15: return s->lut ? pm::init_kernel<15, true, false, GEN> : pm::init_kernel<15, false, false, GEN>;
+    case 25: return s->lut ? pm::init_kernel<25, true, false, GEN> : pm::init_kernel<25, false, false, GEN>;
+    default: return s->lut ? pm::init_kernel<0, true, false, GEN> : pm::init_kernel<0, false, false, GEN>;
+    }
+}
+
+int validate(const gipuma_hip_desc *d)
+{
+    if (!d) return fail(GIPUMA_HIP_ERR_ARG, "null descriptor");
+    if (d->abi_version != GIPUMA_HIP_ABI_VERSION) return fail(GIPUMA_HIP_ERR_ARG, "abi_version mismatch");
+    if (d->rows < 1 || d->cols < 1) return fail(GIPUMA_HIP_ERR_ARG, "rows/cols must be positive");
+    if ((long long)d->rows * (long long)d->pitch >= (1LL << 29))
+        return fail(GIPUMA_HIP_ERR_ARG, "image too large for 32-bit texel offsets");
+    if (d->channels != 1)
+        return fail(GIPUMA_HIP_ERR_UNSUPPORTED, "only gray (channels == 1) is built; colour is SURVEY 8f row N3");
+    if (d->pitch < d->cols) return fail(GIPUMA_HIP_ERR_ARG, "pitch < cols");
+    if (d->n_images < 1 || d->n_images > 512 || !d->images || !d->cameras)
+        return fail(GIPUMA_HIP_ERR_ARG, "images/cameras missing");
+    if (d->n_selected < 0 || d->n_selected > GIPUMA_HIP_MAX_VIEWS || (d->n_selected > 0 && !d->selected))
+        return fail(GIPUMA_HIP_ERR_ARG, "n_selected must be 0..32 (gipuma.cu:736)");
+    for (int i = 0; i < d->n_selected; i++)
+        if (d->selected[i] < 0 || d->selected[i] >= d->n_images || !d->images[d->selected[i]])
+            return fail(GIPUMA_HIP_ERR_ARG, "selected view out of range");
+    if (!d->images[0]) return fail(GIPUMA_HIP_ERR_ARG, "reference image missing");
+    const gipuma_hip_params &p = d->params;
+    if (p.box_hsize < 1 || p.box_vsize < 1 || !(p.box_hsize & 1) || !(p.box_vsize & 1))
+        return fail(GIPUMA_HIP_ERR_ARG, "box sizes must be odd (main.cpp:269-276)");
+    if (p.box_hsize > 49 || p.box_vsize > 49) return fail(GIPUMA_HIP_ERR_UNSUPPORTED, "box size > 49");
+    if (p.iterations < 0) return fail(GIPUMA_HIP_ERR_ARG, "iterations < 0");
+    return 0;
+}
+
+void copy9(float *dst, const float *src) { memcpy(dst, src, 9 * sizeof(float)); }
+void copy3(float *dst, const float *src) { memcpy(dst, src, 3 * sizeof(float)); }
+
+// is every reference-image value an integer in [0,255]? (then w = exp(-|dI|/gamma) has 256 values)
+bool integer_valued(const float *img, int rows, int cols, int pitch)
+{
+    for (int y = 0; y < rows; y++) {
+        const float *r = img + (size_t)y * pitch;
+        for (int x = 0; x < cols; x++) {
+            const float v = r[x];
+            if (!(v >= 0.0f && v <= 255.0f) || v != std::floor(v)) return false;
+        }
+    }
+    return true;
+}
+
+size_t lds_bytes(const gipuma_hip_session *s, int tile_h, bool with_cv)
+{
+    const int hw = (s->hp.box_h + 1) / 2, hh = (s->hp.box_v + 1) / 2;
+    size_t n = pm::kLutSize + (size_t)(pm::kTileW + 2 * hw) * (size_t)(tile_h + 2 * hh);
+    if (with_cv) n += (size_t)s->n_sel * pm::kThreads;
+    return n * sizeof(float);
+}
+
+int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stages)
+{
+    const int gx = (s->cols + pm::kTileW - 1) / pm::kTileW;
+    const int gy = (s->rows + pm::kSweepTileH - 1) / pm::kSweepTileH;
+    const uint32_t phase = 1u + 2u * (uint32_t)iteration + (uint32_t)colour;
+    sweep_fn k = pick_sweep(s);
+    hipLaunchKernelGGL(k, dim3(gx * gy), dim3(pm::kThreads), s->lds_sweep, s->stream, s->dp, s->norm4,
+                       s->cost, colour, phase, stages, s->tune);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int launch_dense(gipuma_hip_session *s, bool generate, float4 *planes, float *cost_out)
+{
+    const int gx = (s->cols + pm::kTileW - 1) / pm::kTileW;
+    const int gy = (s->rows + pm::kDenseTileH - 1) / pm::kDenseTileH;
+    init_fn k = generate ? pick_init<true>(s) : pick_init<false>(s);
+    hipLaunchKernelGGL(k, dim3(gx * gy), dim3(pm::kThreads), s->lds_dense, s->stream, s->dp, planes,
+                       cost_out, s->tune);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gipuma_hip_version(void) { return GIPUMA_HIP_ABI_VERSION; }
+
+const char *gipuma_hip_last_error(void) { return g_err.c_str(); }
+
+int gipuma_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
+{
+    if (!out) return fail(GIPUMA_HIP_ERR_ARG, "null out pointer");
+    *out = nullptr;
+    int rc = validate(d);
+    if (rc) return rc;
+    if (gipuma_hip_device_count() < 1)
+        return fail(GIPUMA_HIP_ERR_NO_DEVICE, "no HIP device visible; this library has no CPU fallback");
+    if (d->device_id < 0 || d->device_id >= gipuma_hip_device_count())
+        return fail(GIPUMA_HIP_ERR_ARG, "device_id out of range");
+    gipuma_hip_session *s = new (std::nothrow) gipuma_hip_session;
+    if (!s) return fail(GIPUMA_HIP_ERR_DEVICE, "out of host memory");
+    // from here on, destroy() cleans up whatever was built
+#define CREATE_OK(expr)                        \
+    do {                                       \
+        hipError_t e_ = (expr);                \
+        if (e_ != hipSuccess) {                \
+            fail(GIPUMA_HIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+            std::string keep = g_err;          \
+            gipuma_hip_destroy(s);             \
+            g_err = keep;                      \
+            return GIPUMA_HIP_ERR_DEVICE;      \
+        }                                      \
+    } while (0)
+    s->device = d->device_id;
+    CREATE_OK(hipSetDevice(s->device));
+    s->rows = d->rows;
+    s->cols = d->cols;
+    s->n_sel = d->n_selected;
+    s->iterations = d->params.iterations;
+    s->unfused = (d->flags & GIPUMA_HIP_FLAG_UNFUSED) != 0;
+    if (const char *t = getenv("GIPUMA_HIP_TUNE")) s->tune = (unsigned)strtoul(t, nullptr, 0);
+    if (d->stream) {
+        s->stream = (hipStream_t)d->stream;
+    } else {
+        CREATE_OK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        s->own_stream = true;
+    }
+    for (auto &e : s->ev) CREATE_OK(hipEventCreate(&e));
+
+    const bool on_device = (d->flags & GIPUMA_HIP_FLAG_IMAGES_ON_DEVICE) != 0;
+    const size_t np = (size_t)d->rows * (size_t)d->cols;
+    pm::Problem &hp = s->hp;
+    hp.rows = d->rows;
+    hp.cols = d->cols;
+    hp.pitch = on_device ? d->pitch : d->cols;
+    hp.n_sel = d->n_selected;
+    hp.box_h = d->params.box_hsize;
+    hp.box_v = d->params.box_vsize;
+    hp.n_best = d->params.n_best;
+    hp.cost_comb = d->params.cost_comb;
+    hp.alpha = d->params.alpha;
+    hp.tau_color = d->params.tau_color;
+    hp.tau_gradient = d->params.tau_gradient;
+    hp.gamma = d->params.gamma;
+    hp.min_disp = d->params.min_disparity;
+    hp.max_disp = d->params.max_disparity;
+    hp.good_factor = d->params.good_factor;
+    hp.seed = d->seed;
+
+    // images: bind resident planes, or upload the reference + the selected views (compact pitch)
+    auto resident = [&](int idx, const float **dst) -> hipError_t {
+        if (on_device) {
+            *dst = d->images[idx];
+            return hipSuccess;
+        }
+        float *p = nullptr;
+        hipError_t e = hipMalloc(&p, np * sizeof(float));
+        if (e != hipSuccess) return e;
+        s->owned.push_back(p);
+        *dst = p;
+        return hipMemcpy2DAsync(p, (size_t)d->cols * sizeof(float), d->images[idx],
+                                (size_t)d->pitch * sizeof(float), (size_t)d->cols * sizeof(float),
+                                (size_t)d->rows, hipMemcpyHostToDevice, s->stream);
+    };
+    CREATE_OK(resident(0, &hp.ref));
+    for (int i = 0; i < d->n_selected; i++) CREATE_OK(resident(d->selected[i], &hp.view[i].img));
+
+    // weight table only if the reference image is integer valued (8-bit input, main.cpp:941)
+    {
+        std::vector<float> tmp;
+        const float *host_ref = d->images[0];
+        int host_pitch = d->pitch;
+        if (on_device) {
+            tmp.resize(np);
+            CREATE_OK(hipMemcpy2D(tmp.data(), (size_t)d->cols * sizeof(float), d->images[0],
+                                  (size_t)d->pitch * sizeof(float), (size_t)d->cols * sizeof(float),
+                                  (size_t)d->rows, hipMemcpyDeviceToHost));
+            host_ref = tmp.data();
+            host_pitch = d->cols;
+        }
+        s->lut = integer_valued(host_ref, d->rows, d->cols, host_pitch) && !(s->tune & Tune::kNoLut);
+    }
+
+    // cameras -> one POD block
+    const gipuma_hip_camera &c0 = d->cameras[0];
+    copy9(hp.rc.K_inv, c0.K_inv);
+    copy9(hp.rc.M_inv, c0.M_inv);
+    copy9(hp.rc.R_orig_inv, c0.R_orig_inv);
+    copy3(hp.rc.P_col34, c0.P_col34);
+    copy3(hp.rc.C, c0.C);
+    hp.rc.fx = c0.fx;
+    hp.rc.cx = c0.K[2];  // cam.K[2], cam.K[2+3] in getDepthFromPlane3_cu, gipuma.cu:699-701
+    hp.rc.cy = c0.K[5];
+    hp.rc.alpha = c0.alpha;
+    hp.rc.f = c0.f;
+    hp.rc.baseline = c0.baseline;
+    hp.rc.depth_min = c0.depth_min;
+    hp.rc.depth_max = c0.depth_max;
+    for (int i = 0; i < d->n_selected; i++) {
+        const gipuma_hip_camera &c = d->cameras[d->selected[i]];
+        copy9(hp.view[i].K, c.K);
+        copy9(hp.view[i].R, c.R);
+        copy3(hp.view[i].t, c.t);
+    }
+    CREATE_OK(hipMalloc(&s->dp, sizeof(pm::Problem)));
+    CREATE_OK(hipMemcpyAsync(s->dp, &hp, sizeof(pm::Problem), hipMemcpyHostToDevice, s->stream));
+
+    // state planes, zero-filled like LineState::resize (linestate.h:16-24)
+    CREATE_OK(hipMalloc(&s->norm4, np * sizeof(float4)));
+    CREATE_OK(hipMalloc(&s->cost, np * sizeof(float)));
+    CREATE_OK(hipMemsetAsync(s->norm4, 0, np * sizeof(float4), s->stream));
+    CREATE_OK(hipMemsetAsync(s->cost, 0, np * sizeof(float), s->stream));
+
+    // kernel variant
+    s->box = 0;
+    if (hp.box_h == hp.box_v && !(s->tune & Tune::kGenericBox) &&
+        (hp.box_h == 11 || hp.box_h == 15 || hp.box_h == 25))
+        s->box = hp.box_h;
+    s->combine_reg = hp.cost_comb == GIPUMA_COMB_BEST_N && hp.n_best >= 1 && hp.n_best <= 4 &&
+                     !(s->tune & Tune::kGenericCombine);
+    if ((s->tune & Tune::kNoInterior) && !(s->box == 15 && s->lut && s->combine_reg)) {
+        s->box = 0;  // the no-interior A/B arm only exists for these two variants
+        s->combine_reg = false;
+    }
+    s->lds_sweep = lds_bytes(s, pm::kSweepTileH, !s->combine_reg);
+    s->lds_dense = lds_bytes(s, pm::kDenseTileH, true);
+    CREATE_OK(hipStreamSynchronize(s->stream));  // host image buffers may be released by the caller
+#undef CREATE_OK
+    *out = s;
+    return 0;
+}
+
+int gipuma_hip_destroy(gipuma_hip_session *s)
+{
+    if (!s) return 0;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (float *p : s->owned) (void)hipFree(p);
+    if (s->dp) (void)hipFree(s->dp);
+    if (s->norm4) (void)hipFree(s->norm4);
+    if (s->cost) (void)hipFree(s->cost);
+    for (auto &e : s->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+    return 0;
+}
+
+int gipuma_hip_init_planes(gipuma_hip_session *s)
+{
+    if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
+    HIP_OK(hipSetDevice(s->device));
+    return launch_dense(s, true, s->norm4, s->cost);
+}
+
+int gipuma_hip_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stages)
+{
+    if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
+    if (iteration < 0 || (colour != GIPUMA_BLACK && colour != GIPUMA_RED) || (stages & ~7u))
+        return fail(GIPUMA_HIP_ERR_ARG, "bad iteration/colour/stages");
+    HIP_OK(hipSetDevice(s->device));
+    if (s->unfused) {  // the reference's three launches per colour, gipuma.cu:1915-1923
+        for (unsigned st = 1; st <= 4; st <<= 1)
+            if (stages & st) {
+                int rc = launch_sweep(s, iteration, colour, st);
+                if (rc) return rc;
+            }
+        return 0;
+    }
+    return stages ? launch_sweep(s, iteration, colour, stages) : 0;
+}
+
+int gipuma_hip_finalize(gipuma_hip_session *s)
+{
+    if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
+    HIP_OK(hipSetDevice(s->device));
+    const int n = s->rows * s->cols;
+    hipLaunchKernelGGL(pm::finalize_kernel, dim3((n + pm::kThreads - 1) / pm::kThreads), dim3(pm::kThreads), 0,
+                       s->stream, s->dp, s->norm4, s->cost);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int gipuma_hip_eval_cost(gipuma_hip_session *s, const float *planes_host, float *cost_out_host)
+{
+    if (!s || !planes_host || !cost_out_host) return fail(GIPUMA_HIP_ERR_ARG, "null argument");
+    HIP_OK(hipSetDevice(s->device));
+    const size_t np = (size_t)s->rows * (size_t)s->cols;
+    float4 *pl = nullptr;
+    float *c = nullptr;
+    HIP_OK(hipMalloc(&pl, np * sizeof(float4)));
+    hipError_t e = hipMalloc(&c, np * sizeof(float));
+    if (e != hipSuccess) {
+        (void)hipFree(pl);
+        return fail(GIPUMA_HIP_ERR_DEVICE, "hipMalloc: %s", hipGetErrorString(e));
+    }
+    int rc = 0;
+    e = hipMemcpyAsync(pl, planes_host, np * sizeof(float4), hipMemcpyHostToDevice, s->stream);
+    if (e == hipSuccess) rc = launch_dense(s, false, pl, c);
+    if (e == hipSuccess && !rc)
+        e = hipMemcpyAsync(cost_out_host, c, np * sizeof(float), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess && !rc) e = hipStreamSynchronize(s->stream);
+    (void)hipFree(pl);
+    (void)hipFree(c);
+    if (e != hipSuccess) return fail(GIPUMA_HIP_ERR_DEVICE, "eval_cost: %s", hipGetErrorString(e));
+    return rc;
+}
+
+int gipuma_hip_get_state(gipuma_hip_session *s, float *norm4_host, float *cost_host)
+{
+    if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
+    HIP_OK(hipSetDevice(s->device));
+    const size_t np = (size_t)s->rows * (size_t)s->cols;
+    if (norm4_host)
+        HIP_OK(hipMemcpyAsync(norm4_host, s->norm4, np * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+    if (cost_host)
+        HIP_OK(hipMemcpyAsync(cost_host, s->cost, np * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    HIP_OK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+int gipuma_hip_set_state(gipuma_hip_session *s, const float *norm4_host, const float *cost_host)
+{
+    if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
+    HIP_OK(hipSetDevice(s->device));
+    const size_t np = (size_t)s->rows * (size_t)s->cols;
+    if (norm4_host)
+        HIP_OK(hipMemcpyAsync(s->norm4, norm4_host, np * sizeof(float4), hipMemcpyHostToDevice, s->stream));
+    if (cost_host)
+        HIP_OK(hipMemcpyAsync(s->cost, cost_host, np * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    HIP_OK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+int gipuma_hip_state_device_ptrs(gipuma_hip_session *s, float **norm4_dev, float **cost_dev)
+{
+    if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
+    if (norm4_dev) *norm4_dev = (float *)s->norm4;
+    if (cost_dev) *cost_dev = s->cost;
+    return 0;
+}
+
+int gipuma_hip_solve(gipuma_hip_session *s, gipuma_hip_timing *timing)
+{
+    if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
+    HIP_OK(hipSetDevice(s->device));
+    int rc;
+    int launches = 0;
+    HIP_OK(hipEventRecord(s->ev[0], s->stream));
+    if ((rc = gipuma_hip_init_planes(s))) return rc;
+    HIP_OK(hipEventRecord(s->ev[1], s->stream));
+    for (int it = 0; it < s->iterations; it++) {  // gipuma.cu:1911-1941
+        if ((rc = gipuma_hip_sweep(s, it, GIPUMA_BLACK, GIPUMA_STAGE_ALL))) return rc;
+        if ((rc = gipuma_hip_sweep(s, it, GIPUMA_RED, GIPUMA_STAGE_ALL))) return rc;
+        launches += s->unfused ? 6 : 2;
+    }
+    HIP_OK(hipEventRecord(s->ev[2], s->stream));
+    if ((rc = gipuma_hip_finalize(s))) return rc;
+    HIP_OK(hipEventRecord(s->ev[3], s->stream));
+    if (timing) {
+        HIP_OK(hipEventSynchronize(s->ev[3]));
+        HIP_OK(hipEventElapsedTime(&timing->ms_init, s->ev[0], s->ev[1]));
+        HIP_OK(hipEventElapsedTime(&timing->ms_sweeps, s->ev[1], s->ev[2]));
+        HIP_OK(hipEventElapsedTime(&timing->ms_finalize, s->ev[2], s->ev[3]));
+        HIP_OK(hipEventElapsedTime(&timing->ms_total, s->ev[0], s->ev[3]));
+        timing->n_sweep_launches = launches;
+        timing->ms_sweep_avg = launches ? timing->ms_sweeps / (float)launches : 0.0f;
+    }
+    return 0;
+}
+
+int gipuma_hip_run(const gipuma_hip_desc *desc, float *norm4_out, float *cost_out, gipuma_hip_timing *timing)
+{
+    gipuma_hip_session *s = nullptr;
+    int rc = gipuma_hip_create(desc, &s);
+    if (rc) return rc;
+    gipuma_hip_timing t{};
+    rc = gipuma_hip_solve(s, &t);
+    if (!rc) rc = gipuma_hip_get_state(s, norm4_out, cost_out);
+    if (timing) *timing = t;
+    std::string keep = g_err;
+    gipuma_hip_destroy(s);
+    g_err = keep;
+    return rc;
+}
+
+}  // extern "C"

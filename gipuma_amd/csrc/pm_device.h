@@ -1,0 +1,595 @@
+// pm_device.h -- device code of the red-black PatchMatch path for gfx950 (MI355X).
+//
+// Written for CDNA4 directly: 64-wide wavefronts, one lane per pixel of the active checkerboard
+// colour, the reference-image tile staged in LDS, camera constants wave-uniform (scalar loads),
+// source views read with software bilinear filtering (gfx950 has no image instructions,
+// SURVEY.md F1).  No MFMA: the patch cost is a small stencil reduction (BASELINE.json).
+//
+// The arithmetic follows the numerical model M1-M4 stated at the top of oracle/gipuma_oracle.c
+// (and DESIGN.md 3); build with -ffp-contract=off so only the fmaf() written here fuse.  The
+// reference functions each piece stands for are cited by file:line of reference gipuma.cu.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pm {
+
+constexpr float kMaxCost = 1000.0f;  // config.h:22
+constexpr int kMaxViews = 32;        // gipuma.cu:736
+constexpr int kThreads = 256;        // 4 wavefronts per workgroup
+constexpr int kTileW = 32;           // pixels per tile row (both colours)
+constexpr int kSweepTileH = 16;      // 32x16 tile, 256 pixels of one colour
+constexpr int kDenseTileH = 8;       // 32x8 tile, all 256 pixels (init / eval / finalize)
+
+struct RefCam {  // Camera_cu of view 0, camera.h:7-62
+    float K_inv[9], M_inv[9], R_orig_inv[9];
+    float P_col34[3], C[3];
+    float fx, cx, cy, alpha, f, baseline, depth_min, depth_max;
+};
+struct ViewCam {  // Camera_cu of a selected source view + its image plane
+    float K[9], R[9], t[3];
+    int pad;
+    const float *img;
+};
+struct Problem {  // lives in device memory, read through scalar loads (wave-uniform)
+    int rows, cols, pitch, n_sel;
+    int box_h, box_v, n_best, cost_comb;
+    float alpha, tau_color, tau_gradient, gamma;
+    float min_disp, max_disp, good_factor;
+    uint32_t seed;
+    const float *ref;
+    RefCam rc;
+    ViewCam view[kMaxViews];
+};
+
+// ---------------------------------------------------------------------------------------------
+// M4: counter-based uniform in (0,1] (stands in for curand_uniform, gipuma.cu:138-141)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t h)
+{
+    h ^= h >> 16;
+    h *= 0x7feb352dU;
+    h ^= h >> 15;
+    h *= 0x846ca68bU;
+    h ^= h >> 16;
+    return h;
+}
+// the (seed, phase, y, x) prefix is hashed once per pixel, the draw index per number
+__device__ __forceinline__ uint32_t rng_prefix(uint32_t seed, uint32_t phase, uint32_t x, uint32_t y)
+{
+    uint32_t h = mix32(seed + 0x9E3779B9U);
+    h = mix32(h ^ (phase + 0x85EBCA6BU));
+    h = mix32(h ^ (y + 0xC2B2AE35U));
+    h = mix32(h ^ (x + 0x27D4EB2FU));
+    return h;
+}
+__device__ __forceinline__ float rng_uniform(uint32_t prefix, uint32_t draw)
+{
+    const uint32_t h = mix32(prefix ^ (draw + 0x165667B1U));
+    return (float)((h >> 8) + 1U) * 5.9604644775390625e-8f;
+}
+__device__ __forceinline__ float between(float u, float lo, float hi) { return u * (hi - lo) + lo; }
+
+// ---------------------------------------------------------------------------------------------
+// M2: exp of the adaptive support weight (weight_cu, gipuma.cu:186-193)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float exp_model(float x)
+{
+    if (!(x >= -86.0f)) return 0.0f;
+    if (x > 86.0f) x = 86.0f;
+    const float n = __builtin_rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693359375f, x);
+    r = __builtin_fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    const float e = __builtin_fmaf(p, r * r, r) + 1.0f;
+    return __int_as_float(__float_as_int(e) + (((int)n) << 23));
+}
+
+// ---------------------------------------------------------------------------------------------
+// planes and rays (reference-camera frame)
+// ---------------------------------------------------------------------------------------------
+struct Vec3 {
+    float x, y, z;
+};
+
+// matvecmul4, config.h:163-176
+__device__ __forceinline__ Vec3 matvec(const float *m, Vec3 v)
+{
+    Vec3 o;
+    o.x = m[0] * v.x + m[1] * v.y + m[2] * v.z;
+    o.y = m[3] * v.x + m[4] * v.y + m[5] * v.z;
+    o.z = m[6] * v.x + m[7] * v.y + m[8] * v.z;
+    return o;
+}
+__device__ __forceinline__ float dot3(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// normalize_cu, gipuma.cu:113-120 (rsqrtf -> 1/sqrtf, M2)
+__device__ __forceinline__ Vec3 normalize3(Vec3 v)
+{
+    const float ns = v.x * v.x + v.y * v.y + v.z * v.z;
+    const float inv = 1.0f / __builtin_sqrtf(ns);
+    v.x *= inv;
+    v.y *= inv;
+    v.z *= inv;
+    return v;
+}
+// getViewVector_cu, gipuma.cu:80-89, 122-130
+__device__ __forceinline__ Vec3 view_vector(const RefCam &rc, int x, int y)
+{
+    Vec3 pt;
+    pt.x = (float)x - rc.P_col34[0];
+    pt.y = (float)y - rc.P_col34[1];
+    pt.z = 1.0f - rc.P_col34[2];
+    Vec3 v = matvec(rc.M_inv, pt);
+    v.x = v.x - rc.C[0];
+    v.y = v.y - rc.C[1];
+    v.z = v.z - rc.C[2];
+    return normalize3(v);
+}
+// vecOnHemisphere_cu, gipuma.cu:131-137
+__device__ __forceinline__ Vec3 on_hemisphere(Vec3 v, Vec3 view)
+{
+    if (dot3(v, view) > 0.0f) {
+        v.x = -v.x;
+        v.y = -v.y;
+        v.z = -v.z;
+    }
+    return v;
+}
+// getD_cu, gipuma.cu:96-111
+__device__ __forceinline__ float plane_d(const RefCam &rc, Vec3 n, int x, int y, float depth)
+{
+    Vec3 pt;
+    pt.x = depth * (float)x - rc.P_col34[0];
+    pt.y = depth * (float)y - rc.P_col34[1];
+    pt.z = depth - rc.P_col34[2];
+    const Vec3 X = matvec(rc.M_inv, pt);
+    return -(dot3(n, X));
+}
+// getDisparity_cu / getDepthFromPlane3_cu, gipuma.cu:694-715
+__device__ __forceinline__ float depth_from_plane(const RefCam &rc, float4 pl, int x, int y)
+{
+    const float d = pl.w;
+    if (d != d) return 1000.0f;
+    return -d * rc.fx /
+           ((pl.x * ((float)x - rc.cx)) + (pl.y * ((float)y - rc.cy)) * rc.alpha + pl.z * rc.fx);
+}
+// disparityDepthConversion_cu, gipuma.cu:66-68
+__device__ __forceinline__ float disp_depth(float f, float baseline, float d) { return f * baseline / d; }
+
+// getHomography_cu, gipuma.cu:339-356:  H = K_to * ((R_to - t_to n^T / d) * K_ref^-1).
+// K, R, t, K_inv are wave-uniform (SGPR operands); n, d are per lane.
+__device__ __forceinline__ void homography(const float *Kinv_ref, const ViewCam &to, float4 pl, float *H)
+{
+    float a[9], b[9];
+    const float n[3] = {pl.x, pl.y, pl.z};
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) a[3 * r + c] = to.R[3 * r + c] - (to.t[r] * n[c]) / pl.w;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            b[3 * r + c] = a[3 * r] * Kinv_ref[c] + a[3 * r + 1] * Kinv_ref[c + 3] + a[3 * r + 2] * Kinv_ref[c + 6];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            H[3 * r + c] = to.K[3 * r] * b[c] + to.K[3 * r + 1] * b[c + 3] + to.K[3 * r + 2] * b[c + 6];
+}
+
+__device__ __forceinline__ float lerp(float a, float t0, float t1) { return __builtin_fmaf(a, t1 - t0, t0); }
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+// ---------------------------------------------------------------------------------------------
+// LDS layout of a workgroup.  One __shared__ array; the kernels carve it:
+//   [0, 256)                     support-weight table  w(k) = exp(-k/gamma), k = |dI| = 0..255
+//   [256, 256 + tw*th)           reference-image tile with halo R = (box+1)/2 (gipuma.cu:1844-1855)
+//   [.., + n_sel*256)            per-lane view-cost columns (only for the generic combiner)
+// ---------------------------------------------------------------------------------------------
+constexpr int kLutSize = 256;
+
+template <int BOX>
+struct Win {  // window geometry: compile-time for the shipped block sizes, runtime for BOX == 0
+    int bh, bv;
+    __device__ __forceinline__ Win(const Problem *P) : bh(P->box_h), bv(P->box_v) {}
+    __device__ __forceinline__ int hrad() const { return BOX ? (BOX - 1) / 2 : (bh - 1) / 2; }
+    __device__ __forceinline__ int vrad() const { return BOX ? (BOX - 1) / 2 : (bv - 1) / 2; }
+    __device__ __forceinline__ int halo_w() const { return BOX ? (BOX + 1) / 2 : (bh + 1) / 2; }
+    __device__ __forceinline__ int halo_h() const { return BOX ? (BOX + 1) / 2 : (bv + 1) / 2; }
+};
+
+// inner (y) sample loop unrolling: full for the small windows, rolled for box 25 (13 samples per
+// column would need > 256 VGPRs) and for the runtime-sized window
+template <int BOX>
+__host__ __device__ constexpr int unroll_j()
+{
+    return BOX == 0 ? 1 : (BOX <= 15 ? (BOX + 1) / 2 : 1);
+}
+
+struct Tune {  // experiment switches (GIPUMA_HIP_TUNE), all default off
+    static constexpr unsigned kNoLut = 1, kNoInterior = 2, kNoXcdRemap = 4, kGenericBox = 8,
+                              kGenericCombine = 16;
+};
+
+// Patch cost of one source view: pmCost_shared + pmCostComputation_shared,
+// gipuma.cu:585-680 and :223-277.  `tp0` points at the pixel's own texel inside the LDS tile.
+template <int BOX, bool LUT, bool INTERIOR>
+__device__ __forceinline__ float view_cost(const Problem *__restrict__ P, const ViewCam &vc,
+                                           const float *__restrict__ tp0, int tw,
+                                           const float *__restrict__ lut, int px, int py, float4 pl,
+                                           const Win<BOX> &win)
+{
+    float H[9];
+    homography(P->rc.K_inv, vc, pl, H);
+    const float *__restrict__ img = vc.img;
+    const int rows = P->rows, cols = P->cols, pitch = P->pitch;
+    const float colsf = (float)cols, rowsf = (float)rows;
+    const float alpha = P->alpha, oma = 1.f - P->alpha;
+    const float tau_color = P->tau_color, tau_gradient = P->tau_gradient, gamma = P->gamma;
+    const float centre = tp0[0];
+    const int hr = win.hrad(), vr = win.vrad();
+    float cost = 0.0f;
+    for (int i = -hr; i <= hr; i += 2) {
+        const float qx = (float)(px + i);
+        const float X0 = __builtin_fmaf(H[0], qx, H[2]);
+        const float Y0 = __builtin_fmaf(H[3], qx, H[5]);
+        const float Z0 = __builtin_fmaf(H[6], qx, H[8]);
+#pragma unroll unroll_j<BOX>()
+        for (int j = -vr; j <= vr; j += 2) {
+            const float *tp = tp0 + j * tw + i;
+            const float qy = (float)(py + j);
+            // weight_cu, gipuma.cu:186-193
+            const float leftValue = tp[0];
+            const float colorDis = __builtin_fabsf(leftValue - centre);
+            float w;
+            if (LUT)
+                w = lut[(int)colorDis];  // reference image is integer valued in [0,255]
+            else
+                w = exp_model(-colorDis / gamma);
+            // getCorrespondingPoint_cu, gipuma.cu:207-217
+            const float X = __builtin_fmaf(H[1], qy, X0);
+            const float Y = __builtin_fmaf(H[4], qy, Y0);
+            const float Z = __builtin_fmaf(H[7], qy, Z0);
+            const float rz = 1.0f / Z;
+            const float sx = X * rz, sy = Y * rz;
+            // M1: five bilinear taps sharing one 4x4 texel window (gipuma.cu:251-253)
+            const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
+            const float a = sx - fx0, b = sy - fy0;
+            const int ix = (int)__builtin_fminf(__builtin_fmaxf(fx0, -2.0f), colsf);
+            const int iy = (int)__builtin_fminf(__builtin_fmaxf(fy0, -2.0f), rowsf);
+            float t01, t02, t10, t11, t12, t13, t20, t21, t22, t23, t31, t32;
+            const bool inside = ix >= 1 && ix <= cols - 3 && iy >= 1 && iy <= rows - 3;
+            if (INTERIOR && __all(inside)) {
+                const float *s = img + (iy * pitch + ix);
+                t01 = s[-pitch];
+                t02 = s[-pitch + 1];
+                t10 = s[-1];
+                t11 = s[0];
+                t12 = s[1];
+                t13 = s[2];
+                t20 = s[pitch - 1];
+                t21 = s[pitch];
+                t22 = s[pitch + 1];
+                t23 = s[pitch + 2];
+                t31 = s[2 * pitch];
+                t32 = s[2 * pitch + 1];
+            } else {
+                const int c0 = clampi(ix - 1, 0, cols - 1), c1 = clampi(ix, 0, cols - 1);
+                const int c2 = clampi(ix + 1, 0, cols - 1), c3 = clampi(ix + 2, 0, cols - 1);
+                const int r0 = clampi(iy - 1, 0, rows - 1) * pitch, r1 = clampi(iy, 0, rows - 1) * pitch;
+                const int r2 = clampi(iy + 1, 0, rows - 1) * pitch, r3 = clampi(iy + 2, 0, rows - 1) * pitch;
+                t01 = img[r0 + c1];
+                t02 = img[r0 + c2];
+                t10 = img[r1 + c0];
+                t11 = img[r1 + c1];
+                t12 = img[r1 + c2];
+                t13 = img[r1 + c3];
+                t20 = img[r2 + c0];
+                t21 = img[r2 + c1];
+                t22 = img[r2 + c2];
+                t23 = img[r2 + c3];
+                t31 = img[r3 + c1];
+                t32 = img[r3 + c2];
+            }
+            const float C0 = lerp(a, t01, t02);
+            const float L1 = lerp(a, t10, t11), C1 = lerp(a, t11, t12), R1 = lerp(a, t12, t13);
+            const float L2 = lerp(a, t20, t21), C2 = lerp(a, t21, t22), R2 = lerp(a, t22, t23);
+            const float C3 = lerp(a, t31, t32);
+            const float sc = lerp(b, C1, C2);
+            const float gx2 = lerp(b, R1, R2) - lerp(b, L1, L2);
+            const float gy2 = lerp(b, C2, C3) - lerp(b, C0, C1);
+            // pmCostComputation_shared, gipuma.cu:251-274
+            const float colDiff = __builtin_fabsf(leftValue - sc);
+            const float gx1 = tp[1] - tp[-1];
+            const float gy1 = tp[tw] - tp[-tw];
+            const float gradX = gx1 - gx2;
+            const float gradY = gy1 - gy2;
+            const float gradDis =
+                __builtin_fminf((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
+            const float colDis = __builtin_fminf(colDiff, tau_color);
+            const float dis = __builtin_fmaf(alpha, gradDis, oma * colDis);
+            cost = __builtin_fmaf(w, dis, cost);
+        }
+    }
+    return cost;
+}
+
+// pmCostMultiview_cu, gipuma.cu:720-806.  COMBINE_REG: best-N with n_best <= 4 keeps the four
+// smallest view costs in registers (a sorting-network insert per view, same values and the same
+// ascending summation order as sort_small + the loop at :781-797); otherwise the view costs go
+// through a per-lane LDS column and the literal insertion sort.
+template <int BOX, bool LUT, bool INTERIOR, bool COMBINE_REG>
+__device__ __forceinline__ float multiview_cost(const Problem *__restrict__ P, const float *__restrict__ tp0,
+                                                int tw, const float *__restrict__ lut, float *cv, int px,
+                                                int py, float4 pl, const Win<BOX> &win)
+{
+    const int n = P->n_sel;
+    int numValid = 0;
+    float b0 = kMaxCost, b1 = kMaxCost, b2 = kMaxCost, b3 = kMaxCost;
+    for (int v = 0; v < n; v++) {
+        float c = view_cost<BOX, LUT, INTERIOR>(P, P->view[v], tp0, tw, lut, px, py, pl, win);
+        if (c < kMaxCost)
+            numValid++;
+        else
+            c = kMaxCost;
+        if (COMBINE_REG) {
+            float t = c, lo;
+            lo = __builtin_fminf(b0, t); t = __builtin_fmaxf(b0, t); b0 = lo;
+            lo = __builtin_fminf(b1, t); t = __builtin_fmaxf(b1, t); b1 = lo;
+            lo = __builtin_fminf(b2, t); t = __builtin_fmaxf(b2, t); b2 = lo;
+            b3 = __builtin_fminf(b3, t);
+        } else {
+            // sort_small (gipuma.cu:684-693) as an online insertion into the lane's column
+            int j = v;
+            for (; j >= 1 && c < cv[(j - 1) * kThreads]; j--) cv[j * kThreads] = cv[(j - 1) * kThreads];
+            cv[j * kThreads] = c;
+        }
+    }
+    float cost = 0.0f;
+    int numConsidered = 0;
+    if (COMBINE_REG) {
+        const int numBest = min(numValid, P->n_best);
+        if (numBest > 0) cost = cost + b0;
+        if (numBest > 1) cost = cost + b1;
+        if (numBest > 2) cost = cost + b2;
+        if (numBest > 3) cost = cost + b3;
+        numConsidered = numBest;
+    } else {
+        int numBest = numValid;
+        if (P->cost_comb == 1) numBest = min(numBest, P->n_best);  // COMB_BEST_N
+        if (P->cost_comb == 3) numBest = n;                        // COMB_GOOD
+        const float costThresh = (n > 0 ? cv[0] : 0.0f) * P->good_factor;
+        for (int i = 0; i < numBest; i++) {
+            numConsidered++;
+            float c = cv[i * kThreads];
+            if (P->cost_comb == 3) c = __builtin_fminf(c, costThresh);
+            cost = cost + c;
+        }
+    }
+    cost = cost / ((float)numConsidered);
+    if (numConsidered < 1) cost = kMaxCost;
+    if (cost != cost || cost > kMaxCost || cost < 0) cost = kMaxCost;
+    return cost;
+}
+
+// ---------------------------------------------------------------------------------------------
+// workgroup helpers
+// ---------------------------------------------------------------------------------------------
+// Workgroup id -> tile id.  Workgroups are dealt round-robin to the 8 XCDs (b % 8); giving each
+// XCD one contiguous band of tiles keeps neighbouring tiles' source-image footprints in one L2.
+__device__ __forceinline__ int tile_id(int b, int nblk, bool remap)
+{
+    if (!remap || nblk < 8) return b;
+    const int xcd = b & 7, local = b >> 3;
+    const int q = nblk >> 3, r = nblk & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
+// stage the reference tile (+halo) and the weight table; the tile holds clamp-to-edge point
+// samples exactly like the reference's (gipuma.cu:1393-1402, 1513-1522)
+template <int BOX>
+__device__ __forceinline__ void stage_tile(const Problem *__restrict__ P, float *lds, int x0, int y0,
+                                           int tile_h, const Win<BOX> &win, bool want_lut)
+{
+    const int hw = win.halo_w(), hh = win.halo_h();
+    const int tw = kTileW + 2 * hw, th = tile_h + 2 * hh;
+    const float *__restrict__ ref = P->ref;
+    float *tile = lds + kLutSize;
+    for (int k = threadIdx.x; k < tw * th; k += kThreads) {
+        const int ty = k / tw, tx = k - ty * tw;
+        const int gx = clampi(x0 - hw + tx, 0, P->cols - 1);
+        const int gy = clampi(y0 - hh + ty, 0, P->rows - 1);
+        tile[k] = ref[gy * P->pitch + gx];
+    }
+    if (want_lut) lds[threadIdx.x] = exp_model(-(float)threadIdx.x / P->gamma);
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+// gipuma_init_cu2 (gipuma.cu:996-1051) when GENERATE, else the cost of a given plane field
+// (gipuma_initial_cost, :1052-1079).  32x8 tile, one lane per pixel.
+template <int BOX, bool LUT, bool COMBINE_REG, bool GENERATE>
+__global__ __launch_bounds__(kThreads) void init_kernel(const Problem *__restrict__ P,
+                                                        float4 *__restrict__ norm4, float *__restrict__ cost,
+                                                        unsigned tune)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const Win<BOX> win(P);
+    const int gx = (P->cols + kTileW - 1) / kTileW;
+    const int gy = (P->rows + kDenseTileH - 1) / kDenseTileH;
+    const int t = tile_id(blockIdx.x, gx * gy, !(tune & Tune::kNoXcdRemap));
+    const int x0 = (t % gx) * kTileW, y0 = (t / gx) * kDenseTileH;
+    stage_tile<BOX>(P, lds, x0, y0, kDenseTileH, win, LUT);
+    const int hw = win.halo_w(), hh = win.halo_h();
+    const int tw = kTileW + 2 * hw;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int px = x0 + lx, py = y0 + ly;
+    if (px >= P->cols || py >= P->rows) return;
+    const float *tp0 = lds + kLutSize + (ly + hh) * tw + (lx + hw);
+    float *cv = lds + kLutSize + tw * (kDenseTileH + 2 * hh) + threadIdx.x;
+    const int center = py * P->cols + px;
+    float4 pl;
+    if (GENERATE) {
+        const RefCam &rc = P->rc;
+        const uint32_t pre = rng_prefix(P->seed, 0u, (uint32_t)px, (uint32_t)py);
+        uint32_t draw = 0;
+        const Vec3 view = view_vector(rc, px, py);
+        const float disp = between(rng_uniform(pre, draw++), P->min_disp, P->max_disp);
+        // rndUnitVectorSphereMarsaglia_cu, gipuma.cu:148-164
+        float rx = 1.0f, ry = 1.0f, sum = 2.0f;
+        while (sum >= 1.0f) {
+            rx = between(rng_uniform(pre, draw++), -1.0f, 1.0f);
+            ry = between(rng_uniform(pre, draw++), -1.0f, 1.0f);
+            sum = rx * rx + ry * ry;
+        }
+        const float sq = __builtin_sqrtf(1.0f - sum);
+        Vec3 n;
+        n.x = 2.0f * rx * sq;
+        n.y = 2.0f * ry * sq;
+        n.z = 1.0f - 2.0f * sum;
+        n = on_hemisphere(n, view);
+        const float depth = disp_depth(rc.f, rc.baseline, disp);
+        pl = make_float4(n.x, n.y, n.z, plane_d(rc, n, px, py, depth));
+        norm4[center] = pl;
+    } else {
+        pl = norm4[center];
+    }
+    float c;
+    if (tune & Tune::kNoInterior)
+        c = multiview_cost<BOX, LUT, false, COMBINE_REG>(P, tp0, tw, lds, cv, px, py, pl, win);
+    else
+        c = multiview_cost<BOX, LUT, true, COMBINE_REG>(P, tp0, tw, lds, cv, px, py, pl, win);
+    cost[center] = c;
+}
+
+// One colour of one iteration: the bodies of gipuma_checkerboard_spatialPropClose_cu
+// (gipuma.cu:1471-1588), ..._spatialPropFar_cu (:1353-1468) and ..._planeRefinement_cu
+// (:1590-1711) run back to back on the same lane.  Fusing them is result-identical: every pixel
+// of a colour reads only its own state and pixels of the OTHER colour (distances 1 and 5 are odd,
+// :1730-1734), which no lane of this launch writes.  `stages` selects a subset so the three
+// reference launches can also be reproduced one by one.
+template <int BOX, bool LUT, bool COMBINE_REG, bool INTERIOR>
+__global__ __launch_bounds__(kThreads) void sweep_kernel(const Problem *__restrict__ P,
+                                                         float4 *__restrict__ norm4, float *__restrict__ cost,
+                                                         int colour, uint32_t phase, unsigned stages,
+                                                         unsigned tune)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const Win<BOX> win(P);
+    const RefCam &rc = P->rc;
+    const int rows = P->rows, cols = P->cols;
+    const int gx = (cols + kTileW - 1) / kTileW;
+    const int gy = (rows + kSweepTileH - 1) / kSweepTileH;
+    const int t = tile_id(blockIdx.x, gx * gy, !(tune & Tune::kNoXcdRemap));
+    const int x0 = (t % gx) * kTileW, y0 = (t / gx) * kSweepTileH;
+    stage_tile<BOX>(P, lds, x0, y0, kSweepTileH, win, LUT);
+    const int hw = win.halo_w(), hh = win.halo_h();
+    const int tw = kTileW + 2 * hw;
+    // lane -> pixel: 16 pixels of the colour per tile row; a wavefront covers 4 rows x 32 columns
+    const int ly = threadIdx.x >> 4;
+    const int lx = 2 * (threadIdx.x & 15) + ((ly + colour) & 1);  // tile origin is even in x and y
+    const int px = x0 + lx, py = y0 + ly;
+    if (px >= cols || py >= rows) return;
+    const float *tp0 = lds + kLutSize + (ly + hh) * tw + (lx + hw);
+    float *cv = lds + kLutSize + tw * (kSweepTileH + 2 * hh) + threadIdx.x;
+    const int center = py * cols + px;
+
+    // read state (gipuma.cu:1527-1530)
+    float4 pl = norm4[center];
+    float cst = cost[center];
+    float depth = depth_from_plane(rc, pl, px, py);
+
+    // spatial propagation: k = 0..3 distance 1, k = 4..7 distance 5; up, down, left, right
+    for (int k = 0; k < 8; k++) {
+        const int dist = k < 4 ? 1 : 5;
+        if (!(stages & (k < 4 ? 1u : 2u))) continue;
+        bool ok;
+        int nb;
+        switch (k & 3) {
+        case 0: ok = py > dist - 1; nb = center - dist * cols; break;
+        case 1: ok = py < rows - dist; nb = center + dist * cols; break;
+        case 2: ok = px > dist - 1; nb = center - dist; break;
+        default: ok = px < cols - dist; nb = center + dist; break;
+        }
+        if (ok) {
+            // spatialPropagation_cu, gipuma.cu:832-874
+            const float4 cand = norm4[nb];
+            const float d_before = depth_from_plane(rc, cand, px, py);
+            const float c_before =
+                multiview_cost<BOX, LUT, INTERIOR, COMBINE_REG>(P, tp0, tw, lds, cv, px, py, cand, win);
+            if (d_before >= rc.depth_min && d_before <= rc.depth_max && c_before < cst) {
+                depth = d_before;
+                pl = cand;
+                cst = c_before;
+            }
+        }
+    }
+
+    if (stages & 4u) {
+        // planeRefinement_cu + getRndDispAndUnitVector_cu, gipuma.cu:928-994, 890-927
+        depth = depth_from_plane(rc, pl, px, py);  // the refine kernel re-derives it, :1660
+        const Vec3 view = view_vector(rc, px, py);
+        const uint32_t pre = rng_prefix(P->seed, phase, (uint32_t)px, (uint32_t)py);
+        uint32_t draw = 0;
+        float deltaN = 1.0f;
+        const float min_disp = P->min_disp, max_disp = P->max_disp;
+        for (float deltaZ = max_disp / 2.0f; deltaZ >= 0.01f; deltaZ = deltaZ / 10.0f) {
+            const float disp = disp_depth(rc.f, rc.baseline, depth);
+            const float minDelta = -__builtin_fminf(deltaZ, min_disp + disp);  // sic, :909
+            const float maxDelta = __builtin_fminf(deltaZ, max_disp - disp);
+            const float u0 = rng_uniform(pre, draw++);
+            const float u1 = rng_uniform(pre, draw++);
+            const float u2 = rng_uniform(pre, draw++);
+            const float u3 = rng_uniform(pre, draw++);
+            const float dz = between(u0, minDelta, maxDelta);
+            const float dispOut = __builtin_fminf(__builtin_fmaxf(disp + dz, min_disp), max_disp);
+            const float depthOut = disp_depth(rc.f, rc.baseline, dispOut);
+            Vec3 n;
+            n.x = pl.x + between(u1, -deltaN, deltaN);
+            n.y = pl.y + between(u2, -deltaN, deltaN);
+            n.z = pl.z + between(u3, -deltaN, deltaN);
+            n = on_hemisphere(normalize3(n), view);
+            const float4 cand = make_float4(n.x, n.y, n.z, plane_d(rc, n, px, py, depthOut));
+            const float c =
+                multiview_cost<BOX, LUT, INTERIOR, COMBINE_REG>(P, tp0, tw, lds, cv, px, py, cand, win);
+            if (c < cst) {
+                cst = c;
+                depth = depthOut;
+                pl = cand;
+            }
+            deltaN = deltaN / 4.0f;
+        }
+    }
+
+    // write back (gipuma.cu:1585-1587): 16 B + 4 B per active pixel
+    cost[center] = cst;
+    norm4[center] = pl;
+}
+
+// gipuma_compute_disp, gipuma.cu:1080-1103
+__global__ __launch_bounds__(kThreads) void finalize_kernel(const Problem *__restrict__ P,
+                                                            float4 *__restrict__ norm4,
+                                                            const float *__restrict__ cost)
+{
+    const int n = P->rows * P->cols;
+    const int center = blockIdx.x * kThreads + threadIdx.x;
+    if (center >= n) return;
+    const int py = center / P->cols, px = center - py * P->cols;
+    const float4 pl = norm4[center];
+    Vec3 v = {pl.x, pl.y, pl.z};
+    const Vec3 w = matvec(P->rc.R_orig_inv, v);
+    float depth = 0.0f;
+    if (cost[center] != kMaxCost) depth = depth_from_plane(P->rc, pl, px, py);
+    norm4[center] = make_float4(w.x, w.y, w.z, depth);
+}
+
+}  // namespace pm

@@ -698,6 +698,50 @@ int gipuma_oracle_time(const gipuma_hip_desc *d, int n_iter_timed, double *sec_i
     return 0;
 }
 
+/* cpu_baseline leg of bench.py on a BOUNDED sample: init for rows [y0-5, y1+5), then one
+ * iteration (black + red, all stages) over rows [y0, y1) only.  Work per pixel is the same for
+ * every row and every iteration, so full-frame time = rows/(y1-y0) *
+ * (sec_init_band + iterations * sec_iter_band). */
+int gipuma_oracle_time_band(const gipuma_hip_desc *d, int y0, int y1, double *sec_init_band,
+                            double *sec_iter_band)
+{
+    int rc = go_check(d);
+    if (rc) return rc;
+    if (y0 < 0 || y1 > d->rows || y0 >= y1) return GIPUMA_HIP_ERR_ARG;
+    const size_t np = (size_t)d->rows * (size_t)d->cols;
+    float *norm4 = (float *)calloc(np * 4, sizeof(float));
+    float *cost = (float *)calloc(np, sizeof(float));
+    if (!norm4 || !cost) {
+        free(norm4);
+        free(cost);
+        return GIPUMA_HIP_ERR_ARG;
+    }
+    const int ya = y0 - 5 < 0 ? 0 : y0 - 5, yb = y1 + 5 > d->rows ? d->rows : y1 + 5;
+    /* halo rows (untimed) */
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int y = ya; y < yb; y++)
+        if (y < y0 || y >= y1)
+            for (int x = 0; x < d->cols; x++) go_init_pixel(d, x, y, norm4, cost);
+    double t0 = go_now();
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int y = y0; y < y1; y++)
+        for (int x = 0; x < d->cols; x++) go_init_pixel(d, x, y, norm4, cost);
+    double t1 = go_now();
+    for (int colour = 0; colour < 2; colour++) {
+        const uint32_t phase = go_phase(0, colour);
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int y = y0; y < y1; y++)
+            for (int x = (y + colour) & 1; x < d->cols; x += 2)
+                go_sweep_pixel(d, x, y, norm4, cost, phase, GIPUMA_STAGE_ALL);
+    }
+    double t2 = go_now();
+    if (sec_init_band) *sec_init_band = t1 - t0;
+    if (sec_iter_band) *sec_iter_band = t2 - t1;
+    free(norm4);
+    free(cost);
+    return 0;
+}
+
 int gipuma_oracle_num_threads(void)
 {
 #ifdef _OPENMP

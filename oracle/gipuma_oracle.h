@@ -38,6 +38,8 @@ int gipuma_oracle_eval_cost(const gipuma_hip_desc *d, const float *planes, float
  * spent in init / sweeps via the two out-params */
 int gipuma_oracle_time(const gipuma_hip_desc *d, int n_iter_timed, double *sec_init,
                        double *sec_sweeps);
+int gipuma_oracle_time_band(const gipuma_hip_desc *d, int y0, int y1, double *sec_init_band,
+                            double *sec_iter_band);
 int gipuma_oracle_num_threads(void);
 
 /* ---- unit pieces, exported for the known-answer tests ---- */

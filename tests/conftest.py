@@ -1,0 +1,34 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from tests import oracle_lib
+    return oracle_lib.lib()
+
+
+@pytest.fixture(scope="session")
+def tiny_problem():
+    """64x48 DTU-geometry problem, 3 source views, box 7, 2 iterations"""
+    from gipuma_amd import synth
+    return synth.build_problem(synth.tiny_config())
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """the HIP library on a box with a GPU; a missing library or device is an ERROR, not a skip"""
+    from gipuma_amd import abi
+    lib = abi.load_library()
+    assert lib.gipuma_hip_device_count() >= 1, "no HIP device visible to the gpu-marked tests"
+    return lib

@@ -33,6 +33,8 @@ def lib():
         L.gipuma_oracle_finalize.argtypes = [D, _FP, _FP]
         L.gipuma_oracle_eval_cost.argtypes = [D, _FP, _FP]
         L.gipuma_oracle_time.argtypes = [D, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.gipuma_oracle_time_band.argtypes = [D, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                              C.POINTER(C.c_double)]
         L.gipuma_oracle_exp.argtypes = [C.c_float]
         L.gipuma_oracle_exp.restype = C.c_float
         L.gipuma_oracle_uniform.argtypes = [C.c_uint32] * 5

@@ -1,0 +1,252 @@
+"""Parity of the HIP path (through the C-ABI) with the CPU oracle on the same seeded inputs.
+
+The bar is bit-exact: the numerical model (oracle/gipuma_oracle.c header) fixes every
+rounding, so norm4 and cost planes must be identical as uint32.  That is stronger than the
+north_star's 1e-4 relative depth / 1e-3 normal tolerance, and it is what makes a parity statement
+through PatchMatch's argmin chain meaningful (an ulp flips a near-tie).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from gipuma_amd import abi, synth
+from gipuma_amd.problem import Session, runcuda
+from tests.oracle_lib import OracleState
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_same(a, b, what):
+    a, b = bits(a), bits(b)
+    if not np.array_equal(a, b):
+        bad = np.argwhere(a != b)
+        fa = a.view(np.float32)[tuple(bad[0])]
+        fb = b.view(np.float32)[tuple(bad[0])]
+        raise AssertionError("%s: %d of %d values differ, first at %s: %r vs %r"
+                             % (what, len(bad), a.size, tuple(bad[0]), fa, fb))
+
+
+def random_planes(gs, seed=7):
+    """plausible random planes: unit normals facing the camera, d from a depth inside the range"""
+    rng = np.random.default_rng(seed)
+    n = rng.normal(size=(gs.rows, gs.cols, 3)).astype(np.float32)
+    n[..., 2] = -np.abs(n[..., 2]) - 0.5
+    n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    depth = rng.uniform(gs.params.depthMin * 1.2, gs.params.depthMax * 0.8,
+                        size=(gs.rows, gs.cols)).astype(np.float32)
+    pl = np.empty((gs.rows, gs.cols, 4), dtype=np.float32)
+    pl[..., :3] = n
+    # d = -n.X with X ~ depth * K^-1 (x, y, 1): close enough to getD_cu for a test input
+    fx = gs.cameras.c_array[0].fx
+    cx, cy = gs.cameras.c_array[0].K[2], gs.cameras.c_array[0].K[5]
+    xs, ys = np.meshgrid(np.arange(gs.cols, dtype=np.float32), np.arange(gs.rows, dtype=np.float32))
+    X = np.stack([(xs - cx) / fx * depth, (ys - cy) / fx * depth, depth], axis=-1)
+    pl[..., 3] = -(n * X).sum(-1)
+    return pl
+
+
+def test_eval_cost_bit_exact(hip, tiny_problem):
+    """kernel-level parity: cost of a GIVEN plane field (no argmin chain), pmCostMultiview_cu"""
+    gs, _ = tiny_problem
+    planes = random_planes(gs)
+    with Session(gs) as s:
+        got = s.eval_cost(planes)
+    want = OracleState(gs).eval_cost(planes)
+    assert_same(got, want, "eval_cost")
+    assert (want < abi.MAXCOST).mean() > 0.9
+
+
+def test_init_bit_exact(hip, tiny_problem):
+    gs, _ = tiny_problem
+    with Session(gs) as s:
+        s.init_planes()
+        n4, c = s.get_state()
+    o = OracleState(gs)
+    o.init_planes()
+    assert_same(n4, o.norm4, "init norm4")
+    assert_same(c, o.cost, "init cost")
+
+
+def test_stage_by_stage_bit_exact(hip, tiny_problem):
+    """every launch of the reference's schedule (gipuma.cu:1915-1935), compared after each one"""
+    gs, _ = tiny_problem
+    o = OracleState(gs)
+    o.init_planes()
+    with Session(gs) as s:
+        s.set_state(o.norm4, o.cost)
+        for it in range(2):
+            for colour in (abi.BLACK, abi.RED):
+                for stage in (abi.STAGE_CLOSE, abi.STAGE_FAR, abi.STAGE_REFINE):
+                    s.sweep(it, colour, stage)
+                    o.sweep(it, colour, stage)
+                    n4, c = s.get_state()
+                    assert_same(n4, o.norm4, "it %d colour %d stage %d norm4" % (it, colour, stage))
+                    assert_same(c, o.cost, "it %d colour %d stage %d cost" % (it, colour, stage))
+        s.finalize()
+        o.finalize()
+        n4, c = s.get_state()
+        assert_same(n4, o.norm4, "finalize norm4")
+
+
+def test_fused_sweep_equals_three_launches(hip, tiny_problem):
+    gs, _ = tiny_problem
+    o = OracleState(gs)
+    o.init_planes()
+    with Session(gs) as s:
+        s.set_state(o.norm4, o.cost)
+        s.sweep(0, abi.BLACK, abi.STAGE_ALL)
+        fused = s.get_state()
+        s.set_state(o.norm4, o.cost)
+        for stage in (abi.STAGE_CLOSE, abi.STAGE_FAR, abi.STAGE_REFINE):
+            s.sweep(0, abi.BLACK, stage)
+        split = s.get_state()
+    assert_same(fused[0], split[0], "fused vs split norm4")
+    assert_same(fused[1], split[1], "fused vs split cost")
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(),                                             # tiny default: box 7 (generic window), best-2
+    dict(blocksize=11, n_best=3),                       # specialised box 11, best-3
+    dict(cols=80, rows=56, blocksize=15, n_src=4, n_best=3, iterations=1),   # box 15
+    dict(cols=70, rows=50, blocksize=9, n_src=2, n_best=1),  # cols/rows not multiples of the tile
+    dict(cols=96, rows=40, blocksize=25, n_src=2, iterations=1),             # box 25
+])
+def test_full_run_bit_exact(hip, cfg):
+    gs, _ = synth.build_problem(synth.tiny_config(**cfg))
+    n4, c = runcuda(gs)
+    o_n4, o_c = OracleState(gs).run()
+    assert_same(n4, o_n4, "run norm4 %r" % cfg)
+    assert_same(c, o_c, "run cost %r" % cfg)
+
+
+@pytest.mark.parametrize("comb", [abi.COMB_ALL, abi.COMB_GOOD, abi.COMB_ANGLE])
+def test_cost_combinations(hip, comb):
+    gs, _ = synth.build_problem(synth.tiny_config(n_src=4, iterations=1), cost_comb=comb)
+    n4, c = runcuda(gs)
+    o_n4, o_c = OracleState(gs).run()
+    assert_same(n4, o_n4, "comb %d norm4" % comb)
+    assert_same(c, o_c, "comb %d cost" % comb)
+
+
+def test_best_n_larger_than_four_uses_generic_combiner(hip):
+    gs, _ = synth.build_problem(synth.tiny_config(n_src=6, n_best=5, iterations=1))
+    n4, c = runcuda(gs)
+    o_n4, o_c = OracleState(gs).run()
+    assert_same(n4, o_n4, "n_best 5 norm4")
+    assert_same(c, o_c, "n_best 5 cost")
+
+
+def test_non_integer_image_takes_the_exp_path(hip):
+    """float-valued reference image: no weight table, exp_model per sample"""
+    gs, _ = synth.build_problem(synth.tiny_config(iterations=1))
+    imgs = [im + np.float32(0.25) * (i + 1) for i, im in enumerate(gs.images)]
+    from gipuma_amd.problem import GlobalState
+    gs2 = GlobalState(imgs, gs.cameras, gs.selected, gs.params, seed=3)
+    n4, c = runcuda(gs2)
+    o_n4, o_c = OracleState(gs2).run()
+    assert_same(n4, o_n4, "float image norm4")
+    assert_same(c, o_c, "float image cost")
+
+
+def test_no_selected_views_gives_maxcost(hip):
+    """numConsidered == 0 -> MAXCOST everywhere (gipuma.cu:798-803), depth 0 after finalize"""
+    gs, _ = synth.build_problem(synth.tiny_config(iterations=1))
+    from gipuma_amd.problem import GlobalState
+    gs0 = GlobalState(gs.images, gs.cameras, [], gs.params, seed=1)
+    n4, c = runcuda(gs0)
+    assert np.all(c == abi.MAXCOST)
+    assert np.all(n4[..., 3] == 0.0)
+    o_n4, o_c = OracleState(gs0).run()
+    assert_same(n4, o_n4, "no views norm4")
+
+
+def test_seed_changes_result_and_is_reproducible(hip, tiny_problem):
+    gs, _ = tiny_problem
+    a = runcuda(gs)
+    b = runcuda(gs)
+    assert_same(a[0], b[0], "same seed twice")
+    gs.desc.seed = 99
+    try:
+        c = runcuda(gs)
+    finally:
+        gs.desc.seed = 1
+    assert not np.array_equal(bits(a[0]), bits(c[0]))
+
+
+def test_unfused_flag_matches(hip, tiny_problem):
+    gs, _ = tiny_problem
+    a = runcuda(gs)
+    gs.desc.flags |= abi.FLAG_UNFUSED
+    try:
+        b = runcuda(gs)
+    finally:
+        gs.desc.flags &= ~abi.FLAG_UNFUSED
+    assert_same(a[0], b[0], "unfused flag norm4")
+    assert_same(a[1], b[1], "unfused flag cost")
+
+
+def test_device_resident_images_with_pitch(hip):
+    """images already in HBM (torch tensors), row pitch larger than cols"""
+    import torch
+    gs, _ = synth.build_problem(synth.tiny_config(iterations=1))
+    pitch = gs.cols + 5
+    dev = []
+    for im in gs.images:
+        t = torch.zeros((gs.rows, pitch), dtype=torch.float32, device="cuda:0")
+        t[:, :gs.cols] = torch.from_numpy(im)
+        dev.append(t)
+    torch.cuda.synchronize()
+    from gipuma_amd.problem import GlobalState
+    gsd = GlobalState(dev, gs.cameras, gs.selected, gs.params, seed=1,
+                      device_ptrs=[t.data_ptr() for t in dev], rows=gs.rows, cols=gs.cols, pitch=pitch)
+    n4, c = runcuda(gsd)
+    o_n4, o_c = OracleState(gs).run()
+    assert_same(n4, o_n4, "device images norm4")
+    assert_same(c, o_c, "device images cost")
+
+
+def test_config_a_full_size(hip):
+    """BASELINE.json configs[0]: 320x240, 2 source views, 4 iterations -- the CPU-runnable case"""
+    gs, info = synth.build_problem("A")
+    n4, c, t = runcuda(gs, timing=True)
+    o_n4, o_c = OracleState(gs).run()
+    assert_same(n4, o_n4, "config A norm4")
+    assert_same(c, o_c, "config A cost")
+    err = np.abs(n4[..., 3] - info["gt_depth"]) / info["gt_depth"]
+    assert (err < 0.01).mean() > 0.9  # and it actually reconstructs the surface
+
+
+def test_properties_at_full_size(hip):
+    """config C size (1600x1200, 10 views), where the oracle is too slow: size-independent
+    properties instead -- determinism, plane/depth consistency, hemisphere, cost bounds, and the
+    cost plane equals a fresh evaluation of the final planes."""
+    gs, info = synth.build_problem("C", iterations=1)
+    with Session(gs) as s:
+        s.init_planes()
+        s.sweep(0, abi.BLACK)
+        s.sweep(0, abi.RED)
+        n4, c = s.get_state()
+        again = s.eval_cost(n4)
+        assert_same(c, again, "stored cost == cost of stored plane")
+        nn = np.linalg.norm(n4[..., :3], axis=-1)
+        assert np.abs(nn - 1).max() < 1e-4
+        assert c.min() >= 0 and c.max() <= abi.MAXCOST
+        s.finalize()
+        f4, _ = s.get_state()
+    valid = c != abi.MAXCOST
+    d = f4[..., 3][valid]
+    assert d.min() > 0
+    # spot-check 64 pixels against the oracle's single-pixel cost
+    from tests.oracle_lib import lib, fptr
+    rng = np.random.default_rng(0)
+    for _ in range(64):
+        x, y = int(rng.integers(0, gs.cols)), int(rng.integers(0, gs.rows))
+        pl = np.ascontiguousarray(n4[y, x])
+        want = lib().gipuma_oracle_multiview_cost(C.byref(gs.desc), x, y, fptr(pl))
+        assert np.float32(want).view(np.uint32) == c[y, x].view(np.uint32), (x, y, want, c[y, x])
