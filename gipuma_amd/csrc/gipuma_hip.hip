@@ -50,7 +50,9 @@ struct gipuma_hip_session {
     std::vector<float *> owned;  // device copies of host images
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    bool lut = false;        // reference image integer valued in [0,255] -> weight table
+    bool u8 = false;         // every image integer valued in [0,255] -> weight table + packed windows
+    std::vector<uint32_t *> packed;  // window-packed copies of the selected views (U8 mode)
+    int *flag = nullptr;
     bool combine_reg = false;
     bool unfused = false;
     int box = 0;             // specialised window size, 0 = runtime
@@ -76,14 +78,14 @@ sweep_fn pick_sweep_box(bool lut, bool creg)
 sweep_fn pick_sweep(const gipuma_hip_session *s)
 {
     if (s->tune & Tune::kNoInterior) {  // A/B switch, generic window only
-        if (s->box == 15 && s->lut && s->combine_reg) return pm::sweep_kernel<15, true, true, false>;
-        return s->lut ? pm::sweep_kernel<0, true, false, false> : pm::sweep_kernel<0, false, false, false>;
+        if (s->box == 15 && s->u8 && s->combine_reg) return pm::sweep_kernel<15, true, true, false>;
+        return s->u8 ? pm::sweep_kernel<0, true, false, false> : pm::sweep_kernel<0, false, false, false>;
     }
     switch (s->box) {
-    case 11: return pick_sweep_box<11>(s->lut, s->combine_reg);
-    case 15: return pick_sweep_box<15>(s->lut, s->combine_reg);
-    case 25: return pick_sweep_box<25>(s->lut, s->combine_reg);
-    default: return pick_sweep_box<0>(s->lut, s->combine_reg);
+    case 11: return pick_sweep_box<11>(s->u8, s->combine_reg);
+    case 15: return pick_sweep_box<15>(s->u8, s->combine_reg);
+    case 25: return pick_sweep_box<25>(s->u8, s->combine_reg);
+    default: return pick_sweep_box<0>(s->u8, s->combine_reg);
     }
 }
 
@@ -91,10 +93,10 @@ template <bool GEN>
 init_fn pick_init(const gipuma_hip_session *s)
 {
     switch (s->box) {
-    case 11: return s->lut ? pm::init_kernel<11, true, false, GEN> : pm::init_kernel<11, false, false, GEN>;
-    case 15: return s->lut ? pm::init_kernel<15, true, false, GEN> : pm::init_kernel<15, false, false, GEN>;
-    case 25: return s->lut ? pm::init_kernel<25, true, false, GEN> : pm::init_kernel<25, false, false, GEN>;
-    default: return s->lut ? pm::init_kernel<0, true, false, GEN> : pm::init_kernel<0, false, false, GEN>;
+    case 11: return s->u8 ? pm::init_kernel<11, true, false, GEN> : pm::init_kernel<11, false, false, GEN>;
+    case 15: return s->u8 ? pm::init_kernel<15, true, false, GEN> : pm::init_kernel<15, false, false, GEN>;
+    case 25: return s->u8 ? pm::init_kernel<25, true, false, GEN> : pm::init_kernel<25, false, false, GEN>;
+    default: return s->u8 ? pm::init_kernel<0, true, false, GEN> : pm::init_kernel<0, false, false, GEN>;
     }
 }
 
@@ -126,19 +128,6 @@ int validate(const gipuma_hip_desc *d)
 
 void copy9(float *dst, const float *src) { memcpy(dst, src, 9 * sizeof(float)); }
 void copy3(float *dst, const float *src) { memcpy(dst, src, 3 * sizeof(float)); }
-
-// is every reference-image value an integer in [0,255]? (then w = exp(-|dI|/gamma) has 256 values)
-bool integer_valued(const float *img, int rows, int cols, int pitch)
-{
-    for (int y = 0; y < rows; y++) {
-        const float *r = img + (size_t)y * pitch;
-        for (int x = 0; x < cols; x++) {
-            const float v = r[x];
-            if (!(v >= 0.0f && v <= 255.0f) || v != std::floor(v)) return false;
-        }
-    }
-    return true;
-}
 
 size_t lds_bytes(const gipuma_hip_session *s, int tile_h, bool with_cv)
 {
@@ -264,20 +253,37 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     CREATE_OK(resident(0, &hp.ref));
     for (int i = 0; i < d->n_selected; i++) CREATE_OK(resident(d->selected[i], &hp.view[i].img));
 
-    // weight table only if the reference image is integer valued (8-bit input, main.cpp:941)
+    // U8 mode (weight table + window-packed source views) if every image handed to the path is
+    // integer valued in [0,255] -- 8-bit input converted to float, main.cpp:941
     {
-        std::vector<float> tmp;
-        const float *host_ref = d->images[0];
-        int host_pitch = d->pitch;
-        if (on_device) {
-            tmp.resize(np);
-            CREATE_OK(hipMemcpy2D(tmp.data(), (size_t)d->cols * sizeof(float), d->images[0],
-                                  (size_t)d->pitch * sizeof(float), (size_t)d->cols * sizeof(float),
-                                  (size_t)d->rows, hipMemcpyDeviceToHost));
-            host_ref = tmp.data();
-            host_pitch = d->cols;
+        CREATE_OK(hipMalloc(&s->flag, sizeof(int)));
+        CREATE_OK(hipMemsetAsync(s->flag, 0, sizeof(int), s->stream));
+        const dim3 cg((d->cols + pm::kThreads - 1) / pm::kThreads, d->rows);
+        hipLaunchKernelGGL(pm::check_u8_kernel, cg, dim3(pm::kThreads), 0, s->stream, hp.ref, hp.rows, hp.cols,
+                           hp.pitch, s->flag);
+        for (int i = 0; i < d->n_selected; i++)
+            hipLaunchKernelGGL(pm::check_u8_kernel, cg, dim3(pm::kThreads), 0, s->stream, hp.view[i].img,
+                               hp.rows, hp.cols, hp.pitch, s->flag);
+        CREATE_OK(hipGetLastError());
+        int not_u8 = 1;
+        CREATE_OK(hipMemcpyAsync(&not_u8, s->flag, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        CREATE_OK(hipStreamSynchronize(s->stream));
+        s->u8 = !not_u8 && !(s->tune & Tune::kNoLut);
+        hp.pw = d->cols + 8;
+        hp.pg = (d->rows + 2) / 4 + 1;
+        if (s->u8) {
+            const size_t words = (size_t)4 * hp.pg * hp.pw;
+            const dim3 pgid((hp.pw + pm::kThreads - 1) / pm::kThreads, hp.pg, 4);
+            for (int i = 0; i < d->n_selected; i++) {
+                uint32_t *pk = nullptr;
+                CREATE_OK(hipMalloc(&pk, words * sizeof(uint32_t)));
+                s->packed.push_back(pk);
+                hp.view[i].packed = pk;
+                hipLaunchKernelGGL(pm::pack_kernel, pgid, dim3(pm::kThreads), 0, s->stream, hp.view[i].img,
+                                   hp.rows, hp.cols, hp.pitch, hp.pw, hp.pg, pk);
+            }
+            CREATE_OK(hipGetLastError());
         }
-        s->lut = integer_valued(host_ref, d->rows, d->cols, host_pitch) && !(s->tune & Tune::kNoLut);
     }
 
     // cameras -> one POD block
@@ -317,7 +323,7 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         s->box = hp.box_h;
     s->combine_reg = hp.cost_comb == GIPUMA_COMB_BEST_N && hp.n_best >= 1 && hp.n_best <= 4 &&
                      !(s->tune & Tune::kGenericCombine);
-    if ((s->tune & Tune::kNoInterior) && !(s->box == 15 && s->lut && s->combine_reg)) {
+    if ((s->tune & Tune::kNoInterior) && !(s->box == 15 && s->u8 && s->combine_reg)) {
         s->box = 0;  // the no-interior A/B arm only exists for these two variants
         s->combine_reg = false;
     }
@@ -335,6 +341,8 @@ int gipuma_hip_destroy(gipuma_hip_session *s)
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     for (float *p : s->owned) (void)hipFree(p);
+    for (uint32_t *p : s->packed) (void)hipFree(p);
+    if (s->flag) (void)hipFree(s->flag);
     if (s->dp) (void)hipFree(s->dp);
     if (s->norm4) (void)hipFree(s->norm4);
     if (s->cost) (void)hipFree(s->cost);

@@ -5,9 +5,10 @@
 // source views read with software bilinear filtering (gfx950 has no image instructions,
 // SURVEY.md F1).  No MFMA: the patch cost is a small stencil reduction (BASELINE.json).
 //
-// The arithmetic follows the numerical model M1-M4 stated at the top of oracle/gipuma_oracle.c
-// (and DESIGN.md 3); build with -ffp-contract=off so only the fmaf() written here fuse.  The
-// reference functions each piece stands for are cited by file:line of reference gipuma.cu.
+// The arithmetic follows the numerical model M1-M4 of DESIGN.md section 3 (fp32 lerp bilinear
+// taps, exp_model, x*(1/z), explicit fmaf); build with -ffp-contract=off so only the fmaf()
+// written here fuse.  The reference functions each piece stands for are cited by file:line of
+// reference gipuma.cu.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,7 +30,8 @@ struct RefCam {  // Camera_cu of view 0, camera.h:7-62
 struct ViewCam {  // Camera_cu of a selected source view + its image plane
     float K[9], R[9], t[3];
     int pad;
-    const float *img;
+    const float *img;        // float plane (row-major, Problem::pitch)
+    const uint32_t *packed;  // window-packed u8 copy (see pack_kernel), or nullptr
 };
 struct Problem {  // lives in device memory, read through scalar loads (wave-uniform)
     int rows, cols, pitch, n_sel;
@@ -38,6 +40,7 @@ struct Problem {  // lives in device memory, read through scalar loads (wave-uni
     float min_disp, max_disp, good_factor;
     uint32_t seed;
     const float *ref;
+    int pw, pg;  // packed layout: words per group row (cols + 8), groups per phase copy
     RefCam rc;
     ViewCam view[kMaxViews];
 };
@@ -218,9 +221,66 @@ struct Tune {  // experiment switches (GIPUMA_HIP_TUNE), all default off
                               kGenericCombine = 16;
 };
 
+// ---------------------------------------------------------------------------------------------
+// Window-packed source views (U8 mode).
+//
+// gfx950 has no texture unit, and a bilinear tap set needs a 4x4 texel window (minus corners) at
+// an arbitrary position per lane: 12 scattered dword gathers per sample on a plain float plane,
+// which is what bounds the float path.  When every image is integer valued in [0,255] (8-bit
+// input converted to float, reference main.cpp:941 -- the only input the reference has), each
+// source view is re-laid out ONCE per session so that the whole 4x4 window is 16 contiguous
+// bytes, fetched by one global_load_dwordx4 at a 4-byte aligned address:
+//
+//   padded image  Pd(Y, X) = I(clamp(Y-3), clamp(X-3)),  X in [0, cols+8), Y in [0, 4*pg+3)
+//   phase copy p in 0..3, group g:   word[p][g][X] = bytes { Pd(4g+p+r, X) : r = 0..3 }
+//
+// A window whose top-left texel is (Y, X) lives in copy p = Y & 3, group g = Y >> 2, words
+// X..X+3: word c holds column X+c, byte r holds row Y+r.  The 3-texel replicated border makes
+// clamp-to-edge addressing implicit, so there is no border branch at all.  The
+// four phase copies together take 4 B/pixel, the size of the float plane they replace;
+// neighbouring lanes (2 px apart) and the 4 pixel rows of a wavefront share cache lines.
+// (float)byte is exact, so the arithmetic is bit-identical to the float path.
+// ---------------------------------------------------------------------------------------------
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+// pointers read out of the Problem block are generic to the compiler; these casts state that the
+// image planes live in global memory so that global_load (not flat_load) is emitted
+typedef const __attribute__((address_space(1))) u32x4_a4 *gptr_u32x4;
+typedef const __attribute__((address_space(1))) float *gptr_f32;
+
+__device__ __forceinline__ float ub(uint32_t w, int r) { return (float)((w >> (8 * r)) & 0xffu); }
+
+// one workgroup row of 256 words per launch row; grid = (ceil(pw/256), pg, 4 phases)
+__global__ __launch_bounds__(kThreads) void pack_kernel(const float *__restrict__ img, int rows, int cols,
+                                                        int pitch, int pw, int pg,
+                                                        uint32_t *__restrict__ packed)
+{
+    const int X = blockIdx.x * kThreads + threadIdx.x;
+    const int g = blockIdx.y, p = blockIdx.z;
+    if (X >= pw) return;
+    const int x = clampi(X - 3, 0, cols - 1);
+    uint32_t w = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int y = clampi(4 * g + p + r - 3, 0, rows - 1);
+        const float v = img[y * pitch + x];
+        w |= ((uint32_t)v & 0xffu) << (8 * r);
+    }
+    packed[((size_t)p * pg + g) * pw + X] = w;
+}
+
+// flag[0] |= 1 if any value of the plane is not an integer in [0,255]
+__global__ __launch_bounds__(kThreads) void check_u8_kernel(const float *__restrict__ img, int rows, int cols,
+                                                            int pitch, int *__restrict__ flag)
+{
+    const int x = blockIdx.x * kThreads + threadIdx.x, y = blockIdx.y;
+    if (x >= cols || y >= rows) return;
+    const float v = img[y * pitch + x];
+    if (!(v >= 0.0f && v <= 255.0f) || v != __builtin_floorf(v)) atomicOr(flag, 1);
+}
+
 // Patch cost of one source view: pmCost_shared + pmCostComputation_shared,
 // gipuma.cu:585-680 and :223-277.  `tp0` points at the pixel's own texel inside the LDS tile.
-template <int BOX, bool LUT, bool INTERIOR>
+template <int BOX, bool U8, bool INTERIOR>
 __device__ __forceinline__ float view_cost(const Problem *__restrict__ P, const ViewCam &vc,
                                            const float *__restrict__ tp0, int tw,
                                            const float *__restrict__ lut, int px, int py, float4 pl,
@@ -228,7 +288,9 @@ __device__ __forceinline__ float view_cost(const Problem *__restrict__ P, const 
 {
     float H[9];
     homography(P->rc.K_inv, vc, pl, H);
-    const float *__restrict__ img = vc.img;
+    const gptr_f32 img = (gptr_f32)vc.img;
+    const uint32_t *__restrict__ packed = vc.packed;
+    const int pw = P->pw, pg = P->pg;
     const int rows = P->rows, cols = P->cols, pitch = P->pitch;
     const float colsf = (float)cols, rowsf = (float)rows;
     const float alpha = P->alpha, oma = 1.f - P->alpha;
@@ -249,8 +311,8 @@ __device__ __forceinline__ float view_cost(const Problem *__restrict__ P, const 
             const float leftValue = tp[0];
             const float colorDis = __builtin_fabsf(leftValue - centre);
             float w;
-            if (LUT)
-                w = lut[(int)colorDis];  // reference image is integer valued in [0,255]
+            if (U8)
+                w = lut[(int)colorDis];  // images are integer valued in [0,255]: 256 possible weights
             else
                 w = exp_model(-colorDis / gamma);
             // getCorrespondingPoint_cu, gipuma.cu:207-217
@@ -266,8 +328,24 @@ __device__ __forceinline__ float view_cost(const Problem *__restrict__ P, const 
             const int iy = (int)__builtin_fminf(__builtin_fmaxf(fy0, -2.0f), rowsf);
             float t01, t02, t10, t11, t12, t13, t20, t21, t22, t23, t31, t32;
             const bool inside = ix >= 1 && ix <= cols - 3 && iy >= 1 && iy <= rows - 3;
-            if (INTERIOR && __all(inside)) {
-                const float *s = img + (iy * pitch + ix);
+            if (U8) {  // U8 mode: the whole window is one 16-byte load
+                const int Y = iy + 2;
+                const uint32_t *wp = packed + (((Y & 3) * pg + (Y >> 2)) * pw + (ix + 2));
+                const u32x4_a4 wv = *(gptr_u32x4)(wp);
+                t10 = ub(wv.x, 1);
+                t20 = ub(wv.x, 2);
+                t01 = ub(wv.y, 0);
+                t11 = ub(wv.y, 1);
+                t21 = ub(wv.y, 2);
+                t31 = ub(wv.y, 3);
+                t02 = ub(wv.z, 0);
+                t12 = ub(wv.z, 1);
+                t22 = ub(wv.z, 2);
+                t32 = ub(wv.z, 3);
+                t13 = ub(wv.w, 1);
+                t23 = ub(wv.w, 2);
+            } else if (INTERIOR && __all(inside)) {
+                const gptr_f32 s = img + (iy * pitch + ix);
                 t01 = s[-pitch];
                 t02 = s[-pitch + 1];
                 t10 = s[-1];
@@ -325,7 +403,7 @@ __device__ __forceinline__ float view_cost(const Problem *__restrict__ P, const 
 // smallest view costs in registers (a sorting-network insert per view, same values and the same
 // ascending summation order as sort_small + the loop at :781-797); otherwise the view costs go
 // through a per-lane LDS column and the literal insertion sort.
-template <int BOX, bool LUT, bool INTERIOR, bool COMBINE_REG>
+template <int BOX, bool U8, bool INTERIOR, bool COMBINE_REG>
 __device__ __forceinline__ float multiview_cost(const Problem *__restrict__ P, const float *__restrict__ tp0,
                                                 int tw, const float *__restrict__ lut, float *cv, int px,
                                                 int py, float4 pl, const Win<BOX> &win)
@@ -334,7 +412,7 @@ __device__ __forceinline__ float multiview_cost(const Problem *__restrict__ P, c
     int numValid = 0;
     float b0 = kMaxCost, b1 = kMaxCost, b2 = kMaxCost, b3 = kMaxCost;
     for (int v = 0; v < n; v++) {
-        float c = view_cost<BOX, LUT, INTERIOR>(P, P->view[v], tp0, tw, lut, px, py, pl, win);
+        float c = view_cost<BOX, U8, INTERIOR>(P, P->view[v], tp0, tw, lut, px, py, pl, win);
         if (c < kMaxCost)
             numValid++;
         else
@@ -400,7 +478,7 @@ __device__ __forceinline__ void stage_tile(const Problem *__restrict__ P, float 
 {
     const int hw = win.halo_w(), hh = win.halo_h();
     const int tw = kTileW + 2 * hw, th = tile_h + 2 * hh;
-    const float *__restrict__ ref = P->ref;
+    const gptr_f32 ref = (gptr_f32)P->ref;
     float *tile = lds + kLutSize;
     for (int k = threadIdx.x; k < tw * th; k += kThreads) {
         const int ty = k / tw, tx = k - ty * tw;
@@ -417,7 +495,7 @@ __device__ __forceinline__ void stage_tile(const Problem *__restrict__ P, float 
 // ---------------------------------------------------------------------------------------------
 // gipuma_init_cu2 (gipuma.cu:996-1051) when GENERATE, else the cost of a given plane field
 // (gipuma_initial_cost, :1052-1079).  32x8 tile, one lane per pixel.
-template <int BOX, bool LUT, bool COMBINE_REG, bool GENERATE>
+template <int BOX, bool U8, bool COMBINE_REG, bool GENERATE>
 __global__ __launch_bounds__(kThreads) void init_kernel(const Problem *__restrict__ P,
                                                         float4 *__restrict__ norm4, float *__restrict__ cost,
                                                         unsigned tune)
@@ -428,7 +506,7 @@ __global__ __launch_bounds__(kThreads) void init_kernel(const Problem *__restric
     const int gy = (P->rows + kDenseTileH - 1) / kDenseTileH;
     const int t = tile_id(blockIdx.x, gx * gy, !(tune & Tune::kNoXcdRemap));
     const int x0 = (t % gx) * kTileW, y0 = (t / gx) * kDenseTileH;
-    stage_tile<BOX>(P, lds, x0, y0, kDenseTileH, win, LUT);
+    stage_tile<BOX>(P, lds, x0, y0, kDenseTileH, win, U8);
     const int hw = win.halo_w(), hh = win.halo_h();
     const int tw = kTileW + 2 * hw;
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
@@ -465,9 +543,9 @@ __global__ __launch_bounds__(kThreads) void init_kernel(const Problem *__restric
     }
     float c;
     if (tune & Tune::kNoInterior)
-        c = multiview_cost<BOX, LUT, false, COMBINE_REG>(P, tp0, tw, lds, cv, px, py, pl, win);
+        c = multiview_cost<BOX, U8, false, COMBINE_REG>(P, tp0, tw, lds, cv, px, py, pl, win);
     else
-        c = multiview_cost<BOX, LUT, true, COMBINE_REG>(P, tp0, tw, lds, cv, px, py, pl, win);
+        c = multiview_cost<BOX, U8, true, COMBINE_REG>(P, tp0, tw, lds, cv, px, py, pl, win);
     cost[center] = c;
 }
 
@@ -477,7 +555,7 @@ __global__ __launch_bounds__(kThreads) void init_kernel(const Problem *__restric
 // of a colour reads only its own state and pixels of the OTHER colour (distances 1 and 5 are odd,
 // :1730-1734), which no lane of this launch writes.  `stages` selects a subset so the three
 // reference launches can also be reproduced one by one.
-template <int BOX, bool LUT, bool COMBINE_REG, bool INTERIOR>
+template <int BOX, bool U8, bool COMBINE_REG, bool INTERIOR>
 __global__ __launch_bounds__(kThreads) void sweep_kernel(const Problem *__restrict__ P,
                                                          float4 *__restrict__ norm4, float *__restrict__ cost,
                                                          int colour, uint32_t phase, unsigned stages,
@@ -491,7 +569,7 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(const Problem *__restri
     const int gy = (rows + kSweepTileH - 1) / kSweepTileH;
     const int t = tile_id(blockIdx.x, gx * gy, !(tune & Tune::kNoXcdRemap));
     const int x0 = (t % gx) * kTileW, y0 = (t / gx) * kSweepTileH;
-    stage_tile<BOX>(P, lds, x0, y0, kSweepTileH, win, LUT);
+    stage_tile<BOX>(P, lds, x0, y0, kSweepTileH, win, U8);
     const int hw = win.halo_w(), hh = win.halo_h();
     const int tw = kTileW + 2 * hw;
     // lane -> pixel: 16 pixels of the colour per tile row; a wavefront covers 4 rows x 32 columns
@@ -525,7 +603,7 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(const Problem *__restri
             const float4 cand = norm4[nb];
             const float d_before = depth_from_plane(rc, cand, px, py);
             const float c_before =
-                multiview_cost<BOX, LUT, INTERIOR, COMBINE_REG>(P, tp0, tw, lds, cv, px, py, cand, win);
+                multiview_cost<BOX, U8, INTERIOR, COMBINE_REG>(P, tp0, tw, lds, cv, px, py, cand, win);
             if (d_before >= rc.depth_min && d_before <= rc.depth_max && c_before < cst) {
                 depth = d_before;
                 pl = cand;
@@ -560,7 +638,7 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(const Problem *__restri
             n = on_hemisphere(normalize3(n), view);
             const float4 cand = make_float4(n.x, n.y, n.z, plane_d(rc, n, px, py, depthOut));
             const float c =
-                multiview_cost<BOX, LUT, INTERIOR, COMBINE_REG>(P, tp0, tw, lds, cv, px, py, cand, win);
+                multiview_cost<BOX, U8, INTERIOR, COMBINE_REG>(P, tp0, tw, lds, cv, px, py, cand, win);
             if (c < cst) {
                 cst = c;
                 depth = depthOut;

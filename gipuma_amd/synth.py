@@ -148,7 +148,7 @@ CONFIGS = {
 
 
 def tiny_config(cols=64, rows=48, n_src=3, blocksize=7, iterations=2, n_best=2):
-    """a DTU-geometry problem small enough for the pure-CPU oracle in unit tests: the DTU
+    """a DTU-geometry problem small enough for CPU-side checking in unit tests: the DTU
     cameras with the image plane scaled down (--cam_scale, cameraGeometryUtils.h:136-147)"""
     return dict(kind="dtu", cols=cols, rows=rows, n_src=n_src, blocksize=blocksize,
                 iterations=iterations, n_best=n_best, depth_min=300.0, depth_max=800.0,

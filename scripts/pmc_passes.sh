@@ -1,0 +1,24 @@
+#!/bin/sh
+# Collect the PMC passes for the dominant kernel, one rocprofv3 run per counter group
+# (counters only with --kernel-trace; never together with sys/hip/hsa tracing).
+#   sh scripts/pmc_passes.sh <outdir-under-gpurun_out> [bench args...]
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$1; shift
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+i=0
+while read -r group; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --kernel-trace --pmc $group -d $OUT -o pmc$i -- \
+     python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $OUT/pmc$i.bench.json 2> $OUT/pmc$i.err
+  echo "pass $i ($group): rc=$?"
+done <<LIST
+SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM
+SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS
+GRBM_GUI_ACTIVE TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum
+TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+FETCH_SIZE
+WRITE_SIZE
+SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT
+LIST
+ls $OUT

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 output databases (rocpd sqlite) into the small text/JSON files kept under
+profiles/.
+
+    python scripts/rocprof_summary.py stats  <results.db>            # per-kernel time table
+    python scripts/rocprof_summary.py pmc    <dir-with-pmc*_results.db> [kernel-substring]
+
+`pmc` prints, for kernels whose name contains the substring (default "sweep_kernel"), the mean
+per-dispatch value of every collected counter plus the derived figures used in DESIGN.md.
+"""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+
+def stats(db):
+    cur = sqlite3.connect(db).cursor()
+    rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+    out = []
+    for name, calls, total, avg, pct in rows:
+        short = name.split("(")[0].replace("void ", "")
+        if len(short) > 70:
+            short = short[:67] + "..."
+        out.append((short, calls, total / 1e3, avg / 1e3, pct))
+    print("%-72s %8s %12s %12s %7s" % ("kernel", "calls", "total_ms", "avg_ms", "%"))
+    for r in out[:15]:
+        print("%-72s %8d %12.1f %12.1f %7.2f" % r)
+
+
+def pmc(d, sub="sweep_kernel"):
+    vals = {}
+    dur = []
+    for db in sorted(glob.glob(os.path.join(d, "*_results.db"))):
+        cur = sqlite3.connect(db).cursor()
+        try:
+            q = cur.execute("select counter_name, avg(value), count(*) from counters_collection "
+                            "where kernel_name like ? group by counter_name", ("%" + sub + "%",))
+            for name, v, n in q:
+                vals[name] = (v, n)
+            for (a,) in cur.execute("select avg(duration) from kernels where name like ?", ("%" + sub + "%",)):
+                if a:
+                    dur.append(a / 1e6)
+        except sqlite3.Error as e:
+            print("skip", db, e)
+    res = {k: v[0] for k, v in vals.items()}
+    res["_dispatches_per_counter"] = max([v[1] for v in vals.values()] or [0])
+    res["_kernel_ms_profiled_mean"] = sum(dur) / len(dur) if dur else None
+    g = res.get
+    if g("FETCH_SIZE") is not None:
+        # MI355X_MICROARCH.md HBM section: FETCH_SIZE (KiB) counts 128-B requests at 64 B on gfx950
+        # for wide coalesced streams -> doubled; WRITE_SIZE taken as reported (uncalibrated).
+        res["hbm_read_bytes_per_launch_x2corr"] = 2.0 * g("FETCH_SIZE") * 1024.0
+    if g("WRITE_SIZE") is not None:
+        res["hbm_write_bytes_per_launch"] = g("WRITE_SIZE") * 1024.0
+    if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None:
+        res["l2_hit_rate"] = g("TCC_HIT_sum") / max(1.0, g("TCC_HIT_sum") + g("TCC_MISS_sum"))
+    if g("TCP_TOTAL_CACHE_ACCESSES_sum") and g("TCP_TCC_READ_REQ_sum") is not None:
+        res["l1_hit_rate_est"] = 1.0 - g("TCP_TCC_READ_REQ_sum") / g("TCP_TOTAL_CACHE_ACCESSES_sum")
+    if g("SQ_WAVE_CYCLES") and g("SQ_ACTIVE_INST_VALU") is not None:
+        res["valu_active_frac_of_wave_cycles"] = g("SQ_ACTIVE_INST_VALU") / g("SQ_WAVE_CYCLES")
+    if g("SQ_WAVE_CYCLES") and g("SQ_WAIT_ANY") is not None:
+        res["wait_any_frac_of_wave_cycles"] = g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES")
+    print(json.dumps(res, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) < 3:
+        sys.exit(__doc__)
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2])
+    else:
+        pmc(sys.argv[2], *(sys.argv[3:4]))

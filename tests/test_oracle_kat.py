@@ -23,21 +23,36 @@ def f32(x):
 # ------------------------------------------------------------------------------------------ K1
 def test_k1_identity_view_costs_zero():
     """source image == reference image, R = I, t = 0  =>  H = I for every plane, every sample
-    difference is 0 and the view cost is exactly 0 (gipuma.cu:348-352, 267-274)."""
-    gs, _ = synth.build_problem(synth.tiny_config(n_src=2, iterations=1))
-    cs = gs.cameras
-    cam1 = cs.c_array[1]
-    ref = cs.c_array[0]
+    difference is 0 and the view cost is exactly 0 (gipuma.cu:348-352, 267-274).  K is chosen with
+    an exactly representable inverse so that K*K^-1 == I in fp32 too."""
+    rows, cols = 48, 64
+    K = np.array([[128.0, 0, 32], [0, 128.0, 24], [0, 0, 1]])
+    P0 = K @ np.hstack([np.eye(3), np.zeros((3, 1))])
+    cs = get_camera_parameters([P0, P0])
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(rows, cols)).astype(np.float32)
+    ap = AlgorithmParameters(depthMin=10.0, depthMax=200.0, n_best=1)
+    ap.set_blocksize(9)
+    gs = GlobalState([img, img], cs, [1], ap)
+    H = np.zeros(9, dtype=np.float32)
+    lib().gipuma_oracle_homography(C.byref(cs.c_array[0]), C.byref(cs.c_array[1]),
+                                   fptr(farr([0.1, -0.2, -0.97])), 61.0, fptr(H))
+    assert np.array_equal(H.reshape(3, 3), np.eye(3, dtype=np.float32))
+    pl = farr([0.1, -0.2, -0.97, 61.0])
+    for (x, y) in [(5, 5), (32, 24), (63, 47), (0, 0)]:
+        assert lib().gipuma_oracle_view_cost(C.byref(gs.desc), 1, x, y, fptr(pl)) == 0.0
+    # and with DTU intrinsics, where K*K^-1 is only I to rounding, the cost is ~0
+    gsd, _ = synth.build_problem(synth.tiny_config(n_src=2, iterations=1))
+    cam1, ref = gsd.cameras.c_array[1], gsd.cameras.c_array[0]
     for k in range(9):
         cam1.K[k] = ref.K[k]
         cam1.R[k] = 1.0 if k in (0, 4, 8) else 0.0
     for k in range(3):
         cam1.t[k] = 0.0
-    gs2 = GlobalState([gs.images[0], gs.images[0], gs.images[2]], cs, gs.selected, gs.params)
-    pl = farr([0.1, -0.2, -0.97, 610.0])
-    for (x, y) in [(5, 5), (32, 24), (63, 47), (0, 0)]:
-        c = lib().gipuma_oracle_view_cost(C.byref(gs2.desc), 1, x, y, fptr(pl))
-        assert c == 0.0
+    gs2 = GlobalState([gsd.images[0], gsd.images[0], gsd.images[2]], gsd.cameras, gsd.selected,
+                      gsd.params)
+    c = lib().gipuma_oracle_view_cost(C.byref(gs2.desc), 1, 32, 24, fptr(farr([0.1, -0.2, -0.97, 610.0])))
+    assert 0.0 <= c < 1e-3
 
 
 # ------------------------------------------------------------------------------------------ K2
