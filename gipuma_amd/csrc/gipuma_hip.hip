@@ -270,17 +270,16 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         CREATE_OK(hipStreamSynchronize(s->stream));
         s->u8 = !not_u8 && !(s->tune & Tune::kNoLut);
         hp.pw = d->cols + 8;
-        hp.pg = (d->rows + 2) / 4 + 1;
         if (s->u8) {
-            const size_t words = (size_t)4 * hp.pg * hp.pw;
-            const dim3 pgid((hp.pw + pm::kThreads - 1) / pm::kThreads, hp.pg, 4);
+            const size_t words = (size_t)(d->rows + 3) * hp.pw;
+            const dim3 pgid((hp.pw + pm::kThreads - 1) / pm::kThreads, d->rows + 3);
             for (int i = 0; i < d->n_selected; i++) {
                 uint32_t *pk = nullptr;
                 CREATE_OK(hipMalloc(&pk, words * sizeof(uint32_t)));
                 s->packed.push_back(pk);
                 hp.view[i].packed = pk;
                 hipLaunchKernelGGL(pm::pack_kernel, pgid, dim3(pm::kThreads), 0, s->stream, hp.view[i].img,
-                                   hp.rows, hp.cols, hp.pitch, hp.pw, hp.pg, pk);
+                                   hp.rows, hp.cols, hp.pitch, hp.pw, pk);
             }
             CREATE_OK(hipGetLastError());
         }

@@ -40,7 +40,7 @@ struct Problem {  // lives in device memory, read through scalar loads (wave-uni
     float min_disp, max_disp, good_factor;
     uint32_t seed;
     const float *ref;
-    int pw, pg;  // packed layout: words per group row (cols + 8), groups per phase copy
+    int pw, pad2;  // packed layout: words per row of V (cols + 8)
     RefCam rc;
     ViewCam view[kMaxViews];
 };
@@ -226,46 +226,64 @@ struct Tune {  // experiment switches (GIPUMA_HIP_TUNE), all default off
 //
 // gfx950 has no texture unit, and a bilinear tap set needs a 4x4 texel window (minus corners) at
 // an arbitrary position per lane: 12 scattered dword gathers per sample on a plain float plane,
-// which is what bounds the float path.  When every image is integer valued in [0,255] (8-bit
-// input converted to float, reference main.cpp:941 -- the only input the reference has), each
-// source view is re-laid out ONCE per session so that the whole 4x4 window is 16 contiguous
-// bytes, fetched by one global_load_dwordx4 at a 4-byte aligned address:
+// which is what bounds the float path (vector-L1 address rate).  When every image is integer
+// valued in [0,255] (8-bit input converted to float, reference main.cpp:941 -- the only input the
+// reference has), each source view is re-laid out ONCE per session as a "vertical-quad" image:
 //
-//   padded image  Pd(Y, X) = I(clamp(Y-3), clamp(X-3)),  X in [0, cols+8), Y in [0, 4*pg+3)
-//   phase copy p in 0..3, group g:   word[p][g][X] = bytes { Pd(4g+p+r, X) : r = 0..3 }
+//   padded image  Pd(Y, X) = I(clamp(Y-3), clamp(X-3)),   X in [0, cols+8), Y in [0, rows+6)
+//   V[Y][X] (one 32-bit word) = bytes { Pd(Y+r, X) : r = 0..3 },  Y in [0, rows+3)
 //
-// A window whose top-left texel is (Y, X) lives in copy p = Y & 3, group g = Y >> 2, words
-// X..X+3: word c holds column X+c, byte r holds row Y+r.  The 3-texel replicated border makes
-// clamp-to-edge addressing implicit, so there is no border branch at all.  The
-// four phase copies together take 4 B/pixel, the size of the float plane they replace;
-// neighbouring lanes (2 px apart) and the 4 pixel rows of a wavefront share cache lines.
-// (float)byte is exact, so the arithmetic is bit-identical to the float path.
+// The 4x4 window whose top-left texel is Pd(Y, X) is the four consecutive words V[Y][X..X+3]
+// (word c = column X+c, byte r = row Y+r): ONE global_load_dwordx4 at a 4-byte aligned address.
+// The 3-texel replicated border makes clamp-to-edge addressing implicit, so there is
+// no border branch.  V takes 4 B/pixel, the size of the float plane it stands for; neighbouring
+// lanes (2 px apart) share cache lines.  (float)byte is exact, so the arithmetic is
+// bit-identical to the float path.
 // ---------------------------------------------------------------------------------------------
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 // pointers read out of the Problem block are generic to the compiler; these casts state that the
 // image planes live in global memory so that global_load (not flat_load) is emitted
 typedef const __attribute__((address_space(1))) u32x4_a4 *gptr_u32x4;
 typedef const __attribute__((address_space(1))) float *gptr_f32;
+typedef const __attribute__((address_space(1))) char *gptr_bytes;
 
-__device__ __forceinline__ float ub(uint32_t w, int r) { return (float)((w >> (8 * r)) & 0xffu); }
+// byte -> float.  Spelled as the hardware instruction so that the compiler keeps ONE half-rate
+// conversion per texel (it otherwise rewrites (float)b1 - (float)b0 into a byte-select
+// subtraction plus a conversion: two half-rate ops for what one full-rate v_sub_f32 does).
+#define PM_UB(n)                                                                \
+    __device__ __forceinline__ float ub##n(uint32_t w)                          \
+    {                                                                           \
+        float f;                                                                \
+        asm("v_cvt_f32_ubyte" #n " %0, %1" : "=v"(f) : "v"(w));                 \
+        return f;                                                               \
+    }
+PM_UB(0) PM_UB(1) PM_UB(2) PM_UB(3)
+#undef PM_UB
+// float -> uint32 with saturation (negative and NaN -> 0, huge -> 0xffffffff): v_cvt_u32_f32.
+// One instruction replaces fmax + fmin + cvt of the clamped conversion.
+__device__ __forceinline__ uint32_t cvt_u32_sat(float x)
+{
+    uint32_t u;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(u) : "v"(x));
+    return u;
+}
 
-// one workgroup row of 256 words per launch row; grid = (ceil(pw/256), pg, 4 phases)
+// grid = (ceil(pw/256), rows+3)
 __global__ __launch_bounds__(kThreads) void pack_kernel(const float *__restrict__ img, int rows, int cols,
-                                                        int pitch, int pw, int pg,
-                                                        uint32_t *__restrict__ packed)
+                                                        int pitch, int pw, uint32_t *__restrict__ packed)
 {
     const int X = blockIdx.x * kThreads + threadIdx.x;
-    const int g = blockIdx.y, p = blockIdx.z;
+    const int Y = blockIdx.y;
     if (X >= pw) return;
     const int x = clampi(X - 3, 0, cols - 1);
     uint32_t w = 0;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const int y = clampi(4 * g + p + r - 3, 0, rows - 1);
+        const int y = clampi(Y + r - 3, 0, rows - 1);
         const float v = img[y * pitch + x];
         w |= ((uint32_t)v & 0xffu) << (8 * r);
     }
-    packed[((size_t)p * pg + g) * pw + X] = w;
+    packed[(size_t)Y * pw + X] = w;
 }
 
 // flag[0] |= 1 if any value of the plane is not an integer in [0,255]
@@ -290,7 +308,8 @@ __device__ __forceinline__ float view_cost(const Problem *__restrict__ P, const 
     homography(P->rc.K_inv, vc, pl, H);
     const gptr_f32 img = (gptr_f32)vc.img;
     const uint32_t *__restrict__ packed = vc.packed;
-    const int pw = P->pw, pg = P->pg;
+    const uint32_t pw = (uint32_t)P->pw;
+    const uint32_t xmax = (uint32_t)(P->cols + 2), ymax = (uint32_t)(P->rows + 2);
     const int rows = P->rows, cols = P->cols, pitch = P->pitch;
     const float colsf = (float)cols, rowsf = (float)rows;
     const float alpha = P->alpha, oma = 1.f - P->alpha;
@@ -298,15 +317,17 @@ __device__ __forceinline__ float view_cost(const Problem *__restrict__ P, const 
     const float centre = tp0[0];
     const int hr = win.hrad(), vr = win.vrad();
     float cost = 0.0f;
-    for (int i = -hr; i <= hr; i += 2) {
-        const float qx = (float)(px + i);
+    // (float)(px + i) == (float)px + (float)i exactly (small integers): full-rate adds, no cvt
+    const float pyf = (float)py;
+    float qx = (float)(px - hr);
+    for (int i = -hr; i <= hr; i += 2, qx += 2.0f) {
         const float X0 = __builtin_fmaf(H[0], qx, H[2]);
         const float Y0 = __builtin_fmaf(H[3], qx, H[5]);
         const float Z0 = __builtin_fmaf(H[6], qx, H[8]);
 #pragma unroll unroll_j<BOX>()
         for (int j = -vr; j <= vr; j += 2) {
             const float *tp = tp0 + j * tw + i;
-            const float qy = (float)(py + j);
+            const float qy = pyf + (float)j;
             // weight_cu, gipuma.cu:186-193
             const float leftValue = tp[0];
             const float colorDis = __builtin_fabsf(leftValue - centre);
@@ -324,27 +345,32 @@ __device__ __forceinline__ float view_cost(const Problem *__restrict__ P, const 
             // M1: five bilinear taps sharing one 4x4 texel window (gipuma.cu:251-253)
             const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
             const float a = sx - fx0, b = sy - fy0;
-            const int ix = (int)__builtin_fminf(__builtin_fmaxf(fx0, -2.0f), colsf);
-            const int iy = (int)__builtin_fminf(__builtin_fmaxf(fy0, -2.0f), rowsf);
             float t01, t02, t10, t11, t12, t13, t20, t21, t22, t23, t31, t32;
-            const bool inside = ix >= 1 && ix <= cols - 3 && iy >= 1 && iy <= rows - 3;
             if (U8) {  // U8 mode: the whole window is one 16-byte load
-                const int Y = iy + 2;
-                const uint32_t *wp = packed + (((Y & 3) * pg + (Y >> 2)) * pw + (ix + 2));
-                const u32x4_a4 wv = *(gptr_u32x4)(wp);
-                t10 = ub(wv.x, 1);
-                t20 = ub(wv.x, 2);
-                t01 = ub(wv.y, 0);
-                t11 = ub(wv.y, 1);
-                t21 = ub(wv.y, 2);
-                t31 = ub(wv.y, 3);
-                t02 = ub(wv.z, 0);
-                t12 = ub(wv.z, 1);
-                t22 = ub(wv.z, 2);
-                t32 = ub(wv.z, 3);
-                t13 = ub(wv.w, 1);
-                t23 = ub(wv.w, 2);
-            } else if (INTERIOR && __all(inside)) {
+                // X = clamp(floor(sx), -2, cols) + 2, same for Y: the +2 is exact wherever the
+                // clamp does not saturate
+                const uint32_t X = min(cvt_u32_sat(fx0 + 2.0f), xmax);
+                const uint32_t Y = min(cvt_u32_sat(fy0 + 2.0f), ymax);
+                const uint32_t off = (Y * pw + X) << 2;
+                const u32x4_a4 wv = *(gptr_u32x4)((gptr_bytes)packed + off);
+                t10 = ub1(wv.x);
+                t20 = ub2(wv.x);
+                t01 = ub0(wv.y);
+                t11 = ub1(wv.y);
+                t21 = ub2(wv.y);
+                t31 = ub3(wv.y);
+                t02 = ub0(wv.z);
+                t12 = ub1(wv.z);
+                t22 = ub2(wv.z);
+                t32 = ub3(wv.z);
+                t13 = ub1(wv.w);
+                t23 = ub2(wv.w);
+            } else {
+                // float planes: keep the float->int conversion defined for huge / NaN coordinates
+                const int ix = (int)__builtin_fminf(__builtin_fmaxf(fx0, -2.0f), colsf);
+                const int iy = (int)__builtin_fminf(__builtin_fmaxf(fy0, -2.0f), rowsf);
+                const bool inside = ix >= 1 && ix <= cols - 3 && iy >= 1 && iy <= rows - 3;
+                if (INTERIOR && __all(inside)) {
                 const gptr_f32 s = img + (iy * pitch + ix);
                 t01 = s[-pitch];
                 t02 = s[-pitch + 1];
@@ -375,6 +401,7 @@ __device__ __forceinline__ float view_cost(const Problem *__restrict__ P, const 
                 t23 = img[r2 + c3];
                 t31 = img[r3 + c1];
                 t32 = img[r3 + c2];
+                }
             }
             const float C0 = lerp(a, t01, t02);
             const float L1 = lerp(a, t10, t11), C1 = lerp(a, t11, t12), R1 = lerp(a, t12, t13);

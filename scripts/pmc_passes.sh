@@ -1,24 +1,29 @@
 #!/bin/sh
-# Collect the PMC passes for the dominant kernel, one rocprofv3 run per counter group
-# (counters only with --kernel-trace; never together with sys/hip/hsa tracing).
-#   sh scripts/pmc_passes.sh <outdir-under-gpurun_out> [bench args...]
+# Collect PMC passes for the PatchMatch kernels only, one rocprofv3 run per counter group
+# (counters only with --kernel-trace; never together with sys/hip/hsa tracing), summarise on the
+# box and keep just the small JSON (the rocpd databases are deleted: gpurun copies back <= 64 MiB).
+#   sh scripts/pmc_passes.sh <name> [bench args...]   ->  gpurun_out/<name>/pmc_summary.json
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$1; shift
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0
 while read -r group; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $group -d $OUT -o pmc$i -- \
+  timeout 240 rocprofv3 --kernel-trace --kernel-include-regex "pm::" --pmc $group -d $OUT -o pmc$i -- \
      python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $OUT/pmc$i.bench.json 2> $OUT/pmc$i.err
   echo "pass $i ($group): rc=$?"
 done <<LIST
 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM
 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS
-GRBM_GUI_ACTIVE TA_BUSY_avr TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum
+GRBM_GUI_ACTIVE TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum
+TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum
 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 FETCH_SIZE
 WRITE_SIZE
-SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT
+SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32
 LIST
-ls $OUT
+python $R/scripts/rocprof_summary.py pmc $OUT sweep_kernel > $OUT/pmc_summary.json
+python $R/scripts/rocprof_summary.py pmc $OUT init_kernel > $OUT/pmc_summary_init.json
+rm -f $OUT/*.db
+ls -la $OUT | head -30

@@ -1,0 +1,76 @@
+// Micro-benchmark: issue cost (cycles per wave64 instruction per SIMD) of the VALU ops the
+// PatchMatch inner loop is made of, on gfx950.  One wave per SIMD and 4 waves per SIMD variants.
+//   hipcc --offload-arch=gfx950 -O3 -o valu_rates valu_rates.hip && ./valu_rates
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define REP16(x) x x x x x x x x x x x x x x x x
+#define KERNEL(name, body)                                                         \
+    __global__ void name(float *out, int iters)                                   \
+    {                                                                              \
+        float a = threadIdx.x * 1.0f, b = 1.0001f, c = 0.5f, d = 2.0f, e = 3.0f;   \
+        float a2 = a + 1, b2 = b + 1, c2 = c + 1, d2 = d + 1;                     \
+        unsigned u = threadIdx.x, v = 77u, w = 3u, u2 = u + 1;                    \
+        for (int i = 0; i < iters; i++) { REP16(body) }                           \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a + b + c + d + e + a2 + b2 + c2 + d2 + (float)(u + v + w + u2); \
+    }
+
+// 4 independent chains per body so latency does not bound
+KERNEL(k_fma, asm volatile("v_fma_f32 %0, %4, %5, %0\n v_fma_f32 %1, %4, %5, %1\n v_fma_f32 %2, %4, %5, %2\n v_fma_f32 %3, %4, %5, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(a2));)
+KERNEL(k_add, asm volatile("v_add_f32 %0, %4, %0\n v_add_f32 %1, %4, %1\n v_add_f32 %2, %4, %2\n v_add_f32 %3, %4, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
+KERNEL(k_mul, asm volatile("v_mul_f32 %0, %4, %0\n v_mul_f32 %1, %4, %1\n v_mul_f32 %2, %4, %2\n v_mul_f32 %3, %4, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(b2));)
+KERNEL(k_pkfma, asm volatile("v_pk_fma_f32 %0, %2, %3, %0\n v_pk_fma_f32 %1, %2, %3, %1\n v_pk_fma_f32 %0, %2, %3, %0\n v_pk_fma_f32 %1, %2, %3, %1" : "+v"(*(double*)&a), "+v"(*(double*)&c) : "v"(*(double*)&a2), "v"(*(double*)&c2));)
+KERNEL(k_pkadd, asm volatile("v_pk_add_f32 %0, %2, %0\n v_pk_add_f32 %1, %2, %1\n v_pk_add_f32 %0, %2, %0\n v_pk_add_f32 %1, %2, %1" : "+v"(*(double*)&a), "+v"(*(double*)&c) : "v"(*(double*)&a2));)
+KERNEL(k_cvtub, asm volatile("v_cvt_f32_ubyte0 %0, %4\n v_cvt_f32_ubyte1 %1, %4\n v_cvt_f32_ubyte2 %2, %4\n v_cvt_f32_ubyte3 %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(u));)
+KERNEL(k_cvti, asm volatile("v_cvt_f32_i32 %0, %4\n v_cvt_f32_i32 %1, %4\n v_cvt_f32_i32 %2, %4\n v_cvt_f32_i32 %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(u));)
+KERNEL(k_cvtf2i, asm volatile("v_cvt_i32_f32 %0, %4\n v_cvt_i32_f32 %1, %4\n v_cvt_i32_f32 %2, %4\n v_cvt_i32_f32 %3, %4" : "+v"(u), "+v"(v), "+v"(w), "+v"(u2) : "v"(a));)
+KERNEL(k_addu, asm volatile("v_add_u32 %0, %4, %0\n v_add_u32 %1, %4, %1\n v_add_u32 %2, %4, %2\n v_add_u32 %3, %4, %3" : "+v"(u), "+v"(v), "+v"(w), "+v"(u2) : "v"(77));)
+KERNEL(k_mullo, asm volatile("v_mul_lo_u32 %0, %4, %0\n v_mul_lo_u32 %1, %4, %1\n v_mul_lo_u32 %2, %4, %2\n v_mul_lo_u32 %3, %4, %3" : "+v"(u), "+v"(v), "+v"(w), "+v"(u2) : "v"(77));)
+KERNEL(k_mad24, asm volatile("v_mad_u32_u24 %0, %4, %0, %0\n v_mad_u32_u24 %1, %4, %1, %1\n v_mad_u32_u24 %2, %4, %2, %2\n v_mad_u32_u24 %3, %4, %3, %3" : "+v"(u), "+v"(v), "+v"(w), "+v"(u2) : "v"(77));)
+KERNEL(k_sdwa, asm volatile("v_sub_u32_sdwa %0, %4, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_0\n v_sub_u32_sdwa %1, %4, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_1\n v_sub_u32_sdwa %2, %4, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_2\n v_sub_u32_sdwa %3, %4, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_0" : "+v"(u), "+v"(v), "+v"(w), "+v"(u2) : "v"(77));)
+KERNEL(k_min, asm volatile("v_min_f32 %0, %4, %0\n v_min_f32 %1, %4, %1\n v_max_f32 %2, %4, %2\n v_max_f32 %3, %4, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
+KERNEL(k_rcp, asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));)
+KERNEL(k_floor, asm volatile("v_floor_f32 %0, %0\n v_floor_f32 %1, %1\n v_floor_f32 %2, %2\n v_floor_f32 %3, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));)
+KERNEL(k_bfe, asm volatile("v_bfe_u32 %0, %4, 8, 8\n v_bfe_u32 %1, %4, 16, 8\n v_bfe_u32 %2, %4, 8, 8\n v_bfe_u32 %3, %4, 16, 8" : "+v"(u), "+v"(v), "+v"(w), "+v"(u2) : "v"(u));)
+KERNEL(k_divfmas, asm volatile("v_div_fixup_f32 %0, %0, %4, %5\n v_div_fixup_f32 %1, %1, %4, %5\n v_div_fixup_f32 %2, %2, %4, %5\n v_div_fixup_f32 %3, %3, %4, %5" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(a2));)
+KERNEL(k_mov, asm volatile("v_mov_b32 %0, %4\n v_mov_b32 %1, %4\n v_mov_b32 %2, %4\n v_mov_b32 %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
+KERNEL(k_fmamix, asm volatile("v_fma_f32 %0, %4, %5, %0\n v_add_u32 %2, %6, %2\n v_fma_f32 %1, %4, %5, %1\n v_add_u32 %3, %6, %3" : "+v"(a), "+v"(b), "+v"(u), "+v"(v) : "v"(e), "v"(a2), "v"(77));)
+
+template <typename K>
+void run(const char *name, K k, float *d, int waves_per_simd)
+{
+    const int iters = 4096, ops = iters * 16 * 4;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const int block = 256 * waves_per_simd;  // 4 SIMDs x waves_per_simd waves per CU
+    hipLaunchKernelGGL(k, dim3(256), dim3(block), 0, 0, d, 16);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k, dim3(256), dim3(block), 0, 0, d, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    // per SIMD: waves_per_simd waves each issuing `ops` instructions
+    const double ns_per_inst = ms * 1e6 / ((double)ops * waves_per_simd);
+    printf("%-10s waves/SIMD=%d  %.3f ns per wave-instruction per SIMD (= %.2f clk @2.4GHz)\n", name, waves_per_simd,
+           ns_per_inst, ns_per_inst * 2.4);
+}
+
+int main()
+{
+    float *d;
+    hipMalloc(&d, 256 * 1024 * sizeof(float));
+    for (int w : {1, 4}) {
+        run("fma", k_fma, d, w); run("add", k_add, d, w); run("mul", k_mul, d, w);
+        run("pk_fma", k_pkfma, d, w); run("pk_add", k_pkadd, d, w);
+        run("cvt_ubyte", k_cvtub, d, w); run("cvt_f32_i32", k_cvti, d, w); run("cvt_i32_f32", k_cvtf2i, d, w);
+        run("add_u32", k_addu, d, w); run("mul_lo_u32", k_mullo, d, w); run("mad_u24", k_mad24, d, w);
+        run("sub_sdwa", k_sdwa, d, w); run("min/max", k_min, d, w); run("rcp", k_rcp, d, w);
+        run("floor", k_floor, d, w); run("bfe", k_bfe, d, w); run("div_fixup", k_divfmas, d, w);
+        run("mov", k_mov, d, w); run("fma+addu", k_fmamix, d, w);
+    }
+    return 0;
+}
