@@ -1,0 +1,2 @@
+/* include-name forwarder: the reference includes <cuda_texture_types.h>; on MI355X that is gipuma_cuda_compat.h */
+#include "gipuma_cuda_compat.h"
