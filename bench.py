@@ -141,10 +141,14 @@ def main():
         alg = algorithmic_bytes_per_sweep_launch(n_pix, n_views)
         achieved = alg / (ms_launch * 1e-3) / 1e9
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
+        # HBM-side bytes per sweep launch from the PMC passes of the SAME command
+        # (scripts/pmc_passes.sh -> profiles/pmc_latest.json): FETCH_SIZE x2 (gfx950 correction,
+        # MI355X_MICROARCH.md HBM section) + WRITE_SIZE; separate --pmc passes
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc) and args.config == "C":
             try:
-                traffic = json.load(open(pmc)).get(args.config, {}).get("hbm_bytes_per_sweep_launch")
+                pj = json.load(open(pmc))
+                traffic = (pj["hbm_read_bytes_per_launch_x2corr"] + pj["hbm_write_bytes_per_launch"]) / 1e9
             except Exception:
                 traffic = None
         box = gs.params.box_hsize
@@ -180,6 +184,7 @@ def main():
                        "device_ms_init": float(np.mean(init_ms))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_unit": "GB per launch (L2<->fabric incl. Infinity Cache hits)",
                          "kernel": "pm::sweep_kernel (one colour: close+far+refine fused)",
                          "kernel_ms": ms_launch,
                          "algorithmic_bytes_per_launch": alg,
@@ -189,9 +194,16 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             # the oracle reads host memory: same frames, copied back from HBM
-            from gipuma_amd.problem import GlobalState
+            from gipuma_amd.problem import GlobalState, runcuda
             gs_host = GlobalState([im.cpu().numpy() for im in gs.images], gs.cameras, gs.selected,
                                   gs.params, seed=gs.desc.seed)
+            # the boundary as the reference's main.cpp uses it: host images in, host planes out
+            # (upload + window packing + solve + download); reported, never `value`
+            t1 = time.perf_counter()
+            runcuda(gs_host)
+            host_s = time.perf_counter() - t1
+            out["host_boundary"] = {"ms_per_view_host_in_host_out": host_s * 1e3,
+                                    "value_pcie_inclusive": n_pix / host_s / 1e6, "unit": "Mpix/s"}
             out["cpu_baseline"] = cpu_baseline(gs_host, iterations)
         print(json.dumps(out))
     if world > 1:

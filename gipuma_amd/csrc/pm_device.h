@@ -218,7 +218,7 @@ __host__ __device__ constexpr int unroll_j()
 
 struct Tune {  // experiment switches (GIPUMA_HIP_TUNE), all default off
     static constexpr unsigned kNoLut = 1, kNoInterior = 2, kNoXcdRemap = 4, kGenericBox = 8,
-                              kGenericCombine = 16;
+                              kGenericCombine = 16, kRowMajorTiles = 32;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -487,14 +487,40 @@ __device__ __forceinline__ float multiview_cost(const Problem *__restrict__ P, c
 // ---------------------------------------------------------------------------------------------
 // workgroup helpers
 // ---------------------------------------------------------------------------------------------
-// Workgroup id -> tile id.  Workgroups are dealt round-robin to the 8 XCDs (b % 8); giving each
-// XCD one contiguous band of tiles keeps neighbouring tiles' source-image footprints in one L2.
-__device__ __forceinline__ int tile_id(int b, int nblk, bool remap)
+// Workgroup id -> tile coordinates.
+//
+// Workgroups are dealt round-robin to the 8 XCDs (b % 8), each with its own 4 MB L2.  The tiles
+// an XCD works on at the same time (~5 workgroups x 32 CUs) should form a compact 2-D block, so
+// that their source-view footprints (tile + window halo, in each of the N views) overlap as much
+// as possible in that L2:  (1) every XCD gets one contiguous chunk of tile ids; (2) tile ids run
+// column-major inside horizontal bands of ceil(gy/8) tile rows, so consecutive ids are vertical
+// neighbours and a run of ~160 ids is a ~17 x 10 tile block, not three full-width rows.
+struct TileXY {
+    int x, y;
+};
+__device__ __forceinline__ TileXY tile_of(int b, int gx, int gy, unsigned tune)
 {
-    if (!remap || nblk < 8) return b;
-    const int xcd = b & 7, local = b >> 3;
-    const int q = nblk >> 3, r = nblk & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    const int nblk = gx * gy;
+    int t = b;
+    if (!(tune & Tune::kNoXcdRemap) && nblk >= 8) {
+        const int xcd = b & 7, local = b >> 3;
+        const int q = nblk >> 3, r = nblk & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    TileXY o;
+    if (tune & Tune::kRowMajorTiles) {
+        o.x = t % gx;
+        o.y = t / gx;
+    } else {
+        const int bo = (int)(tune >> 8);         // experiment override of the band height
+        const int bh = bo ? min(bo, gy) : (gy + 7) >> 3;  // band height in tile rows
+        const int band = t / (bh * gx);
+        const int h = min(bh, gy - band * bh);   // the last band may be shorter
+        const int rem = t - band * bh * gx;
+        o.x = rem / h;
+        o.y = band * bh + rem % h;
+    }
+    return o;
 }
 
 // stage the reference tile (+halo) and the weight table; the tile holds clamp-to-edge point
@@ -531,8 +557,8 @@ __global__ __launch_bounds__(kThreads) void init_kernel(const Problem *__restric
     const Win<BOX> win(P);
     const int gx = (P->cols + kTileW - 1) / kTileW;
     const int gy = (P->rows + kDenseTileH - 1) / kDenseTileH;
-    const int t = tile_id(blockIdx.x, gx * gy, !(tune & Tune::kNoXcdRemap));
-    const int x0 = (t % gx) * kTileW, y0 = (t / gx) * kDenseTileH;
+    const TileXY txy = tile_of(blockIdx.x, gx, gy, tune);
+    const int x0 = txy.x * kTileW, y0 = txy.y * kDenseTileH;
     stage_tile<BOX>(P, lds, x0, y0, kDenseTileH, win, U8);
     const int hw = win.halo_w(), hh = win.halo_h();
     const int tw = kTileW + 2 * hw;
@@ -594,8 +620,8 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(const Problem *__restri
     const int rows = P->rows, cols = P->cols;
     const int gx = (cols + kTileW - 1) / kTileW;
     const int gy = (rows + kSweepTileH - 1) / kSweepTileH;
-    const int t = tile_id(blockIdx.x, gx * gy, !(tune & Tune::kNoXcdRemap));
-    const int x0 = (t % gx) * kTileW, y0 = (t / gx) * kSweepTileH;
+    const TileXY txy = tile_of(blockIdx.x, gx, gy, tune);
+    const int x0 = txy.x * kTileW, y0 = txy.y * kSweepTileH;
     stage_tile<BOX>(P, lds, x0, y0, kSweepTileH, win, U8);
     const int hw = win.halo_w(), hh = win.halo_h();
     const int tw = kTileW + 2 * hw;
