@@ -1,0 +1,522 @@
+// gipuma_host.cpp -- see gipuma_host.h
+#include "gipuma_host.h"
+
+#include <sys/stat.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+namespace gipuma_host {
+
+// ------------------------------------------------------------------------------------------ CLI
+static bool starts(const char *a, const char *opt) { return strncmp(a, opt, strlen(opt)) == 0; }
+
+int parse_command_line(int argc, char **argv, InputFiles &in, OutputFiles &out, AlgorithmParameters &ap)
+{
+    // main.cpp:164-428: positional = image names (first = reference); --x=value; -flag value
+    for (int i = 1; i < argc; i++) {
+        const char *a = argv[i];
+        auto val = [&](const char *opt) { return a + strlen(opt); };
+        if (a[0] != '-') {
+            in.img_filenames.push_back(a);
+        } else if (starts(a, "--algorithm=")) {
+            const char *v = val("--algorithm=");  // parsed for compatibility; the device path has PM_COST only
+            const char *names[] = {"pm", "ct", "adct?", "ct_ss", "pm_ss", "adct", "adct_ss", "sct"};
+            ap.algorithm = -1;
+            for (int k = 0; k < 8; k++)
+                if (!strcmp(v, names[k])) ap.algorithm = k;
+            if (ap.algorithm < 0) {
+                printf("Command-line parameter error: Unknown stereo algorithm\n\n");
+                return -1;
+            }
+        } else if (starts(a, "--cost_comb=")) {
+            const char *v = val("--cost_comb=");
+            ap.cost_comb = !strcmp(v, "all") ? GIPUMA_COMB_ALL : !strcmp(v, "best_n") ? GIPUMA_COMB_BEST_N
+                         : !strcmp(v, "angle") ? GIPUMA_COMB_ANGLE : !strcmp(v, "good") ? GIPUMA_COMB_GOOD : -1;
+            if (ap.cost_comb < 0) {
+                printf("Command-line parameter error: Unknown cost combination method\n\n");
+                return -1;
+            }
+        } else if (starts(a, "--max-disparity=")) {
+            if (sscanf(val("--max-disparity="), "%f", &ap.max_disparity) != 1 || ap.max_disparity < 1) {
+                printf("Command-line parameter error: The max disparity (--maxdisparity=<...>) must be a positive integer \n");
+                return -1;
+            }
+        } else if (starts(a, "--blocksize=")) {
+            int k;
+            if (sscanf(val("--blocksize="), "%d", &k) != 1 || k < 1 || k % 2 != 1) {
+                printf("Command-line parameter error: The block size (--blocksize=<...>) must be a positive odd number\n");
+                return -1;
+            }
+            ap.box_hsize = ap.box_vsize = k;
+        }
+#define FOPT(name, field) else if (starts(a, name)) sscanf(val(name), "%f", &ap.field);
+#define IOPT(name, field) else if (starts(a, name)) sscanf(val(name), "%d", &ap.field);
+        FOPT("--good_factor=", good_factor) FOPT("--cost_tau_color=", tau_color)
+        FOPT("--cost_tau_gradient=", tau_gradient) FOPT("--cost_alpha=", alpha) FOPT("--cost_gamma=", gamma)
+        IOPT("--border_value=", border_value) IOPT("--iterations=", iterations) FOPT("--disp_tol=", dispTol)
+        FOPT("--norm_tol=", normTol) IOPT("--ss_n=", self_similarity_n) FOPT("--ct_eps=", census_epsilon)
+        FOPT("--cam_scale=", cam_scale) IOPT("--num_img_processed=", num_img_processed) IOPT("--n_best=", n_best)
+        FOPT("--depth_min=", depthMin) FOPT("--depth_max=", depthMax) FOPT("--min_angle=", min_angle)
+        FOPT("--max_angle=", max_angle) FOPT("--no_texture_sim", no_texture_sim)
+        FOPT("--no_texture_per", no_texture_per)
+#undef FOPT
+#undef IOPT
+        else if (starts(a, "--max_views=")) sscanf(val("--max_views="), "%u", &ap.max_views);
+        else if (starts(a, "--seed=")) sscanf(val("--seed="), "%u", &ap.seed);  // extension
+        else if (starts(a, "--gtDepth_divisionFactor=") || starts(a, "--gtDepth_tolerance") ||
+                 starts(a, "--camera_idx=")) { /* ground-truth evaluation: not on the path */ }
+        else if (starts(a, "--pmvs_folder")) in.pmvs_folder = argv[++i];
+        else if (!strcmp(a, "-view_selection")) ap.viewSelection = true;
+        else if (!strcmp(a, "-color_processing")) ap.color_processing = true;
+        else if (!strcmp(a, "-o")) out.disparity_filename = argv[++i];
+        else if (!strcmp(a, "-output_folder")) out.parentFolder = argv[++i];
+        else if (!strcmp(a, "-calib_file")) in.calib_filename = argv[++i];
+        else if (!strcmp(a, "-gt")) in.gt_filename = argv[++i];
+        else if (!strcmp(a, "-gt_nocc")) in.gt_nocc_filename = argv[++i];
+        else if (!strcmp(a, "-occl_mask")) in.occ_filename = argv[++i];
+        else if (!strcmp(a, "-gt_normal")) in.gt_normal_filename = argv[++i];
+        else if (!strcmp(a, "-images_folder")) in.images_folder = argv[++i];
+        else if (!strcmp(a, "-p_folder")) in.p_folder = argv[++i];
+        else if (!strcmp(a, "-krt_file")) in.krt_file = argv[++i];
+        else if (!strcmp(a, "-camera_folder")) in.camera_folder = argv[++i];
+        else if (!strcmp(a, "--initial_seed")) in.seed_file = argv[++i];
+        else if (!strcmp(a, "-bounding_folder")) in.bounding_folder = argv[++i];
+        else printf("Command-line parameter warning: unknown option %s\n", a);  // e.g. -no_display
+    }
+    std::cout << "Input files are: ";
+    for (const auto &s : in.img_filenames) std::cout << s << " ";
+    std::cout << std::endl;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ readers
+bool read_p_file(const std::string &path, double P[12])
+{  // readPFileStrechaPmvs, fileIoUtils.h:83-110
+    std::ifstream f(path.c_str());
+    if (!f) return false;
+    std::string line;
+    int r = 0;
+    while (r < 3 && std::getline(f, line)) {
+        if (line.find("CONTOUR") != std::string::npos) continue;
+        std::stringstream ss(line);
+        double v[4];
+        if (ss >> v[0] >> v[1] >> v[2] >> v[3]) {
+            for (int c = 0; c < 4; c++) P[4 * r + c] = (double)(float)v[c];  // atof -> float
+            r++;
+        }
+    }
+    return r == 3;
+}
+
+int read_middlebury_par(const std::string &path, const std::vector<std::string> &names, std::vector<double> &P)
+{  // readKRtFileMiddlebury, fileIoUtils.h:111-162: name K(9) R(9) t(3); P = K [R|t]
+    std::ifstream f(path.c_str());
+    if (!f) return 0;
+    std::string line;
+    std::getline(f, line);  // first line = count
+    P.assign(names.size() * 12, 0.0);
+    int found = 0;
+    while (std::getline(f, line)) {
+        std::stringstream ss(line);
+        std::string name;
+        double K[9], R[9], t[3];
+        ss >> name;
+        for (double &v : K) ss >> v;
+        for (double &v : R) ss >> v;
+        for (double &v : t) ss >> v;
+        if (!ss) continue;
+        for (size_t j = 0; j < names.size(); j++)
+            if (names[j] == name) {
+                double Rt[12];
+                for (int r = 0; r < 3; r++) {
+                    for (int c = 0; c < 3; c++) Rt[4 * r + c] = R[3 * r + c];
+                    Rt[4 * r + 3] = t[r];
+                }
+                for (int r = 0; r < 3; r++)
+                    for (int c = 0; c < 4; c++)
+                        P[12 * j + 4 * r + c] = K[3 * r] * Rt[c] + K[3 * r + 1] * Rt[4 + c] + K[3 * r + 2] * Rt[8 + c];
+                found++;
+            }
+    }
+    return found;
+}
+
+// ------------------------------------------------------------------------------------------ 3x3 math
+static void mul33(const double *a, const double *b, double *o)
+{
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) o[3 * r + c] = a[3 * r] * b[c] + a[3 * r + 1] * b[3 + c] + a[3 * r + 2] * b[6 + c];
+}
+static double det33(const double *m)
+{
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+static void inv33(const double *m, double *o)
+{
+    const double d = det33(m);
+    o[0] = (m[4] * m[8] - m[5] * m[7]) / d; o[1] = (m[2] * m[7] - m[1] * m[8]) / d; o[2] = (m[1] * m[5] - m[2] * m[4]) / d;
+    o[3] = (m[5] * m[6] - m[3] * m[8]) / d; o[4] = (m[0] * m[8] - m[2] * m[6]) / d; o[5] = (m[2] * m[3] - m[0] * m[5]) / d;
+    o[6] = (m[3] * m[7] - m[4] * m[6]) / d; o[7] = (m[1] * m[6] - m[0] * m[7]) / d; o[8] = (m[0] * m[4] - m[1] * m[3]) / d;
+}
+static void mulv(const double *m, const double *v, double *o)
+{
+    for (int r = 0; r < 3; r++) o[r] = m[3 * r] * v[0] + m[3 * r + 1] * v[1] + m[3 * r + 2] * v[2];
+}
+static double dot(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static double nrm(const double *a) { return std::sqrt(dot(a, a)); }
+
+// decomposeProjectionMatrix (cameraGeometryUtils.h:252): M = K R by Gram-Schmidt from the last
+// row up (the RQ decomposition with a positive diagonal), C = -M^-1 p4
+static void decompose(const double *Pin, double *K, double *R, double *C)
+{
+    double P[12];
+    memcpy(P, Pin, sizeof P);
+    double M[9] = {P[0], P[1], P[2], P[4], P[5], P[6], P[8], P[9], P[10]};
+    if (det33(M) < 0)  // a projection matrix is defined up to sign
+        for (double &v : P) v = -v;
+    const double m1[3] = {P[0], P[1], P[2]}, m2[3] = {P[4], P[5], P[6]}, m3[3] = {P[8], P[9], P[10]};
+    double r1[3], r2[3], r3[3], t[3];
+    memset(K, 0, 9 * sizeof(double));
+    K[8] = nrm(m3);
+    for (int k = 0; k < 3; k++) r3[k] = m3[k] / K[8];
+    K[5] = dot(m2, r3);
+    for (int k = 0; k < 3; k++) t[k] = m2[k] - K[5] * r3[k];
+    K[4] = nrm(t);
+    for (int k = 0; k < 3; k++) r2[k] = t[k] / K[4];
+    K[2] = dot(m1, r3);
+    K[1] = dot(m1, r2);
+    for (int k = 0; k < 3; k++) t[k] = m1[k] - K[1] * r2[k] - K[2] * r3[k];
+    K[0] = nrm(t);
+    for (int k = 0; k < 3; k++) r1[k] = t[k] / K[0];
+    for (int k = 0; k < 3; k++) { R[k] = r1[k]; R[3 + k] = r2[k]; R[6 + k] = r3[k]; }
+    double Mi[9], Mm[9] = {P[0], P[1], P[2], P[4], P[5], P[6], P[8], P[9], P[10]}, p4[3] = {P[3], P[7], P[11]};
+    inv33(Mm, Mi);
+    mulv(Mi, p4, C);
+    for (int k = 0; k < 3; k++) C[k] = -C[k];
+}
+
+static void put(float *dst, const double *src, int n)
+{
+    for (int k = 0; k < n; k++) dst[k] = (float)src[k];
+}
+
+void get_camera_parameters(const std::vector<double> &P_list, int n, float cam_scale, CameraSet &cs)
+{  // cameraGeometryUtils.h:174-353
+    cs.cams.assign(n, gipuma_hip_camera());
+    cs.P.assign(12 * n, 0.0);
+    cs.C.assign(3 * n, 0.0);
+    std::vector<double> K(9 * n), R(9 * n), C(3 * n), t(3 * n);
+    for (int i = 0; i < n; i++) {
+        decompose(&P_list[12 * i], &K[9 * i], &R[9 * i], &C[3 * i]);
+        mulv(&R[9 * i], &C[3 * i], &t[3 * i]);                       // t = -R C, :264
+        for (int k = 0; k < 3; k++) t[3 * i + k] = -t[3 * i + k];
+    }
+    auto scaleK = [&](const double *Kin, double *Ko) {                // scaleK, :136-147
+        memcpy(Ko, Kin, 9 * sizeof(double));
+        Ko[0] /= cam_scale; Ko[4] /= cam_scale; Ko[2] /= cam_scale; Ko[5] /= cam_scale;
+    };
+    double K0[9];
+    scaleK(&K[0], K0);
+    cs.f = (float)K0[0];
+    // transform = [R0 t0; 0 1]^-1 = [R0^T  -R0^T t0]                 :109-115, :270-271
+    double R0t[9], t0i[3];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) R0t[3 * r + c] = R[3 * c + r];
+    mulv(R0t, &t[0], t0i);
+    for (int k = 0; k < 3; k++) t0i[k] = -t0i[k];
+    for (int i = 0; i < n; i++) {
+        double Ki[9], Kinv[9], Rn[9], tn[3], Pn[12], Minv[9], Mm[9], Rinv[9];
+        scaleK(&K[9 * i], Ki);
+        inv33(Ki, Kinv);
+        mul33(&R[9 * i], R0t, Rn);                                    // transformCamera, :117-128
+        mulv(&R[9 * i], t0i, tn);
+        for (int k = 0; k < 3; k++) tn[k] += t[3 * i + k];
+        for (int r = 0; r < 3; r++) {                                 // P' = K0 [R'|t']  (K of camera 0 for all)
+            for (int c = 0; c < 3; c++)
+                Pn[4 * r + c] = K0[3 * r] * Rn[c] + K0[3 * r + 1] * Rn[3 + c] + K0[3 * r + 2] * Rn[6 + c];
+            Pn[4 * r + 3] = K0[3 * r] * tn[0] + K0[3 * r + 1] * tn[1] + K0[3 * r + 2] * tn[2];
+        }
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) Mm[3 * r + c] = Pn[4 * r + c];
+        inv33(Mm, Minv);                                              // :301
+        double p4[3] = {Pn[3], Pn[7], Pn[11]}, Cn[3];
+        mulv(Minv, p4, Cn);                                           // centre of P', :130-133
+        for (int k = 0; k < 3; k++) Cn[k] = -Cn[k];
+        inv33(&R[9 * i], Rinv);                                       // :297
+        memcpy(&cs.P[12 * i], Pn, sizeof Pn);
+        memcpy(&cs.C[3 * i], Cn, sizeof Cn);
+        gipuma_hip_camera &cam = cs.cams[i];
+        put(cam.K, Ki, 9); put(cam.K_inv, Kinv, 9); put(cam.R, Rn, 9); put(cam.t, tn, 3);
+        put(cam.M_inv, Minv, 9); put(cam.P_col34, p4, 3); put(cam.C, Cn, 3); put(cam.R_orig_inv, Rinv, 9);
+        cam.fx = (float)K0[0]; cam.fy = (float)K0[4]; cam.f = (float)K0[0];
+        cam.alpha = (float)K0[0] / (float)K0[4];
+        cam.baseline = 0.54f;                                         // :305
+        cam.depth_min = 2.0f; cam.depth_max = 20.0f;                  // camera.h:34,38
+    }
+}
+
+static void view_vector(const CameraSet &cs, int i, int x, int y, double *v)
+{  // getViewVector, cameraGeometryUtils.h:68-76
+    const double *P = &cs.P[12 * i];
+    double M[9] = {P[0], P[1], P[2], P[4], P[5], P[6], P[8], P[9], P[10]}, Mi[9];
+    inv33(M, Mi);
+    double p[3] = {x - P[3], y - P[7], 1.0 - P[11]}, X[3];
+    mulv(Mi, p, X);
+    for (int k = 0; k < 3; k++) v[k] = X[k] - cs.C[3 * i + k];
+    const double n = nrm(v);
+    for (int k = 0; k < 3; k++) v[k] /= n;
+}
+
+std::vector<int> select_views(const CameraSet &cs, int cols, int rows, AlgorithmParameters &ap)
+{  // main.cpp:430-499
+    const int n = (int)cs.cams.size();
+    const int x = cols / 2, y = rows / 2;
+    double vref[3];
+    view_vector(cs, 0, x, y, vref);
+    const double lo = ap.min_angle * M_PI / 180.0, hi = ap.max_angle * M_PI / 180.0;
+    double dmin = 9999, dmax = 0;
+    std::vector<int> subset;
+    if (ap.viewSelection)
+        printf("Accepting intersection angle of central rays from %f to %f degrees, use --min_angle=<angle> and --max_angle=<angle> to modify them\n",
+               ap.min_angle, ap.max_angle);
+    for (int i = 1; i < n; i++) {
+        double v[3], d[3];
+        view_vector(cs, i, x, y, v);
+        for (int k = 0; k < 3; k++) d[k] = cs.C[k] - cs.C[3 * i + k];
+        const double baseline = nrm(d);
+        double c = dot(vref, v);
+        c = c > 1 ? 1 : (c < -1 ? -1 : c);
+        const double angle = std::acos(c);                            // getAngle, mathUtils.h:16-24
+        if (angle > lo && angle < hi) {
+            if (ap.viewSelection) subset.push_back(i);
+            dmin = std::min(dmin, (baseline / 2.0) / std::sin(hi / 2.0));
+            dmax = std::max(dmax, (baseline / 2.0) / std::sin(lo / 2.0));
+        }
+    }
+    if (ap.depthMin == -1) ap.depthMin = (float)dmin;
+    if (ap.depthMax == -1) ap.depthMax = (float)dmax;
+    if (!ap.viewSelection) {
+        subset.clear();
+        for (int i = 1; i < n; i++) subset.push_back(i);
+        return subset;
+    }
+    if (subset.size() >= ap.max_views) {
+        // the reference shuffles with srand(time(0)) (main.cpp:491-496); here the order of the
+        // command line decides, so that a run is reproducible
+        printf("Too many camera, selecting only the first %u of them (modify with --max_views=<number>)\n", ap.max_views);
+        subset.resize(ap.max_views);
+    }
+    return subset;
+}
+
+// ------------------------------------------------------------------------------------------ images, dmb
+bool read_pnm_gray(const std::string &path, std::vector<float> &img, int &rows, int &cols)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char magic[3] = {0, 0, 0};
+    int maxv = 0;
+    auto next_int = [&](int &v) {
+        int c = fgetc(f);
+        while (c == '#' || isspace(c)) {
+            if (c == '#') while (c != '\n' && c != EOF) c = fgetc(f);
+            c = fgetc(f);
+        }
+        v = 0;
+        while (isdigit(c)) { v = 10 * v + (c - '0'); c = fgetc(f); }
+    };
+    if (fread(magic, 1, 2, f) != 2 || magic[0] != 'P' || (magic[1] != '5' && magic[1] != '6')) { fclose(f); return false; }
+    next_int(cols); next_int(rows); next_int(maxv);
+    if (cols < 1 || rows < 1 || maxv != 255) { fclose(f); return false; }
+    const int ch = magic[1] == '6' ? 3 : 1;
+    std::vector<unsigned char> raw((size_t)rows * cols * ch);
+    const bool ok = fread(raw.data(), 1, raw.size(), f) == raw.size();
+    fclose(f);
+    if (!ok) return false;
+    img.resize((size_t)rows * cols);
+    for (size_t k = 0; k < img.size(); k++) {
+        if (ch == 1) img[k] = (float)raw[k];                          // main.cpp:941
+        else {  // OpenCV's 8-bit BGR2GRAY: (R*4899 + G*9617 + B*1868 + 8192) >> 14
+            const int r = raw[3 * k], g = raw[3 * k + 1], b = raw[3 * k + 2];
+            img[k] = (float)((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14);
+        }
+    }
+    return true;
+}
+
+int write_dmb(const std::string &path, const float *data, int rows, int cols, int nb)
+{  // writeDmb / writeDmbNormal, fileIoUtils.h:320-368: int32 {type=1, h, w, nb} + h*w*nb float32
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) { printf("Error opening file %s", path.c_str()); return -1; }
+    const int32_t hdr[4] = {1, rows, cols, nb};
+    fwrite(hdr, sizeof(int32_t), 4, f);
+    fwrite(data, sizeof(float), (size_t)rows * cols * nb, f);
+    fclose(f);
+    return 0;
+}
+
+bool read_dmb(const std::string &path, std::vector<float> &data, int &rows, int &cols, int &nb)
+{  // readDmb, fileIoUtils.h:247-319
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    int32_t hdr[4];
+    bool ok = fread(hdr, sizeof(int32_t), 4, f) == 4 && hdr[0] == 1;
+    if (ok) {
+        rows = hdr[1]; cols = hdr[2]; nb = hdr[3];
+        data.resize((size_t)rows * cols * nb);
+        ok = fread(data.data(), sizeof(float), data.size(), f) == data.size();
+    }
+    fclose(f);
+    return ok;
+}
+
+// ------------------------------------------------------------------------------------------ runGipuma
+int run_gipuma(const InputFiles &in, const OutputFiles &out, AlgorithmParameters &ap, std::string *folder)
+{
+    if (in.img_filenames.size() < 2) {
+        printf("Command-line parameter error: at least 2 images must be specified\n");
+        return -1;
+    }
+    if (ap.color_processing) {
+        printf("-color_processing is not built yet on the MI355X path\n");
+        return -1;
+    }
+    const int n = (int)in.img_filenames.size();
+    // result folder <parent>/<YYYYMMDD_HHMMSS>_<refname>/, main.cpp:702-723
+    time_t tt;
+    time(&tt);
+    tm *pt = localtime(&tt);
+    mkdir(out.parentFolder.c_str(), 0777);
+    const std::string &ref = in.img_filenames[0];
+    const std::string ref_name = ref.size() > 4 ? ref.substr(0, ref.size() - 4) : ref;
+    char outputFolder[512];
+    snprintf(outputFolder, sizeof outputFolder, "%s/%04d%02d%02d_%02d%02d%02d_%s", out.parentFolder.c_str(),
+             pt->tm_year + 1900, pt->tm_mon + 1, pt->tm_mday, pt->tm_hour, pt->tm_min, pt->tm_sec, ref_name.c_str());
+    mkdir(outputFolder, 0777);
+
+    std::vector<std::vector<float>> imgs(n);
+    int rows = 0, cols = 0;
+    for (int i = 0; i < n; i++) {
+        int r, c;
+        if (!read_pnm_gray(in.images_folder + in.img_filenames[i], imgs[i], r, c) || (i && (r != rows || c != cols))) {
+            printf("Image seems to be invalid\n");
+            return -1;
+        }
+        rows = r; cols = c;
+    }
+    std::vector<double> P(12 * n, 0.0);
+    if (!in.krt_file.empty()) {
+        if (read_middlebury_par(in.krt_file, in.img_filenames, P) != n) { printf("krt_file incomplete\n"); return -1; }
+    } else if (!in.p_folder.empty()) {
+        for (int i = 0; i < n; i++)
+            if (!read_p_file(in.p_folder + in.img_filenames[i] + ".P", &P[12 * i])) {
+                printf("cannot read %s\n", (in.p_folder + in.img_filenames[i] + ".P").c_str());
+                return -1;
+            }
+    } else {
+        printf("need -p_folder or -krt_file\n");
+        return -1;
+    }
+    CameraSet cs;
+    get_camera_parameters(P, n, ap.cam_scale, cs);
+    std::vector<int> subset = select_views(cs, cols, rows, ap);
+    std::cout << "Total number of images used: " << subset.size() << std::endl;
+    std::cout << "Selected views: ";
+    for (int v : subset) std::cout << v << ", ";
+    std::cout << std::endl;
+    cs.cams[0].depth_min = ap.depthMin;                               // main.cpp:898-906
+    cs.cams[0].depth_max = ap.depthMax;
+    ap.min_disparity = cs.f * cs.cams[0].baseline / ap.depthMax;
+    ap.max_disparity = cs.f * cs.cams[0].baseline / ap.depthMin;
+    std::cout << "Range of Minimum/Maximum depth is: " << ap.min_disparity << " " << ap.max_disparity
+              << ", change it with --depth_min=<value> and  --depth_max=<value>" << std::endl;
+
+    std::vector<const float *> ptrs(n);
+    for (int i = 0; i < n; i++) ptrs[i] = imgs[i].data();
+    gipuma_hip_desc d{};
+    d.abi_version = GIPUMA_HIP_ABI_VERSION;
+    d.rows = rows; d.cols = cols; d.channels = 1; d.pitch = cols; d.n_images = n;
+    d.images = ptrs.data(); d.cameras = cs.cams.data();
+    d.n_selected = (int)subset.size(); d.selected = subset.data();
+    d.params.box_hsize = ap.box_hsize; d.params.box_vsize = ap.box_vsize; d.params.iterations = ap.iterations;
+    d.params.n_best = ap.n_best; d.params.cost_comb = ap.cost_comb; d.params.alpha = ap.alpha;
+    d.params.tau_color = ap.tau_color; d.params.tau_gradient = ap.tau_gradient; d.params.gamma = ap.gamma;
+    d.params.min_disparity = ap.min_disparity; d.params.max_disparity = ap.max_disparity;
+    d.params.good_factor = ap.good_factor;
+    d.seed = ap.seed;
+    std::vector<float> norm4((size_t)rows * cols * 4), cost((size_t)rows * cols);
+    gipuma_hip_timing t{};
+    printf("Blocksize is %dx%d\n", ap.box_hsize, ap.box_vsize);
+    printf("Number of iterations is %d\n", ap.iterations);
+    const int rc = gipuma_hip_run(&d, norm4.data(), cost.data(), &t);
+    if (rc) {
+        fprintf(stderr, "gipuma_hip_run failed (%d): %s\n", rc, gipuma_hip_last_error());
+        return rc;
+    }
+    printf("\t\tTotal time needed for computation: %f seconds\n", (t.ms_sweeps + t.ms_finalize) / 1000.f);
+    // disp.dmb = norm4.w (depth), normals.dmb = world normals: main.cpp:976-985, 1001-1015
+    std::vector<float> disp((size_t)rows * cols), nrm3((size_t)rows * cols * 3);
+    for (size_t k = 0; k < disp.size(); k++) {
+        disp[k] = norm4[4 * k + 3];
+        nrm3[3 * k] = norm4[4 * k]; nrm3[3 * k + 1] = norm4[4 * k + 1]; nrm3[3 * k + 2] = norm4[4 * k + 2];
+    }
+    const std::string of(outputFolder);
+    write_dmb(of + "/disp.dmb", disp.data(), rows, cols, 1);
+    write_dmb(of + "/normals.dmb", nrm3.data(), rows, cols, 3);
+    write_dmb(of + "/cost.dmb", cost.data(), rows, cols, 1);         // extra: the cost plane (cudacost.png in the reference)
+    if (!out.disparity_filename.empty()) write_dmb(out.disparity_filename, disp.data(), rows, cols, 1);
+    if (folder) *folder = of;
+    return 0;
+}
+
+}  // namespace gipuma_host
+
+extern "C" {
+
+int gipuma_host_camera_parameters(const double *P_list, int n, float cam_scale, gipuma_hip_camera *out, float *f)
+{
+    gipuma_host::CameraSet cs;
+    gipuma_host::get_camera_parameters(std::vector<double>(P_list, P_list + 12 * n), n, cam_scale, cs);
+    for (int i = 0; i < n; i++) out[i] = cs.cams[i];
+    if (f) *f = cs.f;
+    return 0;
+}
+
+int gipuma_host_select_views(const double *P_list, int n, float cam_scale, int cols, int rows, float min_angle,
+                             float max_angle, unsigned max_views, float *depth_min, float *depth_max, int *subset)
+{
+    gipuma_host::CameraSet cs;
+    gipuma_host::get_camera_parameters(std::vector<double>(P_list, P_list + 12 * n), n, cam_scale, cs);
+    gipuma_host::AlgorithmParameters ap;
+    ap.min_angle = min_angle; ap.max_angle = max_angle; ap.max_views = max_views;
+    ap.depthMin = *depth_min; ap.depthMax = *depth_max;
+    std::vector<int> s = gipuma_host::select_views(cs, cols, rows, ap);
+    for (size_t k = 0; k < s.size(); k++) subset[k] = s[k];
+    *depth_min = ap.depthMin; *depth_max = ap.depthMax;
+    return (int)s.size();
+}
+
+int gipuma_host_write_dmb(const char *path, const float *data, int rows, int cols, int nb)
+{
+    return gipuma_host::write_dmb(path, data, rows, cols, nb);
+}
+
+int gipuma_host_main(int argc, char **argv)
+{  // main(), main.cpp:1201-1230
+    gipuma_host::InputFiles in;
+    gipuma_host::OutputFiles out;
+    gipuma_host::AlgorithmParameters ap;
+    if (gipuma_host::parse_command_line(argc, argv, in, out, ap) < 0) return 1;
+    std::string folder;
+    const int rc = gipuma_host::run_gipuma(in, out, ap, &folder);
+    if (!rc) std::cout << "Results written to " << folder << std::endl;
+    return rc ? 1 : 0;
+}
+}

@@ -1,0 +1,87 @@
+// gipuma_host.h -- OpenCV-free host front-end in C++ (the reference's host language), on top of
+// the C-ABI: everything the reference does between its command line and runcuda(), and between
+// runcuda() and its result files.
+//
+//   command line                      main.cpp:164-428   -> parse_command_line
+//   .P / Middlebury _par.txt readers  fileIoUtils.h:83-162
+//   getCameraParameters               cameraGeometryUtils.h:174-353
+//   selectViews                       main.cpp:430-499
+//   depth range -> disparity range    main.cpp:898-906
+//   disp.dmb / normals.dmb            fileIoUtils.h:320-368, main.cpp:1001-1015
+//   result folder <out>/<timestamp>_<refname>/   main.cpp:717-723
+//
+// Images are read as binary PGM/PPM (8 bit) instead of through OpenCV's imread; PPM is converted
+// with the BT.601 weights imread(IMREAD_GRAYSCALE) uses.  OpenCV's decomposeProjectionMatrix is
+// restated (RQ with a positive diagonal, centre = -M^-1 p4) in double precision; neither is
+// pinned by a reference test.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../../include/gipuma_hip.h"
+
+namespace gipuma_host {
+
+struct AlgorithmParameters {  // reference algorithmparameters.h:21-51 (defaults) -- host view
+    int algorithm = 0;
+    float max_disparity = 256.0f, min_disparity = 0.0f;
+    int box_hsize = 19, box_vsize = 19;
+    float tau_color = 10.0f, tau_gradient = 2.0f, alpha = 0.9f, gamma = 10.0f;
+    int border_value = -1, iterations = 8;
+    bool color_processing = false;
+    float dispTol = 1.0f, normTol = 0.1f, census_epsilon = 2.5f;
+    int self_similarity_n = 50;
+    float cam_scale = 1.0f;
+    int num_img_processed = 1;
+    float good_factor = 1.5f;
+    int n_best = 2, cost_comb = GIPUMA_COMB_BEST_N;
+    bool viewSelection = true;
+    float depthMin = -1.0f, depthMax = -1.0f, min_angle = 5.0f, max_angle = 45.0f;
+    float no_texture_sim = 0.9f, no_texture_per = 0.6f;
+    unsigned max_views = 9;
+    unsigned seed = 1;  // extension: --seed=
+};
+
+struct InputFiles {  // reference main.h:39-54
+    std::vector<std::string> img_filenames;
+    std::string images_folder, p_folder, krt_file, calib_filename, camera_folder, bounding_folder, pmvs_folder,
+        seed_file, gt_filename, gt_nocc_filename, occ_filename, gt_normal_filename;
+};
+struct OutputFiles {  // reference main.h:57-61
+    std::string parentFolder = "results", disparity_filename;
+};
+
+// returns 0, or -1 like getParametersFromCommandLine
+int parse_command_line(int argc, char **argv, InputFiles &in, OutputFiles &out, AlgorithmParameters &ap);
+
+bool read_p_file(const std::string &path, double P[12]);
+// fills P for the images named in `names`; returns the number found
+int read_middlebury_par(const std::string &path, const std::vector<std::string> &names, std::vector<double> &P);
+
+struct CameraSet {
+    std::vector<gipuma_hip_camera> cams;  // index 0 = reference
+    std::vector<double> P;                // 12 per view: K0 [R|t] after re-centring
+    std::vector<double> C;                // 3 per view: centre of P
+    float f = 0.0f;
+};
+void get_camera_parameters(const std::vector<double> &P_list, int n, float cam_scale, CameraSet &cs);
+// returns the selected subset; fills depthMin/depthMax when they are -1
+std::vector<int> select_views(const CameraSet &cs, int cols, int rows, AlgorithmParameters &ap);
+
+bool read_pnm_gray(const std::string &path, std::vector<float> &img, int &rows, int &cols);
+int write_dmb(const std::string &path, const float *data, int rows, int cols, int nb);
+bool read_dmb(const std::string &path, std::vector<float> &data, int &rows, int &cols, int &nb);
+
+// the whole of runGipuma (main.cpp:694-1199) minus visualisation: returns 0 and the folder written
+int run_gipuma(const InputFiles &in, const OutputFiles &out, AlgorithmParameters &ap, std::string *folder);
+
+}  // namespace gipuma_host
+
+extern "C" {
+// test hooks (ctypes): same math as the CLI uses
+int gipuma_host_camera_parameters(const double *P_list, int n, float cam_scale, gipuma_hip_camera *out, float *f);
+int gipuma_host_select_views(const double *P_list, int n, float cam_scale, int cols, int rows, float min_angle,
+                             float max_angle, unsigned max_views, float *depth_min, float *depth_max, int *subset);
+int gipuma_host_write_dmb(const char *path, const float *data, int rows, int cols, int nb);
+int gipuma_host_main(int argc, char **argv);
+}

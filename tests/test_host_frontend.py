@@ -1,0 +1,166 @@
+"""SURVEY.md 8f rows N1/N2 in C++ (gipuma_amd/csrc/host/): camera front-end, view selection,
+.dmb writers and the reference's command-line surface, on top of the C-ABI."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from gipuma_amd import abi, dmb, synth
+from gipuma_amd.cameras import CameraSet, get_camera_parameters, select_views
+from gipuma_amd.problem import AlgorithmParameters, GlobalState
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "gipuma_amd", "csrc", "host")
+EXE = os.path.join(HOST, "gipuma_hip")
+
+
+def host_lib():
+    L = C.CDLL(os.path.join(HOST, "libgipuma_host.so"))
+    L.gipuma_host_camera_parameters.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_float,
+                                                C.POINTER(abi.Camera), C.POINTER(C.c_float)]
+    L.gipuma_host_select_views.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_float, C.c_int, C.c_int,
+                                           C.c_float, C.c_float, C.c_uint, C.POINTER(C.c_float),
+                                           C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.gipuma_host_write_dmb.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int]
+    return L
+
+
+def cpp_cameras(P_list, cam_scale=1.0):
+    n = len(P_list)
+    flat = np.ascontiguousarray(np.stack(P_list).reshape(-1), dtype=np.float64)
+    cs = CameraSet(n)
+    f = C.c_float()
+    host_lib().gipuma_host_camera_parameters(flat.ctypes.data_as(C.POINTER(C.c_double)), n, cam_scale,
+                                             cs.c_array, C.byref(f))
+    cs.f = f.value
+    return cs
+
+
+def cam_fields(c):
+    return np.frombuffer(bytes(c), dtype=np.float32)
+
+
+def test_cpp_camera_front_end_matches_python_restatement():
+    """two independent restatements of getCameraParameters (numpy QR vs Gram-Schmidt in C++)"""
+    P = synth.dtu_projection_matrices()
+    ids = [15, 2, 9, 24, 33, 58]
+    Pl = [P[k] for k in ids]
+    for scale in (1.0, 4.0):
+        py = get_camera_parameters(Pl, cam_scale=scale)
+        cpp = cpp_cameras(Pl, cam_scale=scale)
+        for i in range(len(ids)):
+            a, b = cam_fields(py.c_array[i]), cam_fields(cpp.c_array[i])
+            assert np.allclose(a, b, rtol=2e-5, atol=2e-5), (i, np.abs(a - b).max())
+        assert cpp.f == pytest.approx(py.f, rel=1e-6)
+    # reference camera is K[I|0]
+    r = np.array(cpp.c_array[0].R[:]).reshape(3, 3)
+    assert np.allclose(r, np.eye(3), atol=1e-6) and np.allclose(cpp.c_array[0].t[:], 0, atol=1e-4)
+
+
+def test_cpp_select_views_matches_survey_counts():
+    P = synth.dtu_projection_matrices()
+    for ref, want in [(15, 25), (24, 31), (1, 8)]:
+        order = [ref] + [k for k in sorted(P) if k != ref]
+        flat = np.ascontiguousarray(np.stack([P[k] for k in order]).reshape(-1))
+        dmin, dmax = C.c_float(-1), C.c_float(-1)
+        sub = (C.c_int * 64)()
+        n = host_lib().gipuma_host_select_views(flat.ctypes.data_as(C.POINTER(C.c_double)), 64, 1.0, 1600, 1200,
+                                                10.0, 30.0, 100, C.byref(dmin), C.byref(dmax), sub)
+        assert n == want
+        cs = get_camera_parameters([P[k] for k in order])
+        py_sub, py_dmin, py_dmax = select_views(cs, 1600, 1200, 10.0, 30.0, max_views=100)
+        assert list(sub[:n]) == py_sub
+        assert dmin.value == pytest.approx(py_dmin, rel=1e-5) and dmax.value == pytest.approx(py_dmax, rel=1e-5)
+
+
+def test_dmb_layout(tmp_path):
+    """K11: int32 {1, h, w, nb} then h*w*nb float32 row-major (fileIoUtils.h:326-339)"""
+    a = np.arange(2 * 3 * 3, dtype=np.float32).reshape(2, 3, 3)
+    p = str(tmp_path / "n.dmb")
+    assert host_lib().gipuma_host_write_dmb(p.encode(), a.ctypes.data_as(C.POINTER(C.c_float)), 2, 3, 3) == 0
+    raw = open(p, "rb").read()
+    assert np.frombuffer(raw[:16], dtype=np.int32).tolist() == [1, 2, 3, 3]
+    assert np.array_equal(np.frombuffer(raw[16:], dtype=np.float32), a.reshape(-1))
+    assert np.array_equal(dmb.read_dmb(p), a)
+    p2 = str(tmp_path / "d.dmb")
+    dmb.write_dmb(p2, a[..., 0])
+    assert open(p2, "rb").read()[:16] == np.array([1, 2, 3, 1], dtype=np.int32).tobytes()
+    assert np.array_equal(dmb.read_dmb(p2), a[..., 0])
+
+
+def write_scene(tmp, gs, view_ids):
+    img_dir, p_dir = tmp / "img", tmp / "calib"
+    img_dir.mkdir()
+    p_dir.mkdir()
+    P = synth.dtu_projection_matrices()
+    names = []
+    for im, vid in zip(gs.images, view_ids):
+        name = "rect_%03d.pgm" % vid
+        with open(img_dir / name, "wb") as f:
+            f.write(b"P5\n# synthetic\n%d %d\n255\n" % (gs.cols, gs.rows))
+            f.write(im.astype(np.uint8).tobytes())
+        with open(p_dir / (name + ".P"), "w") as f:
+            for r in P[vid]:
+                f.write(" ".join("%.6f" % v for v in r) + "\n")
+        names.append(name)
+    return img_dir, p_dir, names
+
+
+def cli_args(cfg, img_dir, p_dir, names, out_dir):
+    # the flag set of scripts/dtu_fast.sh:9-21,48-49 (+ --cam_scale for the small test image)
+    return [EXE] + names + ["-images_folder", str(img_dir) + "/", "-p_folder", str(p_dir) + "/",
+                            "-output_folder", str(out_dir), "-no_display", "--algorithm=pm",
+                            "--blocksize=%d" % cfg["blocksize"], "--iterations=%d" % cfg["iterations"],
+                            "--cost_gamma=10", "--cost_comb=best_n", "--n_best=%d" % cfg["n_best"],
+                            "--depth_min=300", "--depth_max=800", "--min_angle=10", "--max_angle=30",
+                            "--max_views=%d" % (cfg["n_src"] + 1),
+                            "--cam_scale=%.9g" % np.float32(cfg["cam_scale"])]
+
+
+def test_cli_without_gpu_fails_loudly(tmp_path):
+    if abi.load_library().gipuma_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    cfg = synth.tiny_config(cols=48, rows=32, n_src=2)
+    gs, info = synth.build_problem(cfg)
+    img_dir, p_dir, names = write_scene(tmp_path, gs, info["view_ids"])
+    r = subprocess.run(cli_args(cfg, img_dir, p_dir, names, tmp_path / "out"), capture_output=True, text=True)
+    assert r.returncode != 0
+    assert "no CPU fallback" in r.stderr
+    assert "unknown option -no_display" in r.stdout          # warns like the reference (main.cpp:401-405)
+    assert "Selected views: 1, 2," in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_dmb_matches_oracle(hip, tmp_path):
+    """PGM + .P files in, disp.dmb / normals.dmb out, through the reference's flags; the oracle is
+    fed the cameras the C++ front-end produced, so the dumps must match it bit for bit"""
+    from tests.oracle_lib import OracleState
+    cfg = synth.tiny_config(cols=96, rows=64, n_src=3, blocksize=11, iterations=2, n_best=2)
+    gs, info = synth.build_problem(cfg)
+    ids = info["view_ids"]
+    img_dir, p_dir, names = write_scene(tmp_path, gs, ids)
+    out_dir = tmp_path / "out"
+    r = subprocess.run(cli_args(cfg, img_dir, p_dir, names, out_dir), capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Total time needed for computation" in r.stdout
+    sub = [d for d in os.listdir(out_dir)]
+    assert len(sub) == 1 and sub[0].endswith("_rect_%03d" % ids[0])   # <timestamp>_<refname>, main.cpp:717
+    folder = out_dir / sub[0]
+    disp, normals, cost = (dmb.read_dmb(str(folder / n)) for n in ("disp.dmb", "normals.dmb", "cost.dmb"))
+    # same problem for the oracle, with the C++ front-end's cameras (P files as written: %.6f)
+    P_txt = [np.array([[float("%.6f" % v) for v in row] for row in synth.dtu_projection_matrices()[k]],
+                      dtype=np.float32).astype(np.float64) for k in ids]
+    cs = cpp_cameras(P_txt, cam_scale=float(np.float32(cfg["cam_scale"])))
+    ap = AlgorithmParameters(iterations=2, n_best=2, depthMin=300.0, depthMax=800.0)
+    ap.set_blocksize(11)
+    gs2 = GlobalState(gs.images, cs, [1, 2, 3], ap, seed=1)
+    # main.cpp:905-906 in fp32, as the C++ front-end computes it
+    f32 = np.float32
+    gs2.desc.params.min_disparity = f32(cs.f) * f32(0.54) / f32(800.0)
+    gs2.desc.params.max_disparity = f32(cs.f) * f32(0.54) / f32(300.0)
+    n4, c = OracleState(gs2).run()
+    assert np.array_equal(disp.view(np.uint32), n4[..., 3].view(np.uint32))
+    assert np.array_equal(normals.view(np.uint32), np.ascontiguousarray(n4[..., :3]).view(np.uint32))
+    assert np.array_equal(cost.view(np.uint32), c.view(np.uint32))
