@@ -75,6 +75,15 @@ static inline cudaChannelFormatDesc cudaCreateChannelDesc(int x, int y, int z, i
     cudaChannelFormatDesc d = {x, y, z, w, f};
     return d;
 }
+template <class T> static inline cudaChannelFormatDesc cudaCreateChannelDesc();   /* main.cpp:567 */
+template <> inline cudaChannelFormatDesc cudaCreateChannelDesc<float>()
+{
+    return cudaCreateChannelDesc(32, 0, 0, 0, cudaChannelFormatKindFloat);
+}
+template <> inline cudaChannelFormatDesc cudaCreateChannelDesc<float4>()
+{
+    return cudaCreateChannelDesc(32, 32, 32, 32, cudaChannelFormatKindFloat);
+}
 struct cudaArray {
     void *data;          /* device memory, row-major, pitch_bytes per row */
     size_t width, height, pitch_bytes;

@@ -32,10 +32,7 @@ int runcuda_impl(GS &gs, unsigned seed = 1)
 {
     const auto &ap = *gs.params;
     auto &cp = *gs.cameras;
-    if (ap.color_processing) {
-        fprintf(stderr, "gipuma_hip: -color_processing (T=float4, gipuma.cu:1965) is not built yet\n");
-        exit(EXIT_FAILURE);
-    }
+    const int channels = ap.color_processing ? 4 : 1; /* T = float4 : float, gipuma.cu:1965-1968 */
     const int n_sel = cp.viewSelectionSubsetNumber;
     int n_images = 1;
     for (int i = 0; i < n_sel; i++)
@@ -43,7 +40,7 @@ int runcuda_impl(GS &gs, unsigned seed = 1)
 
     std::vector<gipuma_hip_camera> cams(n_images);
     std::vector<const float *> imgs(n_images, nullptr);
-    int pitch = cp.cols;
+    int pitch = cp.cols * channels;
     for (int i = 0; i < n_images; i++) {
         const auto &c = cp.cameras[i];
         gipuma_hip_camera &o = cams[i];
@@ -71,7 +68,7 @@ int runcuda_impl(GS &gs, unsigned seed = 1)
     d.abi_version = GIPUMA_HIP_ABI_VERSION;
     d.rows = cp.rows;
     d.cols = cp.cols;
-    d.channels = 1;
+    d.channels = channels;
     d.pitch = pitch;
     d.n_images = n_images;
     d.images = imgs.data();

@@ -56,6 +56,7 @@ struct gipuma_hip_session {
     bool combine_reg = false;
     bool unfused = false;
     int box = 0;             // specialised window size, 0 = runtime
+    int ch = 1;              // 1 = gray (T=float), 4 = colour (T=float4)
     unsigned tune = 0;
     size_t lds_sweep = 0, lds_dense = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -68,36 +69,49 @@ using pm::Tune;
 typedef void (*sweep_fn)(const pm::Problem *, float4 *, float *, int, uint32_t, unsigned, unsigned);
 typedef void (*init_fn)(const pm::Problem *, float4 *, float *, unsigned);
 
-template <int BOX>
-sweep_fn pick_sweep_box(bool lut, bool creg)
+template <int BOX, int CH>
+sweep_fn pick_sweep_box(bool u8, bool creg)
 {
-    if (lut) return creg ? pm::sweep_kernel<BOX, true, true, true> : pm::sweep_kernel<BOX, true, false, true>;
-    return creg ? pm::sweep_kernel<BOX, false, true, true> : pm::sweep_kernel<BOX, false, false, true>;
+    if (u8) return creg ? pm::sweep_kernel<BOX, true, true, true, CH> : pm::sweep_kernel<BOX, true, false, true, CH>;
+    return creg ? pm::sweep_kernel<BOX, false, true, true, CH> : pm::sweep_kernel<BOX, false, false, true, CH>;
+}
+
+template <int CH>
+sweep_fn pick_sweep_ch(const gipuma_hip_session *s)
+{
+    switch (s->box) {
+    case 11: return pick_sweep_box<11, CH>(s->u8, s->combine_reg);
+    case 15: return pick_sweep_box<15, CH>(s->u8, s->combine_reg);
+    case 25: return pick_sweep_box<25, CH>(s->u8, s->combine_reg);
+    default: return pick_sweep_box<0, CH>(s->u8, s->combine_reg);
+    }
 }
 
 sweep_fn pick_sweep(const gipuma_hip_session *s)
 {
-    if (s->tune & Tune::kNoInterior) {  // A/B switch, generic window only
-        if (s->box == 15 && s->u8 && s->combine_reg) return pm::sweep_kernel<15, true, true, false>;
-        return s->u8 ? pm::sweep_kernel<0, true, false, false> : pm::sweep_kernel<0, false, false, false>;
+    if (s->ch == 4) return pick_sweep_ch<4>(s);
+    if (s->tune & Tune::kNoInterior) {  // A/B switch, gray only
+        if (s->box == 15 && s->u8 && s->combine_reg) return pm::sweep_kernel<15, true, true, false, 1>;
+        return s->u8 ? pm::sweep_kernel<0, true, false, false, 1> : pm::sweep_kernel<0, false, false, false, 1>;
     }
+    return pick_sweep_ch<1>(s);
+}
+
+template <bool GEN, int CH>
+init_fn pick_init_ch(const gipuma_hip_session *s)
+{
     switch (s->box) {
-    case 11: return pick_sweep_box<11>(s->u8, s->combine_reg);
-    case 15: return pick_sweep_box<15>(s->u8, s->combine_reg);
-    case 25: return pick_sweep_box<25>(s->u8, s->combine_reg);
-    default: return pick_sweep_box<0>(s->u8, s->combine_reg);
+    case 11: return s->u8 ? pm::init_kernel<11, true, false, GEN, CH> : pm::init_kernel<11, false, false, GEN, CH>;
+    case 15: return s->u8 ? pm::init_kernel<15, true, false, GEN, CH> : pm::init_kernel<15, false, false, GEN, CH>;
+    case 25: return s->u8 ? pm::init_kernel<25, true, false, GEN, CH> : pm::init_kernel<25, false, false, GEN, CH>;
+    default: return s->u8 ? pm::init_kernel<0, true, false, GEN, CH> : pm::init_kernel<0, false, false, GEN, CH>;
     }
 }
 
 template <bool GEN>
 init_fn pick_init(const gipuma_hip_session *s)
 {
-    switch (s->box) {
-    case 11: return s->u8 ? pm::init_kernel<11, true, false, GEN> : pm::init_kernel<11, false, false, GEN>;
-    case 15: return s->u8 ? pm::init_kernel<15, true, false, GEN> : pm::init_kernel<15, false, false, GEN>;
-    case 25: return s->u8 ? pm::init_kernel<25, true, false, GEN> : pm::init_kernel<25, false, false, GEN>;
-    default: return s->u8 ? pm::init_kernel<0, true, false, GEN> : pm::init_kernel<0, false, false, GEN>;
-    }
+    return s->ch == 4 ? pick_init_ch<GEN, 4>(s) : pick_init_ch<GEN, 1>(s);
 }
 
 int validate(const gipuma_hip_desc *d)
@@ -107,9 +121,10 @@ int validate(const gipuma_hip_desc *d)
     if (d->rows < 1 || d->cols < 1) return fail(GIPUMA_HIP_ERR_ARG, "rows/cols must be positive");
     if ((long long)d->rows * (long long)d->pitch >= (1LL << 29))
         return fail(GIPUMA_HIP_ERR_ARG, "image too large for 32-bit texel offsets");
-    if (d->channels != 1)
-        return fail(GIPUMA_HIP_ERR_UNSUPPORTED, "only gray (channels == 1) is built; colour is SURVEY 8f row N3");
-    if (d->pitch < d->cols) return fail(GIPUMA_HIP_ERR_ARG, "pitch < cols");
+    if (d->channels != 1 && d->channels != 4)
+        return fail(GIPUMA_HIP_ERR_UNSUPPORTED, "channels must be 1 (gray, T=float) or 4 (colour, T=float4)");
+    if (d->pitch < d->cols * d->channels) return fail(GIPUMA_HIP_ERR_ARG, "pitch < cols*channels");
+    if (d->channels == 4 && (d->pitch & 3)) return fail(GIPUMA_HIP_ERR_ARG, "colour pitch must be a multiple of 4 floats");
     if (d->n_images < 1 || d->n_images > 512 || !d->images || !d->cameras)
         return fail(GIPUMA_HIP_ERR_ARG, "images/cameras missing");
     if (d->n_selected < 0 || d->n_selected > GIPUMA_HIP_MAX_VIEWS || (d->n_selected > 0 && !d->selected))
@@ -132,7 +147,8 @@ void copy3(float *dst, const float *src) { memcpy(dst, src, 3 * sizeof(float)); 
 size_t lds_bytes(const gipuma_hip_session *s, int tile_h, bool with_cv)
 {
     const int hw = (s->hp.box_h + 1) / 2, hh = (s->hp.box_v + 1) / 2;
-    size_t n = pm::kLutSize + (size_t)(pm::kTileW + 2 * hw) * (size_t)(tile_h + 2 * hh);
+    size_t n = (s->ch == 4 ? pm::lut_size<4>() : pm::lut_size<1>()) +
+               (size_t)(pm::kTileW + 2 * hw) * (size_t)(tile_h + 2 * hh) * (size_t)s->ch;
     if (with_cv) n += (size_t)s->n_sel * pm::kThreads;
     return n * sizeof(float);
 }
@@ -220,7 +236,9 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     pm::Problem &hp = s->hp;
     hp.rows = d->rows;
     hp.cols = d->cols;
-    hp.pitch = on_device ? d->pitch : d->cols;
+    s->ch = d->channels;
+    hp.channels = d->channels;
+    hp.pitch = on_device ? d->pitch : d->cols * d->channels;
     hp.n_sel = d->n_selected;
     hp.box_h = d->params.box_hsize;
     hp.box_v = d->params.box_vsize;
@@ -242,12 +260,12 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
             return hipSuccess;
         }
         float *p = nullptr;
-        hipError_t e = hipMalloc(&p, np * sizeof(float));
+        const size_t row_bytes = (size_t)d->cols * d->channels * sizeof(float);
+        hipError_t e = hipMalloc(&p, row_bytes * d->rows);
         if (e != hipSuccess) return e;
         s->owned.push_back(p);
         *dst = p;
-        return hipMemcpy2DAsync(p, (size_t)d->cols * sizeof(float), d->images[idx],
-                                (size_t)d->pitch * sizeof(float), (size_t)d->cols * sizeof(float),
+        return hipMemcpy2DAsync(p, row_bytes, d->images[idx], (size_t)d->pitch * sizeof(float), row_bytes,
                                 (size_t)d->rows, hipMemcpyHostToDevice, s->stream);
     };
     CREATE_OK(resident(0, &hp.ref));
@@ -259,11 +277,11 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         CREATE_OK(hipMalloc(&s->flag, sizeof(int)));
         CREATE_OK(hipMemsetAsync(s->flag, 0, sizeof(int), s->stream));
         const dim3 cg((d->cols + pm::kThreads - 1) / pm::kThreads, d->rows);
-        hipLaunchKernelGGL(pm::check_u8_kernel, cg, dim3(pm::kThreads), 0, s->stream, hp.ref, hp.rows, hp.cols,
-                           hp.pitch, s->flag);
+        auto check = s->ch == 4 ? pm::check_u8_kernel_c4 : pm::check_u8_kernel;
+        hipLaunchKernelGGL(check, cg, dim3(pm::kThreads), 0, s->stream, hp.ref, hp.rows, hp.cols, hp.pitch, s->flag);
         for (int i = 0; i < d->n_selected; i++)
-            hipLaunchKernelGGL(pm::check_u8_kernel, cg, dim3(pm::kThreads), 0, s->stream, hp.view[i].img,
-                               hp.rows, hp.cols, hp.pitch, s->flag);
+            hipLaunchKernelGGL(check, cg, dim3(pm::kThreads), 0, s->stream, hp.view[i].img, hp.rows, hp.cols,
+                               hp.pitch, s->flag);
         CREATE_OK(hipGetLastError());
         int not_u8 = 1;
         CREATE_OK(hipMemcpyAsync(&not_u8, s->flag, sizeof(int), hipMemcpyDeviceToHost, s->stream));
@@ -271,14 +289,15 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         s->u8 = !not_u8 && !(s->tune & Tune::kNoLut);
         hp.pw = d->cols + 8;
         if (s->u8) {
-            const size_t words = (size_t)(d->rows + 3) * hp.pw;
+            const size_t words = (size_t)(d->rows + 3) * hp.pw * (s->ch == 4 ? 3 : 1);
+            auto pack = s->ch == 4 ? pm::pack_kernel_c4 : pm::pack_kernel;
             const dim3 pgid((hp.pw + pm::kThreads - 1) / pm::kThreads, d->rows + 3);
             for (int i = 0; i < d->n_selected; i++) {
                 uint32_t *pk = nullptr;
                 CREATE_OK(hipMalloc(&pk, words * sizeof(uint32_t)));
                 s->packed.push_back(pk);
                 hp.view[i].packed = pk;
-                hipLaunchKernelGGL(pm::pack_kernel, pgid, dim3(pm::kThreads), 0, s->stream, hp.view[i].img,
+                hipLaunchKernelGGL(pack, pgid, dim3(pm::kThreads), 0, s->stream, hp.view[i].img,
                                    hp.rows, hp.cols, hp.pitch, hp.pw, pk);
             }
             CREATE_OK(hipGetLastError());

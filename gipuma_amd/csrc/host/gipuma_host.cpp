@@ -351,6 +351,37 @@ bool read_pnm_gray(const std::string &path, std::vector<float> &img, int &rows, 
     return true;
 }
 
+bool read_pnm_colour(const std::string &path, std::vector<float> &img, int &rows, int &cols)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    int maxv = 0;
+    auto next_int = [&](int &v) {
+        int c = fgetc(f);
+        while (c == '#' || isspace(c)) {
+            if (c == '#') while (c != '\n' && c != EOF) c = fgetc(f);
+            c = fgetc(f);
+        }
+        v = 0;
+        while (isdigit(c)) { v = 10 * v + (c - '0'); c = fgetc(f); }
+    };
+    char magic[2];
+    if (fread(magic, 1, 2, f) != 2 || magic[0] != 'P' || magic[1] != '6') { fclose(f); return false; }
+    next_int(cols); next_int(rows); next_int(maxv);
+    if (cols < 1 || rows < 1 || maxv != 255) { fclose(f); return false; }
+    std::vector<unsigned char> raw((size_t)rows * cols * 3);
+    const bool ok = fread(raw.data(), 1, raw.size(), f) == raw.size();
+    fclose(f);
+    if (!ok) return false;
+    img.assign((size_t)rows * cols * 4, 0.0f);
+    for (size_t k = 0; k < (size_t)rows * cols; k++) {
+        img[4 * k + 0] = (float)raw[3 * k + 2];  // B
+        img[4 * k + 1] = (float)raw[3 * k + 1];  // G
+        img[4 * k + 2] = (float)raw[3 * k + 0];  // R
+    }
+    return true;
+}
+
 int write_dmb(const std::string &path, const float *data, int rows, int cols, int nb)
 {  // writeDmb / writeDmbNormal, fileIoUtils.h:320-368: int32 {type=1, h, w, nb} + h*w*nb float32
     FILE *f = fopen(path.c_str(), "wb");
@@ -384,10 +415,6 @@ int run_gipuma(const InputFiles &in, const OutputFiles &out, AlgorithmParameters
         printf("Command-line parameter error: at least 2 images must be specified\n");
         return -1;
     }
-    if (ap.color_processing) {
-        printf("-color_processing is not built yet on the MI355X path\n");
-        return -1;
-    }
     const int n = (int)in.img_filenames.size();
     // result folder <parent>/<YYYYMMDD_HHMMSS>_<refname>/, main.cpp:702-723
     time_t tt;
@@ -405,7 +432,9 @@ int run_gipuma(const InputFiles &in, const OutputFiles &out, AlgorithmParameters
     int rows = 0, cols = 0;
     for (int i = 0; i < n; i++) {
         int r, c;
-        if (!read_pnm_gray(in.images_folder + in.img_filenames[i], imgs[i], r, c) || (i && (r != rows || c != cols))) {
+        const std::string path = in.images_folder + in.img_filenames[i];
+        const bool ok = ap.color_processing ? read_pnm_colour(path, imgs[i], r, c) : read_pnm_gray(path, imgs[i], r, c);
+        if (!ok || (i && (r != rows || c != cols))) {
             printf("Image seems to be invalid\n");
             return -1;
         }
@@ -442,7 +471,8 @@ int run_gipuma(const InputFiles &in, const OutputFiles &out, AlgorithmParameters
     for (int i = 0; i < n; i++) ptrs[i] = imgs[i].data();
     gipuma_hip_desc d{};
     d.abi_version = GIPUMA_HIP_ABI_VERSION;
-    d.rows = rows; d.cols = cols; d.channels = 1; d.pitch = cols; d.n_images = n;
+    d.rows = rows; d.cols = cols; d.channels = ap.color_processing ? 4 : 1; d.pitch = cols * d.channels;
+    d.n_images = n;
     d.images = ptrs.data(); d.cameras = cs.cams.data();
     d.n_selected = (int)subset.size(); d.selected = subset.data();
     d.params.box_hsize = ap.box_hsize; d.params.box_vsize = ap.box_vsize; d.params.iterations = ap.iterations;

@@ -69,6 +69,8 @@ void get_camera_parameters(const std::vector<double> &P_list, int n, float cam_s
 std::vector<int> select_views(const CameraSet &cs, int cols, int rows, AlgorithmParameters &ap);
 
 bool read_pnm_gray(const std::string &path, std::vector<float> &img, int &rows, int &cols);
+// -color_processing: P6 only, float4 texels B, G, R, 0 (imread(IMREAD_COLOR) order, main.cpp:943-956)
+bool read_pnm_colour(const std::string &path, std::vector<float> &img, int &rows, int &cols);
 int write_dmb(const std::string &path, const float *data, int rows, int cols, int nb);
 bool read_dmb(const std::string &path, std::vector<float> &data, int &rows, int &cols, int &nb);
 

@@ -40,7 +40,7 @@ struct Problem {  // lives in device memory, read through scalar loads (wave-uni
     float min_disp, max_disp, good_factor;
     uint32_t seed;
     const float *ref;
-    int pw, pad2;  // packed layout: words per row of V (cols + 8)
+    int pw, channels;  // packed layout: texels per row of V (cols + 8); 1 = gray, 4 = colour
     RefCam rc;
     ViewCam view[kMaxViews];
 };
@@ -196,7 +196,12 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v,
 //   [256, 256 + tw*th)           reference-image tile with halo R = (box+1)/2 (gipuma.cu:1844-1855)
 //   [.., + n_sel*256)            per-lane view-cost columns (only for the generic combiner)
 // ---------------------------------------------------------------------------------------------
-constexpr int kLutSize = 256;
+constexpr int kLutSize = 256;  // gray: |dI| = 0..255
+template <int CH>
+__host__ __device__ constexpr int lut_size()
+{
+    return CH == 4 ? 768 : kLutSize;  // colour: |dB|+|dG|+|dR| = 0..765
+}
 
 template <int BOX>
 struct Win {  // window geometry: compile-time for the shipped block sizes, runtime for BOX == 0
@@ -296,6 +301,68 @@ __global__ __launch_bounds__(kThreads) void check_u8_kernel(const float *__restr
     if (!(v >= 0.0f && v <= 255.0f) || v != __builtin_floorf(v)) atomicOr(flag, 1);
 }
 
+// The five bilinear taps of pmCostComputation_shared (gipuma.cu:251-253) from one 4x4 window
+// (M1): centre value and the +-1 texel differences in x and y.  t<row><col>, corners unused.
+struct Taps {
+    float sc, gx2, gy2;
+};
+__device__ __forceinline__ Taps taps12(float a, float b, float t01, float t02, float t10, float t11, float t12,
+                                       float t13, float t20, float t21, float t22, float t23, float t31,
+                                       float t32)
+{
+    const float C0 = lerp(a, t01, t02);
+    const float L1 = lerp(a, t10, t11), C1 = lerp(a, t11, t12), R1 = lerp(a, t12, t13);
+    const float L2 = lerp(a, t20, t21), C2 = lerp(a, t21, t22), R2 = lerp(a, t22, t23);
+    const float C3 = lerp(a, t31, t32);
+    Taps o;
+    o.sc = lerp(b, C1, C2);
+    o.gx2 = lerp(b, R1, R2) - lerp(b, L1, L2);
+    o.gy2 = lerp(b, C2, C3) - lerp(b, C0, C1);
+    return o;
+}
+// window words w0..w3 = columns X..X+3, byte r = row Y+r
+__device__ __forceinline__ Taps taps_u8(float a, float b, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3)
+{
+    return taps12(a, b, ub0(w1), ub0(w2), ub1(w0), ub1(w1), ub1(w2), ub1(w3), ub2(w0), ub2(w1), ub2(w2),
+                  ub2(w3), ub3(w1), ub3(w2));
+}
+
+// colour (float4 texels: B, G, R, unused): V3[Y][X][c], c = 0..2 -- the window of all three
+// channels is 12 consecutive words (word 3k+c = column X+k, channel c): three dwordx4 loads
+__global__ __launch_bounds__(kThreads) void pack_kernel_c4(const float *__restrict__ img, int rows, int cols,
+                                                           int pitch, int pw, uint32_t *__restrict__ packed)
+{
+    const int X = blockIdx.x * kThreads + threadIdx.x;
+    const int Y = blockIdx.y;
+    if (X >= pw) return;
+    const int x = clampi(X - 3, 0, cols - 1);
+    uint32_t w[3] = {0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int y = clampi(Y + r - 3, 0, rows - 1);
+#pragma unroll
+        for (int c = 0; c < 3; c++) w[c] |= ((uint32_t)img[y * pitch + 4 * x + c] & 0xffu) << (8 * r);
+    }
+    uint32_t *o = packed + ((size_t)Y * pw + X) * 3;
+    o[0] = w[0];
+    o[1] = w[1];
+    o[2] = w[2];
+}
+
+__global__ __launch_bounds__(kThreads) void check_u8_kernel_c4(const float *__restrict__ img, int rows, int cols,
+                                                               int pitch, int *__restrict__ flag)
+{
+    const int x = blockIdx.x * kThreads + threadIdx.x, y = blockIdx.y;
+    if (x >= cols || y >= rows) return;
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float v = img[y * pitch + 4 * x + c];
+        bad |= !(v >= 0.0f && v <= 255.0f) || v != __builtin_floorf(v);
+    }
+    if (bad) atomicOr(flag, 1);
+}
+
 // Patch cost of one source view: pmCost_shared + pmCostComputation_shared,
 // gipuma.cu:585-680 and :223-277.  `tp0` points at the pixel's own texel inside the LDS tile.
 template <int BOX, bool U8, bool INTERIOR>
@@ -345,7 +412,7 @@ __device__ __forceinline__ float view_cost(const Problem *__restrict__ P, const 
             // M1: five bilinear taps sharing one 4x4 texel window (gipuma.cu:251-253)
             const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
             const float a = sx - fx0, b = sy - fy0;
-            float t01, t02, t10, t11, t12, t13, t20, t21, t22, t23, t31, t32;
+            Taps tp5;
             if (U8) {  // U8 mode: the whole window is one 16-byte load
                 // X = clamp(floor(sx), -2, cols) + 2, same for Y: the +2 is exact wherever the
                 // clamp does not saturate
@@ -353,63 +420,27 @@ __device__ __forceinline__ float view_cost(const Problem *__restrict__ P, const 
                 const uint32_t Y = min(cvt_u32_sat(fy0 + 2.0f), ymax);
                 const uint32_t off = (Y * pw + X) << 2;
                 const u32x4_a4 wv = *(gptr_u32x4)((gptr_bytes)packed + off);
-                t10 = ub1(wv.x);
-                t20 = ub2(wv.x);
-                t01 = ub0(wv.y);
-                t11 = ub1(wv.y);
-                t21 = ub2(wv.y);
-                t31 = ub3(wv.y);
-                t02 = ub0(wv.z);
-                t12 = ub1(wv.z);
-                t22 = ub2(wv.z);
-                t32 = ub3(wv.z);
-                t13 = ub1(wv.w);
-                t23 = ub2(wv.w);
+                tp5 = taps_u8(a, b, wv.x, wv.y, wv.z, wv.w);
             } else {
                 // float planes: keep the float->int conversion defined for huge / NaN coordinates
                 const int ix = (int)__builtin_fminf(__builtin_fmaxf(fx0, -2.0f), colsf);
                 const int iy = (int)__builtin_fminf(__builtin_fmaxf(fy0, -2.0f), rowsf);
                 const bool inside = ix >= 1 && ix <= cols - 3 && iy >= 1 && iy <= rows - 3;
                 if (INTERIOR && __all(inside)) {
-                const gptr_f32 s = img + (iy * pitch + ix);
-                t01 = s[-pitch];
-                t02 = s[-pitch + 1];
-                t10 = s[-1];
-                t11 = s[0];
-                t12 = s[1];
-                t13 = s[2];
-                t20 = s[pitch - 1];
-                t21 = s[pitch];
-                t22 = s[pitch + 1];
-                t23 = s[pitch + 2];
-                t31 = s[2 * pitch];
-                t32 = s[2 * pitch + 1];
-            } else {
-                const int c0 = clampi(ix - 1, 0, cols - 1), c1 = clampi(ix, 0, cols - 1);
-                const int c2 = clampi(ix + 1, 0, cols - 1), c3 = clampi(ix + 2, 0, cols - 1);
-                const int r0 = clampi(iy - 1, 0, rows - 1) * pitch, r1 = clampi(iy, 0, rows - 1) * pitch;
-                const int r2 = clampi(iy + 1, 0, rows - 1) * pitch, r3 = clampi(iy + 2, 0, rows - 1) * pitch;
-                t01 = img[r0 + c1];
-                t02 = img[r0 + c2];
-                t10 = img[r1 + c0];
-                t11 = img[r1 + c1];
-                t12 = img[r1 + c2];
-                t13 = img[r1 + c3];
-                t20 = img[r2 + c0];
-                t21 = img[r2 + c1];
-                t22 = img[r2 + c2];
-                t23 = img[r2 + c3];
-                t31 = img[r3 + c1];
-                t32 = img[r3 + c2];
+                    const gptr_f32 s = img + (iy * pitch + ix);
+                    tp5 = taps12(a, b, s[-pitch], s[-pitch + 1], s[-1], s[0], s[1], s[2], s[pitch - 1], s[pitch],
+                                 s[pitch + 1], s[pitch + 2], s[2 * pitch], s[2 * pitch + 1]);
+                } else {
+                    const int c0 = clampi(ix - 1, 0, cols - 1), c1 = clampi(ix, 0, cols - 1);
+                    const int c2 = clampi(ix + 1, 0, cols - 1), c3 = clampi(ix + 2, 0, cols - 1);
+                    const int r0 = clampi(iy - 1, 0, rows - 1) * pitch, r1 = clampi(iy, 0, rows - 1) * pitch;
+                    const int r2 = clampi(iy + 1, 0, rows - 1) * pitch, r3 = clampi(iy + 2, 0, rows - 1) * pitch;
+                    tp5 = taps12(a, b, img[r0 + c1], img[r0 + c2], img[r1 + c0], img[r1 + c1], img[r1 + c2],
+                                 img[r1 + c3], img[r2 + c0], img[r2 + c1], img[r2 + c2], img[r2 + c3],
+                                 img[r3 + c1], img[r3 + c2]);
                 }
             }
-            const float C0 = lerp(a, t01, t02);
-            const float L1 = lerp(a, t10, t11), C1 = lerp(a, t11, t12), R1 = lerp(a, t12, t13);
-            const float L2 = lerp(a, t20, t21), C2 = lerp(a, t21, t22), R2 = lerp(a, t22, t23);
-            const float C3 = lerp(a, t31, t32);
-            const float sc = lerp(b, C1, C2);
-            const float gx2 = lerp(b, R1, R2) - lerp(b, L1, L2);
-            const float gy2 = lerp(b, C2, C3) - lerp(b, C0, C1);
+            const float sc = tp5.sc, gx2 = tp5.gx2, gy2 = tp5.gy2;
             // pmCostComputation_shared, gipuma.cu:251-274
             const float colDiff = __builtin_fabsf(leftValue - sc);
             const float gx1 = tp[1] - tp[-1];
@@ -426,11 +457,107 @@ __device__ __forceinline__ float view_cost(const Problem *__restrict__ P, const 
     return cost;
 }
 
+// The same patch cost instantiated for T = float4 (-color_processing, gipuma.cu:1965-1968): every
+// image difference is taken per channel and reduced with l1_norm(float4) = mean |.| of x, y, z
+// (gipuma.cu:174-179; the float4 operators zero .w, vector_operations.h:9-14).  `tp0` points at the
+// lane's own texel in a float4 LDS tile.  U8: weight table indexed by the integer
+// |dB|+|dG|+|dR| (766 values), three 16-byte loads for the 4x4x3 window.
+__device__ __forceinline__ float l1_3(float x, float y, float z)
+{
+    return (__builtin_fabsf(x) + __builtin_fabsf(y) + __builtin_fabsf(z)) * 0.3333333f;
+}
+
+template <int BOX, bool U8>
+__device__ __forceinline__ float view_cost_c4(const Problem *__restrict__ P, const ViewCam &vc,
+                                              const float *__restrict__ tp0, int tw,
+                                              const float *__restrict__ lut, int px, int py, float4 pl,
+                                              const Win<BOX> &win)
+{
+    float H[9];
+    homography(P->rc.K_inv, vc, pl, H);
+    const gptr_f32 img = (gptr_f32)vc.img;
+    const uint32_t *__restrict__ packed = vc.packed;
+    const uint32_t pw = (uint32_t)P->pw;
+    const uint32_t xmax = (uint32_t)(P->cols + 2), ymax = (uint32_t)(P->rows + 2);
+    const int rows = P->rows, cols = P->cols, pitch = P->pitch;
+    const float colsf = (float)cols, rowsf = (float)rows;
+    const float alpha = P->alpha, oma = 1.f - P->alpha;
+    const float tau_color = P->tau_color, tau_gradient = P->tau_gradient, gamma = P->gamma;
+    const float4 centre = *reinterpret_cast<const float4 *>(tp0);
+    const int hr = win.hrad(), vr = win.vrad();
+    float cost = 0.0f;
+    const float pyf = (float)py;
+    float qx = (float)(px - hr);
+    for (int i = -hr; i <= hr; i += 2, qx += 2.0f) {
+        const float X0 = __builtin_fmaf(H[0], qx, H[2]);
+        const float Y0 = __builtin_fmaf(H[3], qx, H[5]);
+        const float Z0 = __builtin_fmaf(H[6], qx, H[8]);
+        for (int j = -vr; j <= vr; j += 2) {
+            const float *tp = tp0 + 4 * (j * tw + i);
+            const float qy = pyf + (float)j;
+            const float4 lv = *reinterpret_cast<const float4 *>(tp);
+            float w;
+            if (U8) {
+                const float S = __builtin_fabsf(lv.x - centre.x) + __builtin_fabsf(lv.y - centre.y) +
+                                __builtin_fabsf(lv.z - centre.z);  // exact integer 0..765
+                w = lut[(int)S];
+            } else {
+                w = exp_model(-l1_3(lv.x - centre.x, lv.y - centre.y, lv.z - centre.z) / gamma);
+            }
+            const float X = __builtin_fmaf(H[1], qy, X0);
+            const float Y = __builtin_fmaf(H[4], qy, Y0);
+            const float Z = __builtin_fmaf(H[7], qy, Z0);
+            const float rz = 1.0f / Z;
+            const float sx = X * rz, sy = Y * rz;
+            const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
+            const float a = sx - fx0, b = sy - fy0;
+            Taps t[3];
+            if (U8) {
+                const uint32_t Xw = min(cvt_u32_sat(fx0 + 2.0f), xmax);
+                const uint32_t Yw = min(cvt_u32_sat(fy0 + 2.0f), ymax);
+                const uint32_t off = (Yw * pw + Xw) * 12u;
+                const gptr_bytes base = (gptr_bytes)packed + off;
+                const u32x4_a4 q0 = *(gptr_u32x4)(base), q1 = *(gptr_u32x4)(base + 16), q2 = *(gptr_u32x4)(base + 32);
+                // word 3k+c = column k, channel c
+                t[0] = taps_u8(a, b, q0.x, q0.w, q1.z, q2.y);
+                t[1] = taps_u8(a, b, q0.y, q1.x, q1.w, q2.z);
+                t[2] = taps_u8(a, b, q0.z, q1.y, q2.x, q2.w);
+            } else {
+                const int ix = (int)__builtin_fminf(__builtin_fmaxf(fx0, -2.0f), colsf);
+                const int iy = (int)__builtin_fminf(__builtin_fmaxf(fy0, -2.0f), rowsf);
+                const int c0 = 4 * clampi(ix - 1, 0, cols - 1), c1 = 4 * clampi(ix, 0, cols - 1);
+                const int c2 = 4 * clampi(ix + 1, 0, cols - 1), c3 = 4 * clampi(ix + 2, 0, cols - 1);
+                const int r0 = clampi(iy - 1, 0, rows - 1) * pitch, r1 = clampi(iy, 0, rows - 1) * pitch;
+                const int r2 = clampi(iy + 1, 0, rows - 1) * pitch, r3 = clampi(iy + 2, 0, rows - 1) * pitch;
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+                    t[c] = taps12(a, b, img[r0 + c1 + c], img[r0 + c2 + c], img[r1 + c0 + c], img[r1 + c1 + c],
+                                  img[r1 + c2 + c], img[r1 + c3 + c], img[r2 + c0 + c], img[r2 + c1 + c],
+                                  img[r2 + c2 + c], img[r2 + c3 + c], img[r3 + c1 + c], img[r3 + c2 + c]);
+            }
+            const float4 up = *reinterpret_cast<const float4 *>(tp - 4 * tw);
+            const float4 down = *reinterpret_cast<const float4 *>(tp + 4 * tw);
+            const float4 left = *reinterpret_cast<const float4 *>(tp - 4);
+            const float4 right = *reinterpret_cast<const float4 *>(tp + 4);
+            const float colDiff = l1_3(lv.x - t[0].sc, lv.y - t[1].sc, lv.z - t[2].sc);
+            const float gX = l1_3((right.x - left.x) - t[0].gx2, (right.y - left.y) - t[1].gx2,
+                                  (right.z - left.z) - t[2].gx2);
+            const float gY = l1_3((down.x - up.x) - t[0].gy2, (down.y - up.y) - t[1].gy2,
+                                  (down.z - up.z) - t[2].gy2);
+            const float gradDis = __builtin_fminf((gX + gY) * 0.0625f, tau_gradient);
+            const float colDis = __builtin_fminf(colDiff, tau_color);
+            const float dis = __builtin_fmaf(alpha, gradDis, oma * colDis);
+            cost = __builtin_fmaf(w, dis, cost);
+        }
+    }
+    return cost;
+}
+
 // pmCostMultiview_cu, gipuma.cu:720-806.  COMBINE_REG: best-N with n_best <= 4 keeps the four
 // smallest view costs in registers (a sorting-network insert per view, same values and the same
 // ascending summation order as sort_small + the loop at :781-797); otherwise the view costs go
 // through a per-lane LDS column and the literal insertion sort.
-template <int BOX, bool U8, bool INTERIOR, bool COMBINE_REG>
+template <int BOX, bool U8, bool INTERIOR, bool COMBINE_REG, int CH>
 __device__ __forceinline__ float multiview_cost(const Problem *__restrict__ P, const float *__restrict__ tp0,
                                                 int tw, const float *__restrict__ lut, float *cv, int px,
                                                 int py, float4 pl, const Win<BOX> &win)
@@ -439,7 +566,11 @@ __device__ __forceinline__ float multiview_cost(const Problem *__restrict__ P, c
     int numValid = 0;
     float b0 = kMaxCost, b1 = kMaxCost, b2 = kMaxCost, b3 = kMaxCost;
     for (int v = 0; v < n; v++) {
-        float c = view_cost<BOX, U8, INTERIOR>(P, P->view[v], tp0, tw, lut, px, py, pl, win);
+        float c;
+        if (CH == 4)
+            c = view_cost_c4<BOX, U8>(P, P->view[v], tp0, tw, lut, px, py, pl, win);
+        else
+            c = view_cost<BOX, U8, INTERIOR>(P, P->view[v], tp0, tw, lut, px, py, pl, win);
         if (c < kMaxCost)
             numValid++;
         else
@@ -525,21 +656,28 @@ __device__ __forceinline__ TileXY tile_of(int b, int gx, int gy, unsigned tune)
 
 // stage the reference tile (+halo) and the weight table; the tile holds clamp-to-edge point
 // samples exactly like the reference's (gipuma.cu:1393-1402, 1513-1522)
-template <int BOX>
+template <int BOX, int CH>
 __device__ __forceinline__ void stage_tile(const Problem *__restrict__ P, float *lds, int x0, int y0,
                                            int tile_h, const Win<BOX> &win, bool want_lut)
 {
     const int hw = win.halo_w(), hh = win.halo_h();
     const int tw = kTileW + 2 * hw, th = tile_h + 2 * hh;
     const gptr_f32 ref = (gptr_f32)P->ref;
-    float *tile = lds + kLutSize;
+    float *tile = lds + lut_size<CH>();
     for (int k = threadIdx.x; k < tw * th; k += kThreads) {
         const int ty = k / tw, tx = k - ty * tw;
         const int gx = clampi(x0 - hw + tx, 0, P->cols - 1);
         const int gy = clampi(y0 - hh + ty, 0, P->rows - 1);
-        tile[k] = ref[gy * P->pitch + gx];
+        if (CH == 4) {
+            const gptr_f32 s = ref + (gy * P->pitch + 4 * gx);
+            *reinterpret_cast<float4 *>(tile + 4 * k) = make_float4(s[0], s[1], s[2], 0.0f);
+        } else {
+            tile[k] = ref[gy * P->pitch + gx];
+        }
     }
-    if (want_lut) lds[threadIdx.x] = exp_model(-(float)threadIdx.x / P->gamma);
+    if (want_lut)
+        for (int k = threadIdx.x; k < lut_size<CH>(); k += kThreads)
+            lds[k] = exp_model(-(CH == 4 ? (float)k * 0.3333333f : (float)k) / P->gamma);
     __syncthreads();
 }
 
@@ -548,7 +686,7 @@ __device__ __forceinline__ void stage_tile(const Problem *__restrict__ P, float 
 // ---------------------------------------------------------------------------------------------
 // gipuma_init_cu2 (gipuma.cu:996-1051) when GENERATE, else the cost of a given plane field
 // (gipuma_initial_cost, :1052-1079).  32x8 tile, one lane per pixel.
-template <int BOX, bool U8, bool COMBINE_REG, bool GENERATE>
+template <int BOX, bool U8, bool COMBINE_REG, bool GENERATE, int CH>
 __global__ __launch_bounds__(kThreads) void init_kernel(const Problem *__restrict__ P,
                                                         float4 *__restrict__ norm4, float *__restrict__ cost,
                                                         unsigned tune)
@@ -559,14 +697,14 @@ __global__ __launch_bounds__(kThreads) void init_kernel(const Problem *__restric
     const int gy = (P->rows + kDenseTileH - 1) / kDenseTileH;
     const TileXY txy = tile_of(blockIdx.x, gx, gy, tune);
     const int x0 = txy.x * kTileW, y0 = txy.y * kDenseTileH;
-    stage_tile<BOX>(P, lds, x0, y0, kDenseTileH, win, U8);
+    stage_tile<BOX, CH>(P, lds, x0, y0, kDenseTileH, win, U8);
     const int hw = win.halo_w(), hh = win.halo_h();
     const int tw = kTileW + 2 * hw;
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
     const int px = x0 + lx, py = y0 + ly;
     if (px >= P->cols || py >= P->rows) return;
-    const float *tp0 = lds + kLutSize + (ly + hh) * tw + (lx + hw);
-    float *cv = lds + kLutSize + tw * (kDenseTileH + 2 * hh) + threadIdx.x;
+    const float *tp0 = lds + lut_size<CH>() + ((ly + hh) * tw + (lx + hw)) * CH;
+    float *cv = lds + lut_size<CH>() + tw * (kDenseTileH + 2 * hh) * CH + threadIdx.x;
     const int center = py * P->cols + px;
     float4 pl;
     if (GENERATE) {
@@ -596,9 +734,9 @@ __global__ __launch_bounds__(kThreads) void init_kernel(const Problem *__restric
     }
     float c;
     if (tune & Tune::kNoInterior)
-        c = multiview_cost<BOX, U8, false, COMBINE_REG>(P, tp0, tw, lds, cv, px, py, pl, win);
+        c = multiview_cost<BOX, U8, false, COMBINE_REG, CH>(P, tp0, tw, lds, cv, px, py, pl, win);
     else
-        c = multiview_cost<BOX, U8, true, COMBINE_REG>(P, tp0, tw, lds, cv, px, py, pl, win);
+        c = multiview_cost<BOX, U8, true, COMBINE_REG, CH>(P, tp0, tw, lds, cv, px, py, pl, win);
     cost[center] = c;
 }
 
@@ -608,7 +746,7 @@ __global__ __launch_bounds__(kThreads) void init_kernel(const Problem *__restric
 // of a colour reads only its own state and pixels of the OTHER colour (distances 1 and 5 are odd,
 // :1730-1734), which no lane of this launch writes.  `stages` selects a subset so the three
 // reference launches can also be reproduced one by one.
-template <int BOX, bool U8, bool COMBINE_REG, bool INTERIOR>
+template <int BOX, bool U8, bool COMBINE_REG, bool INTERIOR, int CH>
 __global__ __launch_bounds__(kThreads) void sweep_kernel(const Problem *__restrict__ P,
                                                          float4 *__restrict__ norm4, float *__restrict__ cost,
                                                          int colour, uint32_t phase, unsigned stages,
@@ -622,7 +760,7 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(const Problem *__restri
     const int gy = (rows + kSweepTileH - 1) / kSweepTileH;
     const TileXY txy = tile_of(blockIdx.x, gx, gy, tune);
     const int x0 = txy.x * kTileW, y0 = txy.y * kSweepTileH;
-    stage_tile<BOX>(P, lds, x0, y0, kSweepTileH, win, U8);
+    stage_tile<BOX, CH>(P, lds, x0, y0, kSweepTileH, win, U8);
     const int hw = win.halo_w(), hh = win.halo_h();
     const int tw = kTileW + 2 * hw;
     // lane -> pixel: 16 pixels of the colour per tile row; a wavefront covers 4 rows x 32 columns
@@ -630,8 +768,8 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(const Problem *__restri
     const int lx = 2 * (threadIdx.x & 15) + ((ly + colour) & 1);  // tile origin is even in x and y
     const int px = x0 + lx, py = y0 + ly;
     if (px >= cols || py >= rows) return;
-    const float *tp0 = lds + kLutSize + (ly + hh) * tw + (lx + hw);
-    float *cv = lds + kLutSize + tw * (kSweepTileH + 2 * hh) + threadIdx.x;
+    const float *tp0 = lds + lut_size<CH>() + ((ly + hh) * tw + (lx + hw)) * CH;
+    float *cv = lds + lut_size<CH>() + tw * (kSweepTileH + 2 * hh) * CH + threadIdx.x;
     const int center = py * cols + px;
 
     // read state (gipuma.cu:1527-1530)
@@ -656,7 +794,7 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(const Problem *__restri
             const float4 cand = norm4[nb];
             const float d_before = depth_from_plane(rc, cand, px, py);
             const float c_before =
-                multiview_cost<BOX, U8, INTERIOR, COMBINE_REG>(P, tp0, tw, lds, cv, px, py, cand, win);
+                multiview_cost<BOX, U8, INTERIOR, COMBINE_REG, CH>(P, tp0, tw, lds, cv, px, py, cand, win);
             if (d_before >= rc.depth_min && d_before <= rc.depth_max && c_before < cst) {
                 depth = d_before;
                 pl = cand;
@@ -691,7 +829,7 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(const Problem *__restri
             n = on_hemisphere(normalize3(n), view);
             const float4 cand = make_float4(n.x, n.y, n.z, plane_d(rc, n, px, py, depthOut));
             const float c =
-                multiview_cost<BOX, U8, INTERIOR, COMBINE_REG>(P, tp0, tw, lds, cv, px, py, cand, win);
+                multiview_cost<BOX, U8, INTERIOR, COMBINE_REG, CH>(P, tp0, tw, lds, cv, px, py, cand, win);
             if (c < cst) {
                 cst = c;
                 depth = depthOut;

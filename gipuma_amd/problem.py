@@ -64,20 +64,26 @@ class GlobalState:
     """
 
     def __init__(self, images, camera_set, selected, params, seed=1, device_ptrs=None,
-                 rows=None, cols=None, pitch=None, device_id=0, stream=None, flags=0):
+                 rows=None, cols=None, pitch=None, device_id=0, stream=None, flags=0, channels=1):
         self.params = params
         self.cameras = camera_set
         self.selected = list(selected)
         if len(self.selected) > abi.MAX_VIEWS:
             raise ValueError("at most %d selected views (gipuma.cu:736)" % abi.MAX_VIEWS)
+        # gray: (rows, cols) planes; -color_processing: (rows, cols, 4) = B, G, R, unused alpha
+        # (main.cpp:943-956), pitch counted in floats
         if device_ptrs is None:
             self.images = [np.ascontiguousarray(im, dtype=np.float32) for im in images]
-            self.rows, self.cols = self.images[0].shape
-            self.pitch = self.cols
+            self.rows, self.cols = self.images[0].shape[:2]
+            self.channels = 4 if self.images[0].ndim == 3 else 1
+            if self.channels == 4 and self.images[0].shape[2] != 4:
+                raise ValueError("colour images must be (rows, cols, 4)")
+            self.pitch = self.cols * self.channels
             ptrs = [im.ctypes.data for im in self.images]
         else:
             self.images = images  # keep whatever owns the device memory alive
-            self.rows, self.cols, self.pitch = rows, cols, pitch or cols
+            self.channels = channels
+            self.rows, self.cols, self.pitch = rows, cols, pitch or cols * channels
             ptrs = list(device_ptrs)
             flags |= abi.FLAG_IMAGES_ON_DEVICE
         n = len(ptrs)
@@ -92,7 +98,7 @@ class GlobalState:
         self._sel = (C.c_int32 * max(1, len(self.selected)))(*self.selected)
         d = abi.Desc()
         d.abi_version = abi.ABI_VERSION
-        d.rows, d.cols, d.channels, d.pitch = self.rows, self.cols, 1, self.pitch
+        d.rows, d.cols, d.channels, d.pitch = self.rows, self.cols, self.channels, self.pitch
         d.n_images = n
         d.images = C.cast(self._img_ptrs, C.POINTER(C.c_void_p))
         d.cameras = C.cast(camera_set.c_array, C.POINTER(abi.Camera))

@@ -101,9 +101,10 @@ def _value_noise(u, v, seed):
     return (n00 * (1 - su) + n10 * su) * (1 - sv) + (n01 * (1 - su) + n11 * su) * sv
 
 
-def render(surface, K, R, t, rows, cols, device="cpu"):
+def render(surface, K, R, t, rows, cols, device="cpu", colour=False):
     """Image (float32 0..255, 8-bit quantised) and depth of the surface seen by the camera
-    K [R | t] (pose relative to the reference camera)."""
+    K [R | t] (pose relative to the reference camera).  colour: (rows, cols, 4) = B, G, R and an
+    alpha channel the path must ignore (main.cpp:943-956 leaves it unset)."""
     dt = torch.float64
     K = torch.as_tensor(K, dtype=dt, device=device)
     R = torch.as_tensor(R, dtype=dt, device=device)
@@ -121,9 +122,20 @@ def render(surface, K, R, t, rows, cols, device="cpu"):
         gp = dirs[..., 2] - (hx * dirs[..., 0] + hy * dirs[..., 1])
         lam = lam - g / gp
     X = o + lam[..., None] * dirs
-    img = torch.clamp(torch.round(20.0 + 215.0 * surface.albedo(X[..., 0], X[..., 1])), 0, 255)
     depth = (X @ R.T + t)[..., 2]                        # depth in this camera
-    return img.to(torch.float32), depth.to(torch.float32)
+    if not colour:
+        img = torch.clamp(torch.round(20.0 + 215.0 * surface.albedo(X[..., 0], X[..., 1])), 0, 255)
+        return img.to(torch.float32), depth.to(torch.float32)
+    chans = []
+    seed0 = surface.seed
+    for c in range(3):                                   # three differently seeded albedos, correlated
+        surface.seed = seed0 + 7919 * c
+        a = 0.6 * surface.albedo(X[..., 0], X[..., 1])
+        surface.seed = seed0
+        a = a + 0.4 * surface.albedo(X[..., 0], X[..., 1])
+        chans.append(torch.clamp(torch.round(20.0 + 215.0 * a), 0, 255))
+    chans.append(torch.full_like(chans[0], 77.0))        # alpha: present, never read
+    return torch.stack(chans, dim=-1).to(torch.float32), depth.to(torch.float32)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -156,7 +168,7 @@ def tiny_config(cols=64, rows=48, n_src=3, blocksize=7, iterations=2, n_best=2):
 
 
 def build_problem(cfg, ref_view=15, scene_seed=1234, solver_seed=1, device="cpu",
-                  keep_on_device=False, gamma=10.0, cost_comb=abi.COMB_BEST_N, **overrides):
+                  keep_on_device=False, gamma=10.0, cost_comb=abi.COMB_BEST_N, colour=False, **overrides):
     """Returns (GlobalState, info) for one reference view of a configuration.
 
     info: dict with 'gt_depth' (reference-view depth of the analytic surface, numpy), the chosen
@@ -206,7 +218,7 @@ def build_problem(cfg, ref_view=15, scene_seed=1234, solver_seed=1, device="cpu"
     surf = Surface(z0, amp, wl, tilt=tilt, pixel_footprint=footprint, seed=scene_seed)
     imgs, gt = [], None
     for i in range(cs.n):
-        img, depth = render(surf, cs.K[i], cs.R[i], cs.t[i], rows, cols, device=device)
+        img, depth = render(surf, cs.K[i], cs.R[i], cs.t[i], rows, cols, device=device, colour=colour)
         if i == 0:
             gt = depth.cpu().numpy()
         imgs.append(img)
@@ -222,7 +234,8 @@ def build_problem(cfg, ref_view=15, scene_seed=1234, solver_seed=1, device="cpu"
     if keep_on_device:
         imgs = [im.contiguous() for im in imgs]
         gs = GlobalState(imgs, cs, subset, ap, seed=solver_seed,
-                         device_ptrs=[im.data_ptr() for im in imgs], rows=rows, cols=cols)
+                         device_ptrs=[im.data_ptr() for im in imgs], rows=rows, cols=cols,
+                         channels=4 if colour else 1)
     else:
         gs = GlobalState([im.cpu().numpy() for im in imgs], cs, subset, ap, seed=solver_seed)
     info = dict(gt_depth=gt, view_ids=ids, cameras=cs, surface=surf, cfg=cfg)

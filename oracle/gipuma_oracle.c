@@ -238,19 +238,23 @@ static inline int go_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > h
 
 /* point sample with clamp-to-edge: tex2D(tex, i+0.5, j+0.5) of config.h:245-248 for integer
  * (i,j); also what the shared-memory tile holds (gipuma.cu:1393-1402) */
-static inline float go_texel(const float *img, int rows, int cols, int pitch, int x, int y)
+static inline float go_texel_s(const float *img, int rows, int cols, int pitch, int stride, int x, int y)
 {
     x = go_clampi(x, 0, cols - 1);
     y = go_clampi(y, 0, rows - 1);
-    return img[(size_t)y * (size_t)pitch + (size_t)x];
+    return img[(size_t)y * (size_t)pitch + (size_t)x * (size_t)stride];
+}
+static inline float go_texel(const float *img, int rows, int cols, int pitch, int x, int y)
+{
+    return go_texel_s(img, rows, cols, pitch, 1, x, y);
 }
 
 static inline float go_lerp(float a, float t0, float t1) { return fmaf(a, t1 - t0, t0); }
 
 /* The five bilinear taps of pmCostComputation_shared (gipuma.cu:251-253) at source position
  * (x,y): out = { centre, x+1, x-1, y+1, y-1 }.  Model M1. */
-static inline void go_sample5(const float *img, int rows, int cols, int pitch, float x, float y,
-                              float out[5])
+static inline void go_sample5_s(const float *img, int rows, int cols, int pitch, int stride, float x,
+                                float y, float out[5])
 {
     const float fx0 = floorf(x), fy0 = floorf(y);
     const float a = x - fx0, b = y - fy0;
@@ -259,7 +263,7 @@ static inline void go_sample5(const float *img, int rows, int cols, int pitch, f
     const int iy = (int)fminf(fmaxf(fy0, -2.0f), (float)rows);
     float t[4][4];
     for (int r = 0; r < 4; r++)
-        for (int c = 0; c < 4; c++) t[r][c] = go_texel(img, rows, cols, pitch, ix - 1 + c, iy - 1 + r);
+        for (int c = 0; c < 4; c++) t[r][c] = go_texel_s(img, rows, cols, pitch, stride, ix - 1 + c, iy - 1 + r);
     const float C0 = go_lerp(a, t[0][1], t[0][2]);
     const float L1 = go_lerp(a, t[1][0], t[1][1]);
     const float C1 = go_lerp(a, t[1][1], t[1][2]);
@@ -273,6 +277,12 @@ static inline void go_sample5(const float *img, int rows, int cols, int pitch, f
     out[2] = go_lerp(b, L1, L2);
     out[3] = go_lerp(b, C2, C3);
     out[4] = go_lerp(b, C0, C1);
+}
+
+static inline void go_sample5(const float *img, int rows, int cols, int pitch, float x, float y,
+                              float out[5])
+{
+    go_sample5_s(img, rows, cols, pitch, 1, x, y, out);
 }
 
 void gipuma_oracle_sample5(const float *img, int rows, int cols, int pitch, float x, float y,
@@ -345,10 +355,87 @@ static float go_view_cost(const gipuma_hip_desc *d, int view, int px, int py, co
     return cost;
 }
 
+/* l1_norm(float4), gipuma.cu:174-179: mean |.| of x,y,z; the float4 operators zero .w
+ * (vector_operations.h:9-14) */
+static inline float go_l1_3(const float v[3])
+{
+    return (fabsf(v[0]) + fabsf(v[1]) + fabsf(v[2])) * 0.3333333f;
+}
+
+/* The same functions instantiated with T = float4 (-color_processing, gipuma.cu:1965-1968):
+ * images are float4 per pixel (B, G, R, unset alpha: main.cpp:943-956), every image
+ * difference is per channel and reduced by l1_norm(float4). */
+static float go_view_cost_c4(const gipuma_hip_desc *d, int view, int px, int py, const float pl[4])
+{
+    const gipuma_hip_params *ap = &d->params;
+    const int rows = d->rows, cols = d->cols, pitch = d->pitch;
+    const float *ref = d->images[0];
+    const float *src = d->images[view];
+    const int hRad = (ap->box_hsize - 1) / 2;
+    const int vRad = (ap->box_vsize - 1) / 2;
+    const float alpha = ap->alpha, tau_color = ap->tau_color, tau_gradient = ap->tau_gradient;
+    const float gamma = ap->gamma;
+    const float oma = 1.f - alpha;
+
+    float H[9];
+    go_homography(&d->cameras[0], &d->cameras[view], pl, pl[3], H);
+
+    float centre[3];
+    for (int c = 0; c < 3; c++) centre[c] = go_texel_s(ref + c, rows, cols, pitch, 4, px, py);
+    float cost = 0.0f;
+    for (int i = -hRad; i < hRad + 1; i += GO_WIN_INCREMENT) {
+        const float qx = (float)(px + i);
+        const float X0 = fmaf(H[0], qx, H[2]);
+        const float Y0 = fmaf(H[3], qx, H[5]);
+        const float Z0 = fmaf(H[6], qx, H[8]);
+        for (int j = -vRad; j < vRad + 1; j += GO_WIN_INCREMENT) {
+            const int ix = px + i, iy = py + j;
+            const float qy = (float)iy;
+            float leftValue[3], dc[3];
+            for (int c = 0; c < 3; c++) {
+                leftValue[c] = go_texel_s(ref + c, rows, cols, pitch, 4, ix, iy);
+                dc[c] = leftValue[c] - centre[c];
+            }
+            const float colorDis = go_l1_3(dc);
+            const float w = go_exp(-colorDis / gamma);
+            const float X = fmaf(H[1], qy, X0);
+            const float Y = fmaf(H[4], qy, Y0);
+            const float Z = fmaf(H[7], qy, Z0);
+            const float rz = 1.0f / Z;
+            const float sx = X * rz, sy = Y * rz;
+            float cd[3], gradX[3], gradY[3];
+            for (int c = 0; c < 3; c++) {
+                float s[5];
+                go_sample5_s(src + c, rows, cols, pitch, 4, sx, sy, s);
+                const float gx2 = s[1] - s[2];
+                const float gy2 = s[3] - s[4];
+                cd[c] = leftValue[c] - s[0];
+                const float up = go_texel_s(ref + c, rows, cols, pitch, 4, ix, iy - 1);
+                const float down = go_texel_s(ref + c, rows, cols, pitch, 4, ix, iy + 1);
+                const float left = go_texel_s(ref + c, rows, cols, pitch, 4, ix - 1, iy);
+                const float right = go_texel_s(ref + c, rows, cols, pitch, 4, ix + 1, iy);
+                gradX[c] = (right - left) - gx2;
+                gradY[c] = (down - up) - gy2;
+            }
+            const float colDiff = go_l1_3(cd);
+            const float gradDis = fminf((go_l1_3(gradX) + go_l1_3(gradY)) * 0.0625f, tau_gradient);
+            const float colDis = fminf(colDiff, tau_color);
+            const float dis = fmaf(alpha, gradDis, oma * colDis);
+            cost = fmaf(w, dis, cost);
+        }
+    }
+    return cost;
+}
+
+static float go_view_cost_any(const gipuma_hip_desc *d, int view, int px, int py, const float pl[4])
+{
+    return d->channels == 4 ? go_view_cost_c4(d, view, px, py, pl) : go_view_cost(d, view, px, py, pl);
+}
+
 float gipuma_oracle_view_cost(const gipuma_hip_desc *d, int view, int x, int y,
                               const float plane[4])
 {
-    return go_view_cost(d, view, x, y, plane);
+    return go_view_cost_any(d, view, x, y, plane);
 }
 
 /* sort_small, gipuma.cu:684-693 */
@@ -406,7 +493,7 @@ static float go_multiview_cost(const gipuma_hip_desc *d, int px, int py, const f
 {
     float cv[GIPUMA_HIP_MAX_VIEWS];
     const int n = d->n_selected;
-    for (int i = 0; i < n; i++) cv[i] = go_view_cost(d, d->selected[i], px, py, pl);
+    for (int i = 0; i < n; i++) cv[i] = go_view_cost_any(d, d->selected[i], px, py, pl);
     return go_aggregate(cv, n, d->params.cost_comb, d->params.n_best, d->params.good_factor);
 }
 
@@ -567,7 +654,8 @@ static void go_sweep_pixel(const gipuma_hip_desc *d, int x, int y, float *norm4,
 static int go_check(const gipuma_hip_desc *d)
 {
     if (!d || d->abi_version != GIPUMA_HIP_ABI_VERSION) return GIPUMA_HIP_ERR_ARG;
-    if (d->rows < 1 || d->cols < 1 || d->channels != 1 || d->pitch < d->cols)
+    if (d->rows < 1 || d->cols < 1 || (d->channels != 1 && d->channels != 4) ||
+        d->pitch < d->cols * d->channels)
         return GIPUMA_HIP_ERR_ARG;
     if (d->n_images < 1 || !d->images || !d->cameras) return GIPUMA_HIP_ERR_ARG;
     if (d->n_selected < 0 || d->n_selected > GIPUMA_HIP_MAX_VIEWS) return GIPUMA_HIP_ERR_ARG;

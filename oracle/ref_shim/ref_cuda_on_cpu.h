@@ -75,7 +75,7 @@ template <class T> static inline cudaError_t cudaMalloc(T **p, size_t n) { *p = 
 static inline cudaError_t cudaFree(void *p) { free(p); return 0; }
 
 /* ---- texture unit (numerical model M1) ---- */
-struct RefTexture { const float *data; int cols, rows, pitch; };
+struct RefTexture { const float *data; int cols, rows, pitch, channels; }; /* pitch in floats */
 extern RefTexture ref_textures[];
 extern int ref_tex_mode; /* 0: fp32 lerp weights; 1: weights rounded to 8 fractional bits like CUDA */
 template <class T> T tex2D(cudaTextureObject_t tex, float x, float y);

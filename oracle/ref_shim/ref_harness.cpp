@@ -15,7 +15,7 @@ int ref_pass = 1;
 RefTexture ref_textures[MAX_IMAGES];
 int ref_tex_mode = 0;
 unsigned ref_seed = 1, ref_phase = 0;
-unsigned char my_smem[64 * 1024] __attribute__((aligned(16)));
+unsigned char my_smem[256 * 1024] __attribute__((aligned(16)));
 
 /* M2: same exp model as the oracle and the kernels */
 float ref_model_expf(float x)
@@ -58,29 +58,38 @@ float curand_uniform(curandState *s)
 /* M1: cudaFilterModeLinear on unnormalised coordinates, clamp addressing (main.cpp:644-648):
  * xB = x - 0.5, i = floor(xB), a = frac(xB); each call is independent (per-tap coordinates
  * exactly as the reference passes them) */
-static inline float ref_texel(const RefTexture &t, int x, int y)
+static inline float ref_texel(const RefTexture &t, int x, int y, int c)
 {
     x = x < 0 ? 0 : (x > t.cols - 1 ? t.cols - 1 : x);
     y = y < 0 ? 0 : (y > t.rows - 1 ? t.rows - 1 : y);
-    return t.data[(size_t)y * t.pitch + x];
+    return t.data[(size_t)y * t.pitch + (size_t)x * t.channels + c];
 }
-template <> float tex2D<float>(cudaTextureObject_t tex, float x, float y)
+static inline float ref_tex_channel(const RefTexture &t, float x, float y, int c)
 {
-    const RefTexture &t = ref_textures[tex];
     const float xb = x - 0.5f, yb = y - 0.5f;
     const float fx = floorf(xb), fy = floorf(yb);
     float a = xb - fx, b = yb - fy;
     if (ref_tex_mode == 1) { a = floorf(a * 256.0f + 0.5f) / 256.0f; b = floorf(b * 256.0f + 0.5f) / 256.0f; }
     const int ix = (int)fminf(fmaxf(fx, -2.0f), (float)t.cols);
     const int iy = (int)fminf(fmaxf(fy, -2.0f), (float)t.rows);
-    const float t00 = ref_texel(t, ix, iy), t10 = ref_texel(t, ix + 1, iy);
-    const float t01 = ref_texel(t, ix, iy + 1), t11 = ref_texel(t, ix + 1, iy + 1);
+    const float t00 = ref_texel(t, ix, iy, c), t10 = ref_texel(t, ix + 1, iy, c);
+    const float t01 = ref_texel(t, ix, iy + 1, c), t11 = ref_texel(t, ix + 1, iy + 1, c);
     const float r0 = fmaf(a, t10 - t00, t00), r1 = fmaf(a, t11 - t01, t01);
     return fmaf(b, r1 - r0, r0);
 }
-template <> float4 tex2D<float4>(cudaTextureObject_t, float, float) { return make_float4(0, 0, 0, 0); }
+template <> float tex2D<float>(cudaTextureObject_t tex, float x, float y)
+{
+    return ref_tex_channel(ref_textures[tex], x, y, 0);
+}
+template <> float4 tex2D<float4>(cudaTextureObject_t tex, float x, float y)
+{  /* float4 texels: every component filtered alike (main.cpp:560-605) */
+    const RefTexture &t = ref_textures[tex];
+    return make_float4(ref_tex_channel(t, x, y, 0), ref_tex_channel(t, x, y, 1), ref_tex_channel(t, x, y, 2),
+                       ref_tex_channel(t, x, y, 3));
+}
 
 static GlobalState *g_gs = nullptr;
+static bool g_colour = false; /* T = float4 (runcuda, gipuma.cu:1965-1968) */
 static AlgorithmParameters *g_params = nullptr;
 
 static void set_tile_globals(const AlgorithmParameters &p)
@@ -154,7 +163,8 @@ int ref_create(const gipuma_hip_desc *d)
     p.alpha = d->params.alpha; p.tau_color = d->params.tau_color; p.tau_gradient = d->params.tau_gradient;
     p.gamma = d->params.gamma; p.min_disparity = d->params.min_disparity;
     p.max_disparity = d->params.max_disparity; p.good_factor = d->params.good_factor;
-    p.color_processing = false; p.cols = d->cols; p.rows = d->rows;
+    g_colour = d->channels == 4;
+    p.color_processing = g_colour; p.cols = d->cols; p.rows = d->rows;
     g_gs->params = &p;
     CameraParameters_cu &cp = *g_gs->cameras;
     cp.cols = d->cols; cp.rows = d->rows; cp.f = d->cameras[0].f;
@@ -174,6 +184,7 @@ int ref_create(const gipuma_hip_desc *d)
         cam.depthMin = c.depth_min; cam.depthMax = c.depth_max;
         ref_textures[i].data = d->images[i]; ref_textures[i].cols = d->cols;
         ref_textures[i].rows = d->rows; ref_textures[i].pitch = d->pitch;
+        ref_textures[i].channels = d->channels;
         g_gs->imgs[i] = (cudaTextureObject_t)i;
     }
     g_gs->lines->n = d->rows * d->cols;
@@ -191,7 +202,7 @@ int ref_init_planes(void)
 {
     if (!g_gs) return -1;
     ref_phase = 0;
-    launch_dense(gipuma_init_cu2<float>); /* gipuma.cu:1906 */
+    launch_dense(g_colour ? gipuma_init_cu2<float4> : gipuma_init_cu2<float>); /* gipuma.cu:1906 */
     return 0;
 }
 
@@ -201,20 +212,17 @@ int ref_sweep(int iteration, int colour, unsigned stages)
     const int rows = g_gs->cameras->rows, cols = g_gs->cameras->cols;
     ref_phase = 1u + 2u * (unsigned)iteration + (unsigned)colour;
     /* launches of gipuma.cu:1915-1935, one colour */
-    if (stages & GIPUMA_STAGE_CLOSE)
-        launch_colour(colour == GIPUMA_BLACK ? gipuma_black_spatialPropClose_cu<float>
-                                             : gipuma_red_spatialPropClose_cu<float>, iteration);
-    if (stages & GIPUMA_STAGE_FAR)
-        launch_colour(colour == GIPUMA_BLACK ? gipuma_black_spatialPropFar_cu<float>
-                                             : gipuma_red_spatialPropFar_cu<float>, iteration);
+#define REF_K(name) (g_colour ? (colour == GIPUMA_BLACK ? gipuma_black_##name<float4> : gipuma_red_##name<float4>) \
+                            : (colour == GIPUMA_BLACK ? gipuma_black_##name<float> : gipuma_red_##name<float>))
+    if (stages & GIPUMA_STAGE_CLOSE) launch_colour(REF_K(spatialPropClose_cu), iteration);
+    if (stages & GIPUMA_STAGE_FAR) launch_colour(REF_K(spatialPropFar_cu), iteration);
     if (stages & GIPUMA_STAGE_REFINE) {
         for (int y = 0; y < rows; y++)
             for (int x = 0; x < cols; x++) {
                 curandState &s = g_gs->cs[y * cols + x];
                 s.x = (unsigned)x; s.y = (unsigned)y; s.n = 0;
             }
-        launch_colour(colour == GIPUMA_BLACK ? gipuma_black_planeRefine_cu<float>
-                                             : gipuma_red_planeRefine_cu<float>, iteration);
+        launch_colour(REF_K(planeRefine_cu), iteration);
     }
     return 0;
 }
@@ -230,7 +238,7 @@ int ref_finalize(void)
 int ref_initial_cost(void)
 {
     if (!g_gs) return -1;
-    launch_dense(gipuma_initial_cost<float>);
+    launch_dense(g_colour ? gipuma_initial_cost<float4> : gipuma_initial_cost<float>);
     return 0;
 }
 

@@ -81,7 +81,8 @@ def test_create_validates_the_descriptor():
     assert rc_with(abi_version=99)[0] == -1
     assert rc_with(rows=0)[0] == -1
     assert rc_with(pitch=3)[0] == -1
-    assert rc_with(channels=4)[0] == -4           # colour mode is not built yet
+    assert rc_with(channels=3)[0] == -4           # 1 = gray (T=float) or 4 = colour (T=float4) only
+    assert rc_with(channels=4)[0] == -1           # colour needs pitch >= 4*cols
     assert rc_with(n_selected=33)[0] == -1        # costVector[32], gipuma.cu:736
     rc, msg = rc_with(p_box_hsize=8)
     assert rc == -1 and b"odd" in msg              # main.cpp:269-276

@@ -91,16 +91,17 @@ def test_dmb_layout(tmp_path):
 
 
 def write_scene(tmp, gs, view_ids):
+    """PGM (gray) or PPM (colour: the float4 planes are B, G, R, alpha -> file order R, G, B)"""
     img_dir, p_dir = tmp / "img", tmp / "calib"
     img_dir.mkdir()
     p_dir.mkdir()
     P = synth.dtu_projection_matrices()
     names = []
     for im, vid in zip(gs.images, view_ids):
-        name = "rect_%03d.pgm" % vid
+        name = "rect_%03d.%s" % (vid, "ppm" if im.ndim == 3 else "pgm")
         with open(img_dir / name, "wb") as f:
-            f.write(b"P5\n# synthetic\n%d %d\n255\n" % (gs.cols, gs.rows))
-            f.write(im.astype(np.uint8).tobytes())
+            f.write(b"%s\n# synthetic\n%d %d\n255\n" % (b"P6" if im.ndim == 3 else b"P5", gs.cols, gs.rows))
+            f.write((im[..., 2::-1] if im.ndim == 3 else im).astype(np.uint8).tobytes())
         with open(p_dir / (name + ".P"), "w") as f:
             for r in P[vid]:
                 f.write(" ".join("%.6f" % v for v in r) + "\n")
@@ -133,16 +134,18 @@ def test_cli_without_gpu_fails_loudly(tmp_path):
 
 
 @pytest.mark.gpu
-def test_cli_end_to_end_dmb_matches_oracle(hip, tmp_path):
+@pytest.mark.parametrize("colour", [False, True])
+def test_cli_end_to_end_dmb_matches_oracle(hip, tmp_path, colour):
     """PGM + .P files in, disp.dmb / normals.dmb out, through the reference's flags; the oracle is
     fed the cameras the C++ front-end produced, so the dumps must match it bit for bit"""
     from tests.oracle_lib import OracleState
     cfg = synth.tiny_config(cols=96, rows=64, n_src=3, blocksize=11, iterations=2, n_best=2)
-    gs, info = synth.build_problem(cfg)
+    gs, info = synth.build_problem(cfg, colour=colour)
     ids = info["view_ids"]
     img_dir, p_dir, names = write_scene(tmp_path, gs, ids)
     out_dir = tmp_path / "out"
-    r = subprocess.run(cli_args(cfg, img_dir, p_dir, names, out_dir), capture_output=True, text=True)
+    args = cli_args(cfg, img_dir, p_dir, names, out_dir) + (["-color_processing"] if colour else [])
+    r = subprocess.run(args, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Total time needed for computation" in r.stdout
     sub = [d for d in os.listdir(out_dir)]
@@ -155,7 +158,12 @@ def test_cli_end_to_end_dmb_matches_oracle(hip, tmp_path):
     cs = cpp_cameras(P_txt, cam_scale=float(np.float32(cfg["cam_scale"])))
     ap = AlgorithmParameters(iterations=2, n_best=2, depthMin=300.0, depthMax=800.0)
     ap.set_blocksize(11)
-    gs2 = GlobalState(gs.images, cs, [1, 2, 3], ap, seed=1)
+    imgs = gs.images
+    if colour:   # the CLI reads 8-bit PPM: alpha comes back as 0
+        imgs = [im.copy() for im in gs.images]
+        for im in imgs:
+            im[..., 3] = 0
+    gs2 = GlobalState(imgs, cs, [1, 2, 3], ap, seed=1)
     # main.cpp:905-906 in fp32, as the C++ front-end computes it
     f32 = np.float32
     gs2.desc.params.min_disparity = f32(cs.f) * f32(0.54) / f32(800.0)

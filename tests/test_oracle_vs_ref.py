@@ -201,3 +201,23 @@ def test_golden_fixture_is_what_the_reference_produces_now():
     rn, rc = ref_lib.RefState(gs).run()
     assert np.array_equal(bits(rn), bits(g["final_norm4"]))
     assert np.array_equal(bits(rc), bits(g["final_cost"]))
+
+
+@needs_ref
+def test_ref_colour_float4_instantiation():
+    """-color_processing: the reference's T=float4 kernels (gipuma.cu:1965-1968) vs the oracle's
+    colour path, free-running"""
+    gs, info = synth.build_problem(synth.tiny_config(cols=96, rows=64, n_src=3, blocksize=9, iterations=2,
+                                                     n_best=2), colour=True)
+    r = ref_lib.RefState(gs)
+    o = OracleState(gs)
+    r.init_planes()
+    o.init_planes()
+    rn, rc = r.get_state()
+    assert np.array_equal(bits(rn), bits(o.norm4))
+    assert costs_close(rc, o.cost)
+    rn, rc = ref_lib.RefState(gs).run()
+    on, oc = OracleState(gs).run()
+    d_rel = rel(rn[..., 3], on[..., 3])
+    n_err = np.abs(rn[..., :3] - on[..., :3]).max(-1)
+    assert ((d_rel < 1e-4) & (n_err < 1e-3)).mean() > 0.99

@@ -250,3 +250,56 @@ def test_properties_at_full_size(hip):
         pl = np.ascontiguousarray(n4[y, x])
         want = lib().gipuma_oracle_multiview_cost(C.byref(gs.desc), x, y, fptr(pl))
         assert np.float32(want).view(np.uint32) == c[y, x].view(np.uint32), (x, y, want, c[y, x])
+
+
+# ------------------------------------------------------------------------------------------------
+# -color_processing (T = float4)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [
+    dict(blocksize=7, n_src=3, n_best=2),              # runtime-sized window
+    dict(cols=80, rows=56, blocksize=15, n_src=4, n_best=3, iterations=1),
+    dict(cols=70, rows=50, blocksize=11, n_src=2, n_best=1),
+])
+def test_colour_full_run_bit_exact(hip, cfg):
+    gs, _ = synth.build_problem(synth.tiny_config(**cfg), colour=True)
+    assert gs.channels == 4
+    n4, c = runcuda(gs)
+    o_n4, o_c = OracleState(gs).run()
+    assert_same(n4, o_n4, "colour run norm4 %r" % cfg)
+    assert_same(c, o_c, "colour run cost %r" % cfg)
+
+
+def test_colour_stage_by_stage_and_generic_combiner(hip):
+    gs, _ = synth.build_problem(synth.tiny_config(n_src=4, iterations=1), colour=True, cost_comb=abi.COMB_GOOD)
+    o = OracleState(gs)
+    o.init_planes()
+    with Session(gs) as s:
+        s.init_planes()
+        n4, c = s.get_state()
+        assert_same(n4, o.norm4, "colour init norm4")
+        assert_same(c, o.cost, "colour init cost")
+        for colour in (abi.BLACK, abi.RED):
+            for stage in (abi.STAGE_CLOSE, abi.STAGE_FAR, abi.STAGE_REFINE):
+                s.sweep(0, colour, stage)
+                o.sweep(0, colour, stage)
+                n4, c = s.get_state()
+                assert_same(n4, o.norm4, "colour %d stage %d norm4" % (colour, stage))
+                assert_same(c, o.cost, "colour %d stage %d cost" % (colour, stage))
+
+
+def test_colour_float_valued_images_and_ignored_alpha(hip):
+    """non-integer colour images take the float4 gather path; the alpha channel is never read"""
+    from gipuma_amd.problem import GlobalState
+    gs, _ = synth.build_problem(synth.tiny_config(iterations=1), colour=True)
+    imgs = []
+    for i, im in enumerate(gs.images):
+        im = im.copy()
+        im[..., :3] += np.float32(0.125) * (i + 1)
+        im[..., 3] = np.float32(1e30) if i % 2 else np.float32("nan")     # must not matter
+        imgs.append(im)
+    gs2 = GlobalState(imgs, gs.cameras, gs.selected, gs.params, seed=5)
+    n4, c = runcuda(gs2)
+    o_n4, o_c = OracleState(gs2).run()
+    assert_same(n4, o_n4, "float colour norm4")
+    assert_same(c, o_c, "float colour cost")
+    assert np.isfinite(c).all()
