@@ -191,6 +191,25 @@ int gipuma_hip_device_count(void)
     return n;
 }
 
+int gipuma_hip_selftest_reciprocal(int device_id, unsigned long long *mismatches)
+{
+    if (!mismatches) return fail(GIPUMA_HIP_ERR_ARG, "null argument");
+    if (device_id < 0 || device_id >= gipuma_hip_device_count())
+        return fail(GIPUMA_HIP_ERR_NO_DEVICE, "no such HIP device");
+    HIP_OK(hipSetDevice(device_id));
+    unsigned long long *d = nullptr;
+    HIP_OK(hipMalloc(&d, sizeof *d));
+    hipError_t e = hipMemset(d, 0, sizeof *d);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pm::rcp_selftest_kernel, dim3(65536), dim3(pm::kThreads), 0, 0, d, 1u, 252u);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(mismatches, d, sizeof *d, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(GIPUMA_HIP_ERR_DEVICE, "selftest: %s", hipGetErrorString(e));
+    return 0;
+}
+
 int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
 {
     if (!out) return fail(GIPUMA_HIP_ERR_ARG, "null out pointer");

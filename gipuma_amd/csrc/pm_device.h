@@ -301,6 +301,38 @@ __global__ __launch_bounds__(kThreads) void check_u8_kernel(const float *__restr
     if (!(v >= 0.0f && v <= 255.0f) || v != __builtin_floorf(v)) atomicOr(flag, 1);
 }
 
+// 1/z of the warped point (M2: an IEEE-correct reciprocal).  v_rcp_f32 followed by one Newton step
+// is bit-identical to the correctly rounded 1.0f/z for EVERY input whose biased exponent is
+// 1..252, i.e. 2^-126 <= |z| < 2^126 (exhaustive check over all 2^32 inputs:
+// scripts/ubench/rcp_exact.hip and gipuma_hip_selftest_reciprocal(), run by the gpu tests).  It is
+// 3 instructions against the 10 of the div_scale/div_fmas/div_fixup expansion.  view_cost uses it
+// only after proving the whole window stays inside a (much narrower) safe range.
+__device__ __forceinline__ float rcp_newton(float z)
+{
+    const float r = __builtin_amdgcn_rcpf(z);
+    const float e = __builtin_fmaf(-z, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+template <bool FAST>
+__device__ __forceinline__ float recip(float z)
+{
+    return FAST ? rcp_newton(z) : 1.0f / z;
+}
+// counts inputs in [lo_exp, hi_exp] (biased exponents) where rcp_newton != 1.0f/z
+__global__ __launch_bounds__(kThreads) void rcp_selftest_kernel(unsigned long long *bad, uint32_t lo_exp,
+                                                                uint32_t hi_exp)
+{
+    const uint32_t hi = blockIdx.x;
+    unsigned c = 0;
+    for (uint32_t lo = threadIdx.x; lo < 65536; lo += kThreads) {
+        const uint32_t bits = (hi << 16) | lo;
+        const uint32_t ex = (bits >> 23) & 0xffu;
+        const float z = __uint_as_float(bits);
+        if (ex >= lo_exp && ex <= hi_exp) c += __float_as_uint(rcp_newton(z)) != __float_as_uint(1.0f / z);
+    }
+    if (c) atomicAdd(bad, (unsigned long long)c);
+}
+
 // The five bilinear taps of pmCostComputation_shared (gipuma.cu:251-253) from one 4x4 window
 // (M1): centre value and the +-1 texel differences in x and y.  t<row><col>, corners unused.
 struct Taps {
@@ -365,14 +397,27 @@ __global__ __launch_bounds__(kThreads) void check_u8_kernel_c4(const float *__re
 
 // Patch cost of one source view: pmCost_shared + pmCostComputation_shared,
 // gipuma.cu:585-680 and :223-277.  `tp0` points at the pixel's own texel inside the LDS tile.
-template <int BOX, bool U8, bool INTERIOR>
-__device__ __forceinline__ float view_cost(const Problem *__restrict__ P, const ViewCam &vc,
-                                           const float *__restrict__ tp0, int tw,
-                                           const float *__restrict__ lut, int px, int py, float4 pl,
-                                           const Win<BOX> &win)
+// Is every warped-point denominator of the window safely inside the range where rcp_newton is
+// exact?  Z(i,j) = fmaf(H7, qy, fmaf(H6, qx, H8)) is monotone in qx and in qy (one rounding each),
+// so all window values lie between the four corner values.
+__device__ __forceinline__ bool window_z_safe(const float *H, float qx0, float qx1, float qy0, float qy1)
 {
-    float H[9];
-    homography(P->rc.K_inv, vc, pl, H);
+    const float z00 = __builtin_fmaf(H[7], qy0, __builtin_fmaf(H[6], qx0, H[8]));
+    const float z01 = __builtin_fmaf(H[7], qy1, __builtin_fmaf(H[6], qx0, H[8]));
+    const float z10 = __builtin_fmaf(H[7], qy0, __builtin_fmaf(H[6], qx1, H[8]));
+    const float z11 = __builtin_fmaf(H[7], qy1, __builtin_fmaf(H[6], qx1, H[8]));
+    const float lo = __builtin_fminf(__builtin_fminf(z00, z01), __builtin_fminf(z10, z11));
+    const float hi = __builtin_fmaxf(__builtin_fmaxf(z00, z01), __builtin_fmaxf(z10, z11));
+    // same sign, and magnitudes in [2^-100, 2^100] (NaN fails every comparison)
+    return (lo >= 0x1p-100f && hi <= 0x1p100f) || (hi <= -0x1p-100f && lo >= -0x1p100f);
+}
+
+template <int BOX, bool U8, bool INTERIOR, bool FAST>
+__device__ __forceinline__ float view_cost_loop(const Problem *__restrict__ P, const ViewCam &vc,
+                                                const float *__restrict__ H, const float *__restrict__ tp0,
+                                                int tw, const float *__restrict__ lut, int px, int py,
+                                                const Win<BOX> &win)
+{
     const gptr_f32 img = (gptr_f32)vc.img;
     const uint32_t *__restrict__ packed = vc.packed;
     const uint32_t pw = (uint32_t)P->pw;
@@ -407,7 +452,7 @@ __device__ __forceinline__ float view_cost(const Problem *__restrict__ P, const 
             const float X = __builtin_fmaf(H[1], qy, X0);
             const float Y = __builtin_fmaf(H[4], qy, Y0);
             const float Z = __builtin_fmaf(H[7], qy, Z0);
-            const float rz = 1.0f / Z;
+            const float rz = recip<FAST>(Z);
             const float sx = X * rz, sy = Y * rz;
             // M1: five bilinear taps sharing one 4x4 texel window (gipuma.cu:251-253)
             const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
@@ -455,6 +500,20 @@ __device__ __forceinline__ float view_cost(const Problem *__restrict__ P, const 
         }
     }
     return cost;
+}
+
+template <int BOX, bool U8, bool INTERIOR>
+__device__ __forceinline__ float view_cost(const Problem *__restrict__ P, const ViewCam &vc,
+                                           const float *__restrict__ tp0, int tw,
+                                           const float *__restrict__ lut, int px, int py, float4 pl,
+                                           const Win<BOX> &win)
+{
+    float H[9];
+    homography(P->rc.K_inv, vc, pl, H);
+    const int hr = win.hrad(), vr = win.vrad();
+    const bool safe = window_z_safe(H, (float)(px - hr), (float)(px + hr), (float)(py - vr), (float)(py + vr));
+    if (__all(safe)) return view_cost_loop<BOX, U8, INTERIOR, true>(P, vc, H, tp0, tw, lut, px, py, win);
+    return view_cost_loop<BOX, U8, INTERIOR, false>(P, vc, H, tp0, tw, lut, px, py, win);
 }
 
 // The same patch cost instantiated for T = float4 (-color_processing, gipuma.cu:1965-1968): every
@@ -777,41 +836,43 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(const Problem *__restri
     float cst = cost[center];
     float depth = depth_from_plane(rc, pl, px, py);
 
-    // spatial propagation: k = 0..3 distance 1, k = 4..7 distance 5; up, down, left, right
-    for (int k = 0; k < 8; k++) {
-        const int dist = k < 4 ? 1 : 5;
-        if (!(stages & (k < 4 ? 1u : 2u))) continue;
+    // One candidate loop, one call site of the cost function:
+    //   k = 0..3  neighbours at distance 1, k = 4..7 at distance 5 (up, down, left, right)
+    //             spatialPropagation_cu, gipuma.cu:832-874
+    //   k >= 8    random plane refinement steps, planeRefinement_cu + getRndDispAndUnitVector_cu,
+    //             gipuma.cu:928-994, 890-927
+    const float min_disp = P->min_disp, max_disp = P->max_disp;
+    int nref = 0;  // number of refinement steps: deltaZ = max_disp/2, /10 ... >= 0.01 (:958-959)
+    if (stages & 4u)
+        for (float dz = max_disp / 2.0f; dz >= 0.01f; dz = dz / 10.0f) nref++;
+    Vec3 view = {0.f, 0.f, 0.f};
+    uint32_t pre = 0, draw = 0;
+    float deltaN = 1.0f, deltaZ = max_disp / 2.0f;
+    for (int k = 0; k < 8 + nref; k++) {
         bool ok;
-        int nb;
-        switch (k & 3) {
-        case 0: ok = py > dist - 1; nb = center - dist * cols; break;
-        case 1: ok = py < rows - dist; nb = center + dist * cols; break;
-        case 2: ok = px > dist - 1; nb = center - dist; break;
-        default: ok = px < cols - dist; nb = center + dist; break;
-        }
-        if (ok) {
-            // spatialPropagation_cu, gipuma.cu:832-874
-            const float4 cand = norm4[nb];
-            const float d_before = depth_from_plane(rc, cand, px, py);
-            const float c_before =
-                multiview_cost<BOX, U8, INTERIOR, COMBINE_REG, CH>(P, tp0, tw, lds, cv, px, py, cand, win);
-            if (d_before >= rc.depth_min && d_before <= rc.depth_max && c_before < cst) {
-                depth = d_before;
-                pl = cand;
-                cst = c_before;
+        float4 cand;
+        float d_new;
+        if (k < 8) {
+            if (!(stages & (k < 4 ? 1u : 2u))) continue;
+            const int dist = k < 4 ? 1 : 5;
+            int nb;
+            switch (k & 3) {
+            case 0: ok = py > dist - 1; nb = center - dist * cols; break;
+            case 1: ok = py < rows - dist; nb = center + dist * cols; break;
+            case 2: ok = px > dist - 1; nb = center - dist; break;
+            default: ok = px < cols - dist; nb = center + dist; break;
             }
-        }
-    }
-
-    if (stages & 4u) {
-        // planeRefinement_cu + getRndDispAndUnitVector_cu, gipuma.cu:928-994, 890-927
-        depth = depth_from_plane(rc, pl, px, py);  // the refine kernel re-derives it, :1660
-        const Vec3 view = view_vector(rc, px, py);
-        const uint32_t pre = rng_prefix(P->seed, phase, (uint32_t)px, (uint32_t)py);
-        uint32_t draw = 0;
-        float deltaN = 1.0f;
-        const float min_disp = P->min_disp, max_disp = P->max_disp;
-        for (float deltaZ = max_disp / 2.0f; deltaZ >= 0.01f; deltaZ = deltaZ / 10.0f) {
+            if (ok) {
+                cand = norm4[nb];
+                d_new = depth_from_plane(rc, cand, px, py);
+            }
+        } else {
+            if (k == 8) {
+                depth = depth_from_plane(rc, pl, px, py);  // the refine kernel re-derives it, :1660
+                view = view_vector(rc, px, py);
+                pre = rng_prefix(P->seed, phase, (uint32_t)px, (uint32_t)py);
+            }
+            ok = true;
             const float disp = disp_depth(rc.f, rc.baseline, depth);
             const float minDelta = -__builtin_fminf(deltaZ, min_disp + disp);  // sic, :909
             const float maxDelta = __builtin_fminf(deltaZ, max_disp - disp);
@@ -821,21 +882,27 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(const Problem *__restri
             const float u3 = rng_uniform(pre, draw++);
             const float dz = between(u0, minDelta, maxDelta);
             const float dispOut = __builtin_fminf(__builtin_fmaxf(disp + dz, min_disp), max_disp);
-            const float depthOut = disp_depth(rc.f, rc.baseline, dispOut);
+            d_new = disp_depth(rc.f, rc.baseline, dispOut);
             Vec3 n;
             n.x = pl.x + between(u1, -deltaN, deltaN);
             n.y = pl.y + between(u2, -deltaN, deltaN);
             n.z = pl.z + between(u3, -deltaN, deltaN);
             n = on_hemisphere(normalize3(n), view);
-            const float4 cand = make_float4(n.x, n.y, n.z, plane_d(rc, n, px, py, depthOut));
+            cand = make_float4(n.x, n.y, n.z, plane_d(rc, n, px, py, d_new));
+            deltaN = deltaN / 4.0f;
+            deltaZ = deltaZ / 10.0f;
+        }
+        if (ok) {
             const float c =
                 multiview_cost<BOX, U8, INTERIOR, COMBINE_REG, CH>(P, tp0, tw, lds, cv, px, py, cand, win);
-            if (c < cst) {
-                cst = c;
-                depth = depthOut;
+            // propagation also requires the plane's depth at this pixel inside [depthMin, depthMax]
+            // (ISDISPDEPTHWITHINBORDERS, :829-830); refinement does not (:986)
+            const bool in_range = k >= 8 || (d_new >= rc.depth_min && d_new <= rc.depth_max);
+            if (in_range && c < cst) {
+                depth = d_new;
                 pl = cand;
+                cst = c;
             }
-            deltaN = deltaN / 4.0f;
         }
     }
 

@@ -98,7 +98,7 @@ typedef struct gipuma_hip_params {
 typedef struct gipuma_hip_desc {
     uint32_t abi_version;            /* GIPUMA_HIP_ABI_VERSION */
     int32_t rows, cols;              /* CameraParameters_cu::rows, cols */
-    int32_t channels;                /* 1 = gray (T=float); 4 = colour is not built yet */
+    int32_t channels;                /* 1 = gray (T=float, one float per pixel); 4 = colour (T=float4: B, G, R, unused) */
     int32_t pitch;                   /* elements per image row (>= cols*channels) */
     int32_t n_images;                /* reference + source views handed over (<= 512, config.h:2) */
     const float *const *images;      /* GlobalState::imgs[] as linear buffers (no texture HW on gfx950) */
@@ -128,6 +128,12 @@ typedef struct gipuma_hip_session gipuma_hip_session;
 int gipuma_hip_version(void);                 /* GIPUMA_HIP_ABI_VERSION of the built library */
 const char *gipuma_hip_last_error(void);      /* thread-local text of the last failure */
 int gipuma_hip_device_count(void);            /* usable HIP devices (0 if none) */
+
+/* Device self-test of an arithmetic shortcut the kernels rely on: v_rcp_f32 + one Newton step must
+ * equal the IEEE-correct 1.0f/z bit for bit for EVERY float with biased exponent 1..252.  Runs the
+ * exhaustive comparison (2^32 inputs, ~1 s) on `device_id` and returns the number of mismatches in
+ * that range through *mismatches (0 expected); the gpu tests call it. */
+int gipuma_hip_selftest_reciprocal(int device_id, unsigned long long *mismatches);
 
 /* ---- session: the pieces of gipuma<T>() (gipuma.cu:1825-1960), one call per launch ---- */
 /* validates the descriptor, uploads/binds images and cameras, allocates norm4/cost in HBM

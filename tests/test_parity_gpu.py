@@ -303,3 +303,26 @@ def test_colour_float_valued_images_and_ignored_alpha(hip):
     assert_same(n4, o_n4, "float colour norm4")
     assert_same(c, o_c, "float colour cost")
     assert np.isfinite(c).all()
+
+
+def test_fast_reciprocal_is_exact_on_this_device(hip):
+    """the kernels replace the IEEE divide 1.0f/z by v_rcp_f32 + one Newton step wherever the
+    whole window's |z| is inside [2^-100, 2^100]; exhaustive check over every float with biased
+    exponent 1..252 that the two agree bit for bit on this GPU"""
+    n = C.c_ulonglong(123)
+    assert hip.gipuma_hip_selftest_reciprocal(0, C.byref(n)) == 0
+    assert n.value == 0
+
+
+def test_degenerate_planes_take_the_safe_divide_path(hip, tiny_problem):
+    """planes through / near the source camera centres make some warped denominators tiny, zero or
+    negative: the window guard must fall back to the IEEE divide and still match the oracle"""
+    gs, _ = tiny_problem
+    rng = np.random.default_rng(3)
+    planes = random_planes(gs, seed=11)
+    planes[..., 3] *= rng.choice([1e-6, 1e-3, -1.0, 1.0, 1e3, 0.0], size=planes.shape[:2]).astype(np.float32)
+    planes[0, 0, 3] = np.float32("nan")
+    with Session(gs) as s:
+        got = s.eval_cost(planes)
+    want = OracleState(gs).eval_cost(planes)
+    assert_same(got, want, "degenerate eval_cost")
