@@ -148,7 +148,7 @@ size_t lds_bytes(const gipuma_hip_session *s, int tile_h, bool with_cv)
 {
     const int hw = (s->hp.box_h + 1) / 2, hh = (s->hp.box_v + 1) / 2;
     size_t n = (s->ch == 4 ? pm::lut_size<4>() : pm::lut_size<1>()) +
-               (size_t)(pm::kTileW + 2 * hw) * (size_t)(tile_h + 2 * hh) * (size_t)s->ch;
+               (size_t)(pm::kTileW + 2 * hw) * (size_t)(tile_h + 2 * hh) * (size_t)(s->ch == 4 ? 4 : 5);
     if (with_cv) n += (size_t)s->n_sel * pm::kThreads;
     return n * sizeof(float);
 }

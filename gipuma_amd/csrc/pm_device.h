@@ -192,8 +192,11 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v,
 
 // ---------------------------------------------------------------------------------------------
 // LDS layout of a workgroup.  One __shared__ array; the kernels carve it:
-//   [0, 256)                     support-weight table  w(k) = exp(-k/gamma), k = |dI| = 0..255
-//   [256, 256 + tw*th)           reference-image tile with halo R = (box+1)/2 (gipuma.cu:1844-1855)
+//   [0, L)                       support-weight table: gray L = 256, w(k) = exp(-k/gamma), k = |dI|;
+//                                colour L = 768, k = |dB|+|dG|+|dR|
+//   [L, L + 4*tw*th)             reference tile with halo R = (box+1)/2 (gipuma.cu:1844-1855), one
+//                                float4 per texel: gray {I, gx1, gy1, I}, colour {B, G, R, 0}
+//   gray only: + tw*th           scratch plane used while the gradients are formed
 //   [.., + n_sel*256)            per-lane view-cost columns (only for the generic combiner)
 // ---------------------------------------------------------------------------------------------
 constexpr int kLutSize = 256;  // gray: |dI| = 0..255
@@ -438,10 +441,11 @@ __device__ __forceinline__ float view_cost_loop(const Problem *__restrict__ P, c
         const float Z0 = __builtin_fmaf(H[6], qx, H[8]);
 #pragma unroll unroll_j<BOX>()
         for (int j = -vr; j <= vr; j += 2) {
-            const float *tp = tp0 + j * tw + i;
+            // one ds_read_b128: {I(q), gx1(q), gy1(q)} of the reference tile
+            const float4 t4 = *reinterpret_cast<const float4 *>(tp0 + 4 * (j * tw + i));
             const float qy = pyf + (float)j;
             // weight_cu, gipuma.cu:186-193
-            const float leftValue = tp[0];
+            const float leftValue = t4.x;
             const float colorDis = __builtin_fabsf(leftValue - centre);
             float w;
             if (U8)
@@ -487,9 +491,9 @@ __device__ __forceinline__ float view_cost_loop(const Problem *__restrict__ P, c
             }
             const float sc = tp5.sc, gx2 = tp5.gx2, gy2 = tp5.gy2;
             // pmCostComputation_shared, gipuma.cu:251-274
-            const float colDiff = __builtin_fabsf(leftValue - sc);
-            const float gx1 = tp[1] - tp[-1];
-            const float gy1 = tp[tw] - tp[-tw];
+            const float colDiff = __builtin_fabsf(t4.w - sc);  // t4.w == t4.x == I(q)
+            const float gx1 = t4.y;
+            const float gy1 = t4.z;
             const float gradX = gx1 - gx2;
             const float gradY = gy1 - gy2;
             const float gradDis =
@@ -722,7 +726,10 @@ __device__ __forceinline__ void stage_tile(const Problem *__restrict__ P, float 
     const int hw = win.halo_w(), hh = win.halo_h();
     const int tw = kTileW + 2 * hw, th = tile_h + 2 * hh;
     const gptr_f32 ref = (gptr_f32)P->ref;
-    float *tile = lds + lut_size<CH>();
+    float *tile = lds + lut_size<CH>();  // float4 per texel
+    // gray: the scalar image goes to a scratch plane behind the float4 tile first, so that the
+    // central differences can be formed once per tile instead of once per sample
+    float *plane = tile + 4 * tw * th;
     for (int k = threadIdx.x; k < tw * th; k += kThreads) {
         const int ty = k / tw, tx = k - ty * tw;
         const int gx = clampi(x0 - hw + tx, 0, P->cols - 1);
@@ -731,13 +738,29 @@ __device__ __forceinline__ void stage_tile(const Problem *__restrict__ P, float 
             const gptr_f32 s = ref + (gy * P->pitch + 4 * gx);
             *reinterpret_cast<float4 *>(tile + 4 * k) = make_float4(s[0], s[1], s[2], 0.0f);
         } else {
-            tile[k] = ref[gy * P->pitch + gx];
+            plane[k] = ref[gy * P->pitch + gx];
         }
     }
     if (want_lut)
         for (int k = threadIdx.x; k < lut_size<CH>(); k += kThreads)
             lds[k] = exp_model(-(CH == 4 ? (float)k * 0.3333333f : (float)k) / P->gamma);
     __syncthreads();
+    if (CH == 1) {
+        // {I, gx1, gy1, -} with gx1 = I(x+1) - I(x-1), gy1 = I(y+1) - I(y-1): the reference-side
+        // terms of pmCostComputation_shared (gipuma.cu:254-259), same fp32 subtractions
+        for (int k = threadIdx.x; k < tw * th; k += kThreads) {
+            const int ty = k / tw, tx = k - ty * tw;
+            float gx1 = 0.0f, gy1 = 0.0f;
+            if (tx > 0 && tx < tw - 1 && ty > 0 && ty < th - 1) {
+                gx1 = plane[k + 1] - plane[k - 1];
+                gy1 = plane[k + tw] - plane[k - tw];
+            }
+            // .w repeats I so that the per-sample read uses all four dwords: one ds_read_b128 (4 LDS
+            // cycles) instead of the ds_read_b96 (8) the compiler picks for three
+            *reinterpret_cast<float4 *>(tile + 4 * k) = make_float4(plane[k], gx1, gy1, plane[k]);
+        }
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -762,8 +785,8 @@ __global__ __launch_bounds__(kThreads) void init_kernel(const Problem *__restric
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
     const int px = x0 + lx, py = y0 + ly;
     if (px >= P->cols || py >= P->rows) return;
-    const float *tp0 = lds + lut_size<CH>() + ((ly + hh) * tw + (lx + hw)) * CH;
-    float *cv = lds + lut_size<CH>() + tw * (kDenseTileH + 2 * hh) * CH + threadIdx.x;
+    const float *tp0 = lds + lut_size<CH>() + ((ly + hh) * tw + (lx + hw)) * 4;
+    float *cv = lds + lut_size<CH>() + tw * (kDenseTileH + 2 * hh) * (CH == 4 ? 4 : 5) + threadIdx.x;
     const int center = py * P->cols + px;
     float4 pl;
     if (GENERATE) {
@@ -827,8 +850,8 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(const Problem *__restri
     const int lx = 2 * (threadIdx.x & 15) + ((ly + colour) & 1);  // tile origin is even in x and y
     const int px = x0 + lx, py = y0 + ly;
     if (px >= cols || py >= rows) return;
-    const float *tp0 = lds + lut_size<CH>() + ((ly + hh) * tw + (lx + hw)) * CH;
-    float *cv = lds + lut_size<CH>() + tw * (kSweepTileH + 2 * hh) * CH + threadIdx.x;
+    const float *tp0 = lds + lut_size<CH>() + ((ly + hh) * tw + (lx + hw)) * 4;
+    float *cv = lds + lut_size<CH>() + tw * (kSweepTileH + 2 * hh) * (CH == 4 ? 4 : 5) + threadIdx.x;
     const int center = py * cols + px;
 
     // read state (gipuma.cu:1527-1530)
