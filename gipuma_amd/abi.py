@@ -95,7 +95,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("GIPUMA_HIP_LIB") or LIB_PATH  # env: A/B a differently built library
     if not os.path.exists(p):
         raise GipumaHipError(
             "HIP extension not built: %s is missing (run `python -c 'import __graft_entry__ as g; "

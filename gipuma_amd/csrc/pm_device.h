@@ -216,12 +216,13 @@ struct Win {  // window geometry: compile-time for the shipped block sizes, runt
     __device__ __forceinline__ int halo_h() const { return BOX ? (BOX + 1) / 2 : (bv + 1) / 2; }
 };
 
-// inner (y) sample loop unrolling: full for the small windows, rolled for box 25 (13 samples per
-// column would need > 256 VGPRs) and for the runtime-sized window
+// inner (y) sample loop unrolling, measured on config C (box 15): 1 -> 14.6 ms (80 VGPRs),
+// 2 -> 13.3 ms (102), 4 -> 13.7 ms (128), full 8 -> 13.95 ms per sweep.  Two samples in flight
+// hide the window load behind the previous sample's arithmetic without costing occupancy.
 template <int BOX>
 __host__ __device__ constexpr int unroll_j()
 {
-    return BOX == 0 ? 1 : (BOX <= 15 ? (BOX + 1) / 2 : 1);
+    return BOX == 0 ? 1 : (BOX <= 15 ? 2 : 1);
 }
 
 struct Tune {  // experiment switches (GIPUMA_HIP_TUNE), all default off
