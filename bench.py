@@ -87,15 +87,28 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        # gloo prints a connection banner on stdout; keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = "cuda:%d" % local_rank
+    # one rank per GPU; modulo only matters when a launch oversubscribes the node (e.g. a 2-rank
+    # dry run on a 1-GPU box)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = "cuda:%d" % dev_index
 
     # this rank's shard: one reference view (config E = 8 different views, one per GPU)
     ref_view = views_for_rank(synth.DTU_REF_VIEWS, rank, world)[0]
     gs, info = synth.build_problem(args.config, ref_view=ref_view, device=dev, keep_on_device=True)
-    gs.desc.device_id = local_rank
+    gs.desc.device_id = dev_index
     torch.cuda.synchronize()
     n_pix = gs.rows * gs.cols
     n_views = len(gs.selected)
