@@ -1,0 +1,152 @@
+"""Batch runner: every image of a scan as reference view, sharded over the GPUs of a node
+(replaces the per-view process loop of the reference's scripts/dtu_fast.sh:30-55).
+
+    python -m gipuma_amd.batch --images-folder scan9/ --p-folder calib/ --output-folder results/ \\
+        --blocksize=15 --iterations=8 --n_best=3 --depth_min=300 --depth_max=800 \\
+        --min_angle=10 --max_angle=30 --max_views=10
+    python -m torch.distributed.run --nproc-per-node 8 -m gipuma_amd.batch ...      # 8 GPUs
+
+MI355X-first differences from the shell loop:
+  * one process per GPU handles MANY reference views; the scan's images are decoded and uploaded
+    to HBM once per process (a 49-view DTU scan is 0.4 GB of the 288 GB) and every session binds
+    them by device pointer -- no per-view process start, disk read or PCIe upload;
+  * reference views are sharded round-robin over the ranks (gipuma_amd.shard); there is no
+    inter-GPU communication;
+  * results land in <output>/<refname>/{disp.dmb, normals.dmb, cost.dmb} -- the dumps the
+    reference writes (main.cpp:1001-1015) and fusibile reads.
+
+Images: binary PGM (P5, 8 bit).  Calibration: <p-folder>/<image name>.P (fileIoUtils.h:83-110).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import abi, dmb
+from .cameras import get_camera_parameters, read_p_file, select_views
+from .problem import AlgorithmParameters, GlobalState, Session
+from .shard import views_for_rank
+
+
+def read_pgm(path):
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:2] != b"P5":
+        raise ValueError("%s: only binary PGM (P5) is read here" % path)
+    tokens, pos = [], 2
+    while len(tokens) < 3:
+        while data[pos:pos + 1].isspace():
+            pos += 1
+        if data[pos:pos + 1] == b"#":
+            pos = data.index(b"\n", pos) + 1
+            continue
+        end = pos
+        while not data[end:end + 1].isspace():
+            end += 1
+        tokens.append(int(data[pos:end]))
+        pos = end
+    cols, rows, maxv = tokens
+    if maxv != 255:
+        raise ValueError("%s: 8-bit images only" % path)
+    img = np.frombuffer(data, dtype=np.uint8, count=rows * cols, offset=pos + 1).reshape(rows, cols)
+    return img.astype(np.float32)
+
+
+def plan_views(P_all, names, ref_idx, cols, rows, ap, cam_scale=1.0):
+    """the reference's per-view recipe: reference first, every other image as a candidate,
+    selectViews keeps those inside the angle cone (main.cpp:430-499); returns the camera set
+    restricted to [reference] + selected views and their global indices"""
+    order = [ref_idx] + [i for i in range(len(names)) if i != ref_idx]
+    cs_all = get_camera_parameters([P_all[i] for i in order], cam_scale=cam_scale)
+    ap_view = AlgorithmParameters(**{k: getattr(ap, k) for k in vars(ap)})
+    subset, dmin, dmax = select_views(cs_all, cols, rows, ap.min_angle, ap.max_angle, ap.max_views,
+                                      ap.depthMin, ap.depthMax)
+    used = [order[0]] + [order[i] for i in subset]
+    cs = get_camera_parameters([P_all[i] for i in used], cam_scale=cam_scale)
+    ap_view.depthMin, ap_view.depthMax = dmin, dmax
+    return cs, used, ap_view
+
+
+def main(argv=None):
+    pa = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    pa.add_argument("--images-folder", required=True)
+    pa.add_argument("--p-folder", required=True)
+    pa.add_argument("--output-folder", required=True)
+    pa.add_argument("--views", default="all", help="comma separated image names to use as reference (default all)")
+    pa.add_argument("--blocksize", type=int, default=19)
+    pa.add_argument("--iterations", type=int, default=8)
+    pa.add_argument("--n_best", type=int, default=2)
+    pa.add_argument("--cost_gamma", type=float, default=10.0)
+    pa.add_argument("--depth_min", type=float, default=-1.0)
+    pa.add_argument("--depth_max", type=float, default=-1.0)
+    pa.add_argument("--min_angle", type=float, default=5.0)
+    pa.add_argument("--max_angle", type=float, default=45.0)
+    pa.add_argument("--max_views", type=int, default=9)
+    pa.add_argument("--cam_scale", type=float, default=1.0)
+    pa.add_argument("--seed", type=int, default=1)
+    args = pa.parse_args(argv)
+    # the reference parses these with sscanf("%f") into float fields (main.cpp:300-360)
+    for k in ("cost_gamma", "depth_min", "depth_max", "min_angle", "max_angle", "cam_scale"):
+        setattr(args, k, float(np.float32(getattr(args, k))))
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise abi.GipumaHipError("gipuma_amd.batch needs a GPU; there is no CPU fallback")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+
+    names = sorted(n for n in os.listdir(args.images_folder) if n.lower().endswith(".pgm"))
+    if len(names) < 2:
+        raise SystemExit("need at least 2 PGM images in %s" % args.images_folder)
+    P_all = [read_p_file(os.path.join(args.p_folder, n + ".P")) for n in names]
+    # the whole scan resident in HBM, once
+    t0 = time.perf_counter()
+    host = [read_pgm(os.path.join(args.images_folder, n)) for n in names]
+    rows, cols = host[0].shape
+    dev = [torch.from_numpy(im).to("cuda:%d" % dev_index) for im in host]
+    torch.cuda.synchronize()
+    t_load = time.perf_counter() - t0
+
+    refs = names if args.views == "all" else [v for v in args.views.split(",") if v]
+    mine = views_for_rank(refs, rank, world) if len(refs) >= world else refs[rank:rank + 1]
+    ap = AlgorithmParameters(iterations=args.iterations, n_best=args.n_best, gamma=args.cost_gamma,
+                             depthMin=args.depth_min, depthMax=args.depth_max, min_angle=args.min_angle,
+                             max_angle=args.max_angle, max_views=args.max_views)
+    ap.set_blocksize(args.blocksize)
+    os.makedirs(args.output_folder, exist_ok=True)
+    report = []
+    for ref_name in mine:
+        ref_idx = names.index(ref_name)
+        cs, used, ap_view = plan_views(P_all, names, ref_idx, cols, rows, ap, args.cam_scale)
+        if len(used) < 2:
+            report.append({"ref": ref_name, "skipped": "no source view inside the angle cone"})
+            continue
+        imgs = [dev[i] for i in used]
+        gs = GlobalState(imgs, cs, list(range(1, len(used))), ap_view, seed=args.seed,
+                         device_ptrs=[t.data_ptr() for t in imgs], rows=rows, cols=cols, device_id=dev_index)
+        with Session(gs) as s:
+            t = s.solve(timing=True)
+            n4, cost = s.get_state()
+        folder = os.path.join(args.output_folder, os.path.splitext(ref_name)[0])
+        os.makedirs(folder, exist_ok=True)
+        dmb.write_dmb(os.path.join(folder, "disp.dmb"), n4[..., 3])
+        dmb.write_dmb(os.path.join(folder, "normals.dmb"), n4[..., :3])
+        dmb.write_dmb(os.path.join(folder, "cost.dmb"), cost)
+        report.append({"ref": ref_name, "sources": [names[i] for i in used[1:]], "device_ms": t.ms_total,
+                       "mpix_per_s": rows * cols / (t.ms_total * 1e-3) / 1e6})
+    with open(os.path.join(args.output_folder, "batch_rank%d.json" % rank), "w") as f:
+        json.dump({"rank": rank, "world": world, "device": dev_index, "load_seconds": t_load,
+                   "views": report}, f, indent=1)
+    print("rank %d/%d: %d reference views on cuda:%d" % (rank, world, len(report), dev_index))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
