@@ -221,3 +221,26 @@ def test_ref_colour_float4_instantiation():
     d_rel = rel(rn[..., 3], on[..., 3])
     n_err = np.abs(rn[..., :3] - on[..., :3]).max(-1)
     assert ((d_rel < 1e-4) & (n_err < 1e-3)).mean() > 0.99
+
+
+@needs_ref
+@pytest.mark.parametrize("comb", [abi.COMB_ALL, abi.COMB_GOOD, abi.COMB_ANGLE])
+def test_ref_other_cost_combinations(comb):
+    """ALL / GOOD / ANGLE through the reference's pmCostMultiview_cu (gipuma.cu:769-805)"""
+    gs, _ = synth.build_problem(synth.tiny_config(cols=64, rows=64, n_src=4, blocksize=7, iterations=1),
+                                cost_comb=comb)
+    r = ref_lib.RefState(gs)
+    o = OracleState(gs)
+    r.init_planes()
+    o.init_planes()
+    rn, rc = r.get_state()
+    assert np.array_equal(bits(rn), bits(o.norm4))
+    assert costs_close(rc, o.cost)
+    for colour in (abi.BLACK, abi.RED):
+        o.norm4[:], o.cost[:] = rn, rc
+        r.sweep(0, colour)
+        o.sweep(0, colour, unfused=True)
+        rn, rc = r.get_state()
+        same = (bits(rn) == bits(o.norm4)).all(-1)
+        assert same.mean() > 0.995
+        assert costs_close(rc[same], o.cost[same])

@@ -326,3 +326,85 @@ def test_degenerate_planes_take_the_safe_divide_path(hip, tiny_problem):
         got = s.eval_cost(planes)
     want = OracleState(gs).eval_cost(planes)
     assert_same(got, want, "degenerate eval_cost")
+
+
+# ------------------------------------------------------------------------------------------------
+# edge cases: ragged / tiny images, maximum view count, largest window, zero iterations
+# ------------------------------------------------------------------------------------------------
+def _problem_from(gs, images, selected, **ap_over):
+    from gipuma_amd.problem import AlgorithmParameters, GlobalState
+    ap = AlgorithmParameters(**{k: getattr(gs.params, k) for k in vars(gs.params)})
+    for k, v in ap_over.items():
+        setattr(ap, k, v)
+    return GlobalState(images, gs.cameras, selected, ap, seed=7)
+
+
+@pytest.mark.parametrize("cols,rows", [(33, 17), (5, 3), (1, 1), (64, 2), (3, 40)])
+def test_ragged_and_tiny_images(hip, cols, rows):
+    """sizes that are not tile multiples, smaller than the window, smaller than the far-neighbour
+    distance, down to a single pixel"""
+    gs, _ = synth.build_problem(synth.tiny_config(cols=64, rows=48, n_src=2, blocksize=7, iterations=2))
+    imgs = [np.ascontiguousarray(im[:rows, :cols]) for im in gs.images]
+    g = _problem_from(gs, imgs, gs.selected)
+    n4, c = runcuda(g)
+    o_n4, o_c = OracleState(g).run()
+    assert_same(n4, o_n4, "ragged %dx%d norm4" % (cols, rows))
+    assert_same(c, o_c, "ragged %dx%d cost" % (cols, rows))
+
+
+def test_maximum_number_of_views(hip):
+    """32 selected views = the reference's costVector[32] limit (gipuma.cu:736), ALL combiner"""
+    from gipuma_amd.cameras import CameraSet
+    gs, _ = synth.build_problem(synth.tiny_config(cols=48, rows=32, n_src=4, blocksize=7, iterations=1))
+    n = 33
+    cs = CameraSet(n)
+    imgs = []
+    for i in range(n):
+        src = 0 if i == 0 else 1 + (i - 1) % 4
+        C.memmove(C.byref(cs.c_array[i]), C.byref(gs.cameras.c_array[src]), C.sizeof(abi.Camera))
+        imgs.append(gs.images[src])
+    cs.f = gs.cameras.f
+    from gipuma_amd.problem import AlgorithmParameters, GlobalState
+    for comb in (abi.COMB_BEST_N, abi.COMB_ALL):
+        ap = AlgorithmParameters(iterations=1, n_best=3, cost_comb=comb, depthMin=300.0, depthMax=800.0)
+        ap.set_blocksize(7)
+        g = GlobalState(imgs, cs, list(range(1, n)), ap, seed=2)
+        n4, c = runcuda(g)
+        o_n4, o_c = OracleState(g).run()
+        assert_same(n4, o_n4, "32 views comb %d norm4" % comb)
+        assert_same(c, o_c, "32 views comb %d cost" % comb)
+    lib = abi.load_library()
+    g.desc.n_selected = 33
+    h = C.c_void_p()
+    assert lib.gipuma_hip_create(C.byref(g.desc), C.byref(h)) == -1      # one too many
+    g.desc.n_selected = 32
+
+
+def test_largest_window_and_rectangular_window(hip):
+    gs, _ = synth.build_problem(synth.tiny_config(cols=64, rows=48, n_src=2, blocksize=7, iterations=1))
+    for bh, bv in ((49, 49), (11, 5), (3, 25), (1, 1)):
+        g = _problem_from(gs, gs.images, gs.selected, box_hsize=bh, box_vsize=bv)
+        n4, c = runcuda(g)
+        o_n4, o_c = OracleState(g).run()
+        assert_same(n4, o_n4, "box %dx%d norm4" % (bh, bv))
+        assert_same(c, o_c, "box %dx%d cost" % (bh, bv))
+
+
+def test_zero_iterations_is_init_plus_final_conversion(hip, tiny_problem):
+    gs, _ = tiny_problem
+    g = _problem_from(gs, gs.images, gs.selected, iterations=0)
+    n4, c = runcuda(g)
+    o = OracleState(g)
+    o.init_planes()
+    o.finalize()
+    assert_same(n4, o.norm4, "0 iterations norm4")
+    assert_same(c, o.cost, "0 iterations cost")
+
+
+def test_n_best_larger_than_number_of_views(hip, tiny_problem):
+    gs, _ = tiny_problem
+    g = _problem_from(gs, gs.images, gs.selected[:1], n_best=4)      # one view, best-4
+    n4, c = runcuda(g)
+    o_n4, o_c = OracleState(g).run()
+    assert_same(n4, o_n4, "n_best > views norm4")
+    assert_same(c, o_c, "n_best > views cost")
