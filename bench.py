@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C", help="workload: A, B, C (default, the metric's config) or D")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cols", type=int, default=0, help="experiments only: override the frame width")
+    ap.add_argument("--rows", type=int, default=0, help="experiments only: override the frame height")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -107,7 +109,12 @@ def main():
 
     # this rank's shard: one reference view (config E = 8 different views, one per GPU)
     ref_view = views_for_rank(synth.DTU_REF_VIEWS, rank, world)[0]
-    gs, info = synth.build_problem(args.config, ref_view=ref_view, device=dev, keep_on_device=True)
+    over = {}
+    if args.cols:
+        over["cols"] = args.cols
+    if args.rows:
+        over["rows"] = args.rows
+    gs, info = synth.build_problem(args.config, ref_view=ref_view, device=dev, keep_on_device=True, **over)
     gs.desc.device_id = dev_index
     torch.cuda.synchronize()
     n_pix = gs.rows * gs.cols
@@ -205,6 +212,23 @@ def main():
                                  "%.3g patch samples/s" % (samples_per_frame / (np.mean(total_ms) * 1e-3))},
             "quality": quality,
         }
+        # The roof that actually binds: vector-ALU issue.  PMC
+        # SQ_INSTS_VALU of the same command (profiles/pmc_latest.json) x 64 lanes / launch time,
+        # against 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz for full-rate ops (the mix also holds
+        # half-rate cvt/min/floor, so 100 % is not reachable; DESIGN.md gives the mix bound).
+        if os.path.exists(pmc) and args.config == "C":
+            try:
+                pj = json.load(open(pmc))
+                lane_ops = pj["SQ_INSTS_VALU"] * 64.0
+                peak = 256 * 4 * 32 * 2.4e9
+                out["roofline_valu"] = {
+                    "bound": "valu", "achieved": lane_ops / (ms_launch * 1e-3) / 1e12, "peak": peak / 1e12,
+                    "unit": "T lane-instr/s", "frac": lane_ops / (ms_launch * 1e-3) / peak,
+                    "valu_instr_per_patch_sample": pj["SQ_INSTS_VALU"] * 64.0 / (samples_per_frame /
+                                                   (1 + iterations * (8 + r_ref)) * (8 + r_ref) / 2.0),
+                    "source": "profiles/pmc_latest.json (rocprofv3 --pmc SQ_INSTS_VALU, same command)"}
+            except Exception:
+                pass
         if world == 1 and not args.no_cpu_baseline:
             # the oracle reads host memory: same frames, copied back from HBM
             from gipuma_amd.problem import GlobalState, runcuda
