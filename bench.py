@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C", help="workload: A, B, C (default, the metric's config) or D")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--colour", action="store_true", help="-color_processing variant of the workload (T=float4)")
     ap.add_argument("--cols", type=int, default=0, help="experiments only: override the frame width")
     ap.add_argument("--rows", type=int, default=0, help="experiments only: override the frame height")
     args = ap.parse_args()
@@ -114,7 +115,8 @@ def main():
         over["cols"] = args.cols
     if args.rows:
         over["rows"] = args.rows
-    gs, info = synth.build_problem(args.config, ref_view=ref_view, device=dev, keep_on_device=True, **over)
+    gs, info = synth.build_problem(args.config, ref_view=ref_view, device=dev, keep_on_device=True,
+                                   colour=args.colour, **over)
     gs.desc.device_id = dev_index
     torch.cuda.synchronize()
     n_pix = gs.rows * gs.cols
@@ -180,8 +182,8 @@ def main():
             dz /= 10.0
         samples_per_frame = n_pix * (1 + iterations * (8 + r_ref)) * n_views * S
         out = {
-            "metric": "Mpixels/sec/GPU (1600x1200, 10 src views, 8 iters)" if args.config == "C"
-                      else "Mpixels/sec/GPU (config %s)" % args.config,
+            "metric": "Mpixels/sec/GPU (1600x1200, 10 src views, 8 iters)" if args.config == "C" and not args.colour
+                      else "Mpixels/sec/GPU (config %s%s)" % (args.config, ", colour" if args.colour else ""),
             "value": value,
             "unit": "Mpix/s",
             "value_per_gpu": value / world,
@@ -233,7 +235,7 @@ def main():
             # the oracle reads host memory: same frames, copied back from HBM
             from gipuma_amd.problem import GlobalState, runcuda
             gs_host = GlobalState([im.cpu().numpy() for im in gs.images], gs.cameras, gs.selected,
-                                  gs.params, seed=gs.desc.seed)
+                                  gs.params, seed=gs.desc.seed)  # (rows, cols[, 4]) arrays
             # the boundary as the reference's main.cpp uses it: host images in, host planes out
             # (upload + window packing + solve + download); reported, never `value`
             t1 = time.perf_counter()
