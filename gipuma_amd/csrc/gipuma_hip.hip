@@ -55,6 +55,9 @@ struct gipuma_hip_session {
     int *flag = nullptr;
     bool combine_reg = false;
     bool unfused = false;
+    // state invariant cost[p] == cost(p, plane[p]): true once init_planes has run, not assumed after
+    // gipuma_hip_set_state (the caller may install any pair); the sweep kernel's skip rule (A) needs it
+    bool costs_trusted = false;
     int box = 0;             // specialised window size, 0 = runtime
     int ch = 1;              // 1 = gray (T=float), 4 = colour (T=float4)
     unsigned tune = 0;
@@ -144,11 +147,12 @@ int validate(const gipuma_hip_desc *d)
 void copy9(float *dst, const float *src) { memcpy(dst, src, 9 * sizeof(float)); }
 void copy3(float *dst, const float *src) { memcpy(dst, src, 3 * sizeof(float)); }
 
-size_t lds_bytes(const gipuma_hip_session *s, int tile_h, bool with_cv)
+size_t lds_bytes(const gipuma_hip_session *s, int tile_h, bool with_cv, bool sweep)
 {
     const int hw = (s->hp.box_h + 1) / 2, hh = (s->hp.box_v + 1) / 2;
-    size_t n = (s->ch == 4 ? pm::lut_size<4>() : pm::lut_size<1>()) +
-               (size_t)(pm::kTileW + 2 * hw) * (size_t)(tile_h + 2 * hh) * (size_t)(s->ch == 4 ? 4 : 5);
+    const int texels = (pm::kTileW + 2 * hw) * (tile_h + 2 * hh);
+    size_t n = (s->ch == 4 ? pm::lut_size<4>() : pm::lut_size<1>()) + (size_t)4 * texels +
+               (size_t)(s->ch == 4 ? pm::work_floats<4>(texels, sweep) : pm::work_floats<1>(texels, sweep));
     if (with_cv) n += (size_t)s->n_sel * pm::kThreads;
     return n * sizeof(float);
 }
@@ -159,8 +163,9 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
     const int gy = (s->rows + pm::kSweepTileH - 1) / pm::kSweepTileH;
     const uint32_t phase = 1u + 2u * (uint32_t)iteration + (uint32_t)colour;
     sweep_fn k = pick_sweep(s);
+    const unsigned tune = s->tune | (s->costs_trusted ? 0u : Tune::kUntrustedCosts);
     hipLaunchKernelGGL(k, dim3(gx * gy), dim3(pm::kThreads), s->lds_sweep, s->stream, s->dp, s->norm4,
-                       s->cost, colour, phase, stages, s->tune);
+                       s->cost, colour, phase, stages, tune);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -364,8 +369,8 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         s->box = 0;  // the no-interior A/B arm only exists for these two variants
         s->combine_reg = false;
     }
-    s->lds_sweep = lds_bytes(s, pm::kSweepTileH, !s->combine_reg);
-    s->lds_dense = lds_bytes(s, pm::kDenseTileH, true);
+    s->lds_sweep = lds_bytes(s, pm::kSweepTileH, !s->combine_reg, true);
+    s->lds_dense = lds_bytes(s, pm::kDenseTileH, true, false);
     CREATE_OK(hipStreamSynchronize(s->stream));  // host image buffers may be released by the caller
 #undef CREATE_OK
     *out = s;
@@ -394,7 +399,9 @@ int gipuma_hip_init_planes(gipuma_hip_session *s)
 {
     if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
     HIP_OK(hipSetDevice(s->device));
-    return launch_dense(s, true, s->norm4, s->cost);
+    const int rc = launch_dense(s, true, s->norm4, s->cost);
+    if (!rc) s->costs_trusted = true;
+    return rc;
 }
 
 int gipuma_hip_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stages)
@@ -473,6 +480,7 @@ int gipuma_hip_set_state(gipuma_hip_session *s, const float *norm4_host, const f
     if (cost_host)
         HIP_OK(hipMemcpyAsync(s->cost, cost_host, np * sizeof(float), hipMemcpyHostToDevice, s->stream));
     HIP_OK(hipStreamSynchronize(s->stream));
+    s->costs_trusted = false;
     return 0;
 }
 

@@ -206,6 +206,19 @@ __host__ __device__ constexpr int lut_size()
     return CH == 4 ? 768 : kLutSize;  // colour: |dB|+|dG|+|dR| = 0..765
 }
 
+// sweep kernel scratch per workgroup: [8][256] candidate costs, 2048 u16 task slots, 32 counters
+constexpr int kTaskScratchFloats = 8 * kThreads + (8 * kThreads) / 2 + 32;
+
+template <int CH>
+__host__ __device__ constexpr int work_floats(int tile_texels, bool sweep)
+{
+    // gray staging plane (tile_texels floats, dead after stage_tile) and the sweep kernel's
+    // per-wavefront task scratch share one region
+    const int plane = CH == 1 ? tile_texels : 0;
+    const int tasks = sweep ? kTaskScratchFloats : 0;
+    return plane > tasks ? plane : tasks;
+}
+
 template <int BOX>
 struct Win {  // window geometry: compile-time for the shipped block sizes, runtime for BOX == 0
     int bh, bv;
@@ -227,7 +240,8 @@ __host__ __device__ constexpr int unroll_j()
 
 struct Tune {  // experiment switches (GIPUMA_HIP_TUNE), all default off
     static constexpr unsigned kNoLut = 1, kNoInterior = 2, kNoXcdRemap = 4, kGenericBox = 8,
-                              kGenericCombine = 16, kRowMajorTiles = 32;
+                              kGenericCombine = 16, kRowMajorTiles = 32, kNoSkip = 64,
+                              kUntrustedCosts = 128;  // set by the host after gipuma_hip_set_state
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -787,7 +801,8 @@ __global__ __launch_bounds__(kThreads) void init_kernel(const Problem *__restric
     const int px = x0 + lx, py = y0 + ly;
     if (px >= P->cols || py >= P->rows) return;
     const float *tp0 = lds + lut_size<CH>() + ((ly + hh) * tw + (lx + hw)) * 4;
-    float *cv = lds + lut_size<CH>() + tw * (kDenseTileH + 2 * hh) * (CH == 4 ? 4 : 5) + threadIdx.x;
+    float *cv = lds + lut_size<CH>() + 4 * tw * (kDenseTileH + 2 * hh) +
+                work_floats<CH>(tw * (kDenseTileH + 2 * hh), false) + threadIdx.x;
     const int center = py * P->cols + px;
     float4 pl;
     if (GENERATE) {
@@ -825,10 +840,46 @@ __global__ __launch_bounds__(kThreads) void init_kernel(const Problem *__restric
 
 // One colour of one iteration: the bodies of gipuma_checkerboard_spatialPropClose_cu
 // (gipuma.cu:1471-1588), ..._spatialPropFar_cu (:1353-1468) and ..._planeRefinement_cu
-// (:1590-1711) run back to back on the same lane.  Fusing them is result-identical: every pixel
-// of a colour reads only its own state and pixels of the OTHER colour (distances 1 and 5 are odd,
-// :1730-1734), which no lane of this launch writes.  `stages` selects a subset so the three
-// reference launches can also be reproduced one by one.
+// (:1590-1711) in one launch.  Fusing them is result-identical: every pixel of a colour reads only
+// its own state and pixels of the OTHER colour (distances 1 and 5 are odd, :1730-1734), which no
+// lane of this launch writes.  `stages` selects a subset so the three reference launches can also
+// be reproduced one by one.
+//
+// Work reduction that cannot change a result ("exact skipping"):
+//   The cost of a plane at a pixel is a pure function of (pixel, plane).  Of the up-to-8
+//   propagation candidates of a pixel, one that is BITWISE equal to
+//     (A) the pixel's current plane -- its cost is exactly the stored cost (the state invariant
+//         cost[p] == cost(p, plane[p]) holds after init_planes and after every accept; it is NOT
+//         assumed after gipuma_hip_set_state, see `trust`), so `c < cost_now` is false; or
+//     (D) an earlier candidate of the same pixel -- same cost and same depth test; if the earlier
+//         one was accepted then c == cost_now, if it was rejected then c >= cost_then >= cost_now
+//   can never be accepted (strict <, gipuma.cu:868) and is not evaluated.  On config C the
+//   evaluated candidates drop from 8 to 2.7 per pixel by the last half-sweep.  Because the
+//   per-wavefront MAXIMUM stays near 8, the surviving (pixel, candidate) pairs of the whole
+//   workgroup are compacted -- wavefront ballots + a 32-counter exchange through LDS -- into one
+//   task list (ordered by candidate slot, then lane, so neighbouring lanes still evaluate
+//   neighbouring pixels) and evaluated 256 at a time by whichever lane is free, which also
+//   balances the four wavefronts; the owner lane then replays its accept decisions in the
+//   reference order up, down, left, right (distance 1, then 5) from the stored costs.
+__device__ __forceinline__ bool same_bits(float4 a, float4 b)
+{
+    return ((__float_as_uint(a.x) ^ __float_as_uint(b.x)) | (__float_as_uint(a.y) ^ __float_as_uint(b.y)) |
+            (__float_as_uint(a.z) ^ __float_as_uint(b.z)) | (__float_as_uint(a.w) ^ __float_as_uint(b.w))) == 0u;
+}
+
+// neighbour of candidate slot k (0..3 distance 1, 4..7 distance 5; up, down, left, right) and
+// whether the reference's guard lets it be tested (gipuma.cu:1571-1582, 1450-1462)
+__device__ __forceinline__ bool neighbour(int k, int px, int py, int rows, int cols, int center, int &nb)
+{
+    const int dist = k < 4 ? 1 : 5;
+    switch (k & 3) {
+    case 0: nb = center - dist * cols; return py > dist - 1;
+    case 1: nb = center + dist * cols; return py < rows - dist;
+    case 2: nb = center - dist; return px > dist - 1;
+    default: nb = center + dist; return px < cols - dist;
+    }
+}
+
 template <int BOX, bool U8, bool COMBINE_REG, bool INTERIOR, int CH>
 __global__ __launch_bounds__(kThreads) void sweep_kernel(const Problem *__restrict__ P,
                                                          float4 *__restrict__ norm4, float *__restrict__ cost,
@@ -845,26 +896,82 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(const Problem *__restri
     const int x0 = txy.x * kTileW, y0 = txy.y * kSweepTileH;
     stage_tile<BOX, CH>(P, lds, x0, y0, kSweepTileH, win, U8);
     const int hw = win.halo_w(), hh = win.halo_h();
-    const int tw = kTileW + 2 * hw;
+    const int tw = kTileW + 2 * hw, th = kSweepTileH + 2 * hh;
+    const float *tile = lds + lut_size<CH>();
+    float *work = lds + lut_size<CH>() + 4 * tw * th;
+    float *cv = work + work_floats<CH>(tw * th, true) + threadIdx.x;
+    // (gray: the staging plane inside `work` is dead after stage_tile's last barrier)
+    const int wave = threadIdx.x >> 6;
+    float *bres = work;                                                           // [8][256] costs
+    unsigned short *btask = reinterpret_cast<unsigned short *>(work + 8 * kThreads);  // [2048] tid | slot << 8
+    int *wcnt = reinterpret_cast<int *>(work + 8 * kThreads + (8 * kThreads) / 2);  // [4 waves][8 slots]
+
     // lane -> pixel: 16 pixels of the colour per tile row; a wavefront covers 4 rows x 32 columns
     const int ly = threadIdx.x >> 4;
     const int lx = 2 * (threadIdx.x & 15) + ((ly + colour) & 1);  // tile origin is even in x and y
     const int px = x0 + lx, py = y0 + ly;
-    if (px >= cols || py >= rows) return;
-    const float *tp0 = lds + lut_size<CH>() + ((ly + hh) * tw + (lx + hw)) * 4;
-    float *cv = lds + lut_size<CH>() + tw * (kSweepTileH + 2 * hh) * (CH == 4 ? 4 : 5) + threadIdx.x;
+    const bool active = px < cols && py < rows;
     const int center = py * cols + px;
+    const bool trust = !(tune & Tune::kUntrustedCosts);
 
     // read state (gipuma.cu:1527-1530)
-    float4 pl = norm4[center];
-    float cst = cost[center];
-    float depth = depth_from_plane(rc, pl, px, py);
+    float4 pl = make_float4(0.f, 0.f, 0.f, 0.f);
+    float cst = 0.f, depth = 0.f;
+    unsigned needmask = 0;  // candidate slots of this pixel that must be evaluated
+    if (active) {
+        pl = norm4[center];
+        cst = cost[center];
+        depth = depth_from_plane(rc, pl, px, py);
+        float4 cands[8];
+        unsigned valid = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            int nb;
+            const bool ok = neighbour(k, px, py, rows, cols, center, nb) && (stages & (k < 4 ? 1u : 2u));
+            if (ok) {
+                cands[k] = norm4[nb];
+                valid |= 1u << k;
+            }
+        }
+        if (tune & Tune::kNoSkip) {
+            needmask = valid;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                bool fresh = (valid >> k) & 1u;
+                if (fresh && trust && same_bits(cands[k], pl)) fresh = false;  // (A)
+#pragma unroll
+                for (int j = 0; j < k; j++)
+                    if (fresh && ((valid >> j) & 1u) && same_bits(cands[k], cands[j])) fresh = false;  // (D)
+                if (fresh) needmask |= 1u << k;
+            }
+        }
+    }
+    // workgroup task list, slot-major then lane-minor: per-wavefront ballot counts are exchanged
+    // through LDS, then every lane places its own surviving candidates
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const unsigned long long m = __ballot((needmask >> k) & 1u);
+        if ((threadIdx.x & 63) == 0) wcnt[wave * 8 + k] = __popcll(m);
+    }
+    __syncthreads();
+    int n_tasks = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const bool b = (needmask >> k) & 1u;
+        const unsigned long long m = __ballot(b);
+        const int c0 = wcnt[k], c1 = wcnt[8 + k], c2 = wcnt[16 + k], c3 = wcnt[24 + k];
+        if (b) {
+            const int before = (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
+            const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            btask[n_tasks + before + below] = (unsigned short)(threadIdx.x | (k << 8));
+        }
+        n_tasks += c0 + c1 + c2 + c3;
+    }
+    __syncthreads();
+    const int prop_rounds = (n_tasks + kThreads - 1) / kThreads;
 
-    // One candidate loop, one call site of the cost function:
-    //   k = 0..3  neighbours at distance 1, k = 4..7 at distance 5 (up, down, left, right)
-    //             spatialPropagation_cu, gipuma.cu:832-874
-    //   k >= 8    random plane refinement steps, planeRefinement_cu + getRndDispAndUnitVector_cu,
-    //             gipuma.cu:928-994, 890-927
+    // planeRefinement_cu + getRndDispAndUnitVector_cu, gipuma.cu:928-994, 890-927
     const float min_disp = P->min_disp, max_disp = P->max_disp;
     int nref = 0;  // number of refinement steps: deltaZ = max_disp/2, /10 ... >= 0.01 (:958-959)
     if (stages & 4u)
@@ -872,57 +979,86 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(const Problem *__restri
     Vec3 view = {0.f, 0.f, 0.f};
     uint32_t pre = 0, draw = 0;
     float deltaN = 1.0f, deltaZ = max_disp / 2.0f;
-    for (int k = 0; k < 8 + nref; k++) {
-        bool ok;
-        float4 cand;
-        float d_new;
-        if (k < 8) {
-            if (!(stages & (k < 4 ? 1u : 2u))) continue;
-            const int dist = k < 4 ? 1 : 5;
-            int nb;
-            switch (k & 3) {
-            case 0: ok = py > dist - 1; nb = center - dist * cols; break;
-            case 1: ok = py < rows - dist; nb = center + dist * cols; break;
-            case 2: ok = px > dist - 1; nb = center - dist; break;
-            default: ok = px < cols - dist; nb = center + dist; break;
+
+    // One loop, one call site of the cost function: rounds [0, prop_rounds) evaluate compacted
+    // propagation tasks (possibly of another lane's pixel), then the owner replays its accepts,
+    // then rounds [prop_rounds, prop_rounds + nref) are the lane's own refinement steps.
+    for (int r = 0; r <= prop_rounds + nref; r++) {
+        if (r == prop_rounds) {
+            // replay: spatialPropagation_cu's accept test (gipuma.cu:865-872) in slot order
+            __syncthreads();  // every wavefront runs the same number of rounds, so this is uniform
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if ((needmask >> k) & 1u) {
+                    int nb;
+                    neighbour(k, px, py, rows, cols, center, nb);
+                    const float4 cand = norm4[nb];
+                    const float c = bres[k * kThreads + threadIdx.x];
+                    const float d_new = depth_from_plane(rc, cand, px, py);
+                    if (d_new >= rc.depth_min && d_new <= rc.depth_max && c < cst) {  // :829-830, :868
+                        depth = d_new;
+                        pl = cand;
+                        cst = c;
+                    }
+                }
             }
-            if (ok) {
-                cand = norm4[nb];
-                d_new = depth_from_plane(rc, cand, px, py);
-            }
-        } else {
-            if (k == 8) {
+            if (nref > 0 && active) {
                 depth = depth_from_plane(rc, pl, px, py);  // the refine kernel re-derives it, :1660
                 view = view_vector(rc, px, py);
                 pre = rng_prefix(P->seed, phase, (uint32_t)px, (uint32_t)py);
             }
-            ok = true;
-            const float disp = disp_depth(rc.f, rc.baseline, depth);
-            const float minDelta = -__builtin_fminf(deltaZ, min_disp + disp);  // sic, :909
-            const float maxDelta = __builtin_fminf(deltaZ, max_disp - disp);
-            const float u0 = rng_uniform(pre, draw++);
-            const float u1 = rng_uniform(pre, draw++);
-            const float u2 = rng_uniform(pre, draw++);
-            const float u3 = rng_uniform(pre, draw++);
-            const float dz = between(u0, minDelta, maxDelta);
-            const float dispOut = __builtin_fminf(__builtin_fmaxf(disp + dz, min_disp), max_disp);
-            d_new = disp_depth(rc.f, rc.baseline, dispOut);
-            Vec3 n;
-            n.x = pl.x + between(u1, -deltaN, deltaN);
-            n.y = pl.y + between(u2, -deltaN, deltaN);
-            n.z = pl.z + between(u3, -deltaN, deltaN);
-            n = on_hemisphere(normalize3(n), view);
-            cand = make_float4(n.x, n.y, n.z, plane_d(rc, n, px, py, d_new));
+        }
+        if (r == prop_rounds + nref) break;
+
+        bool do_eval;
+        float4 cand = make_float4(0.f, 0.f, -1.f, 1.f);
+        int epx = px, epy = py, slot = 0, owner = threadIdx.x;
+        float d_new = 0.f;
+        if (r < prop_rounds) {
+            const int pos = r * kThreads + threadIdx.x;
+            do_eval = pos < n_tasks;
+            if (do_eval) {
+                const unsigned t = btask[pos];
+                owner = (int)(t & 255u);
+                slot = (int)(t >> 8);
+                const int oly = owner >> 4;
+                const int olx = 2 * (owner & 15) + ((oly + colour) & 1);
+                epx = x0 + olx;
+                epy = y0 + oly;
+                int nb;
+                neighbour(slot, epx, epy, rows, cols, epy * cols + epx, nb);
+                cand = norm4[nb];
+            }
+        } else {
+            do_eval = active;
+            if (do_eval) {
+                const float disp = disp_depth(rc.f, rc.baseline, depth);
+                const float minDelta = -__builtin_fminf(deltaZ, min_disp + disp);  // sic, :909
+                const float maxDelta = __builtin_fminf(deltaZ, max_disp - disp);
+                const float u0 = rng_uniform(pre, draw++);
+                const float u1 = rng_uniform(pre, draw++);
+                const float u2 = rng_uniform(pre, draw++);
+                const float u3 = rng_uniform(pre, draw++);
+                const float dz = between(u0, minDelta, maxDelta);
+                const float dispOut = __builtin_fminf(__builtin_fmaxf(disp + dz, min_disp), max_disp);
+                d_new = disp_depth(rc.f, rc.baseline, dispOut);
+                Vec3 n;
+                n.x = pl.x + between(u1, -deltaN, deltaN);
+                n.y = pl.y + between(u2, -deltaN, deltaN);
+                n.z = pl.z + between(u3, -deltaN, deltaN);
+                n = on_hemisphere(normalize3(n), view);
+                cand = make_float4(n.x, n.y, n.z, plane_d(rc, n, px, py, d_new));
+            }
             deltaN = deltaN / 4.0f;
             deltaZ = deltaZ / 10.0f;
         }
-        if (ok) {
+        if (do_eval) {
+            const float *etp0 = tile + (((epy - y0) + hh) * tw + ((epx - x0) + hw)) * 4;
             const float c =
-                multiview_cost<BOX, U8, INTERIOR, COMBINE_REG, CH>(P, tp0, tw, lds, cv, px, py, cand, win);
-            // propagation also requires the plane's depth at this pixel inside [depthMin, depthMax]
-            // (ISDISPDEPTHWITHINBORDERS, :829-830); refinement does not (:986)
-            const bool in_range = k >= 8 || (d_new >= rc.depth_min && d_new <= rc.depth_max);
-            if (in_range && c < cst) {
+                multiview_cost<BOX, U8, INTERIOR, COMBINE_REG, CH>(P, etp0, tw, lds, cv, epx, epy, cand, win);
+            if (r < prop_rounds) {
+                bres[slot * kThreads + owner] = c;
+            } else if (c < cst) {  // refinement has no depth-range test, :986
                 depth = d_new;
                 pl = cand;
                 cst = c;
@@ -931,8 +1067,10 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(const Problem *__restri
     }
 
     // write back (gipuma.cu:1585-1587): 16 B + 4 B per active pixel
-    cost[center] = cst;
-    norm4[center] = pl;
+    if (active) {
+        cost[center] = cst;
+        norm4[center] = pl;
+    }
 }
 
 // gipuma_compute_disp, gipuma.cu:1080-1103

@@ -31,6 +31,18 @@ with Session(gs) as s:
             b = n4.view(np.uint32)
             need = np.zeros((R, Cc), np.int32)
             needB = np.zeros((R, Cc), np.int32)
+            # stateless variant: distinct planes among the 8 candidates that differ from the own plane
+            cands = []
+            for dist in (1, 5):
+                for dy, dx in ((-dist, 0), (dist, 0), (0, -dist), (0, dist)):
+                    ok = (ys + dy >= 0) & (ys + dy < R) & (xs + dx >= 0) & (xs + dx < Cc)
+                    cands.append((np.roll(b, (-dy, -dx), axis=(0, 1)), ok))
+            needAC = np.zeros((R, Cc), np.int32)
+            for k, (ck, okk) in enumerate(cands):
+                fresh = okk & ~(ck == b).all(-1)
+                for j in range(k):
+                    fresh &= ~(cands[j][1] & (cands[j][0] == ck).all(-1))
+                needAC += fresh
             for dist in (1, 5):
                 for dy, dx in ((-dist, 0), (dist, 0), (0, -dist), (0, dist)):
                     ok = (ys + dy >= 0) & (ys + dy < R) & (xs + dx >= 0) & (xs + dx < Cc)
@@ -46,8 +58,14 @@ with Session(gs) as s:
             n4, _ = s.get_state()
             chg = (before.view(np.uint32) != n4.view(np.uint32)).any(-1)
             changed[act] = chg[act]
+            blkAC = np.where(act, needAC, 0)[:Rt, :Ct].reshape(Rt // 16, 16, Ct // 32, 32).transpose(0, 2, 1, 3).reshape(-1, 512).sum(1)
+            wave = np.where(act, needAC, 0)[:Rt // 4 * 4, :Ct].reshape(Rt // 4, 4, Ct // 32, 32).transpose(0, 2, 1, 3).reshape(-1, 128).sum(1)
+            tot_ac = globals().get("tot_ac", 0.0) + np.ceil(wave / 64.0).mean() + 3
+            globals()["tot_ac"] = tot_ac
+            print("   stateless A+dedupe: %.2f / 8 per pixel; wave-compacted rounds %.2f" % (needAC[act].mean(), np.ceil(wave / 64.0).mean()))
             tot_need += rounds + 3
             tot_full += 11
             print("it %d colour %d: need eval (A+B) %.2f / 8 per pixel (B only %.2f); compacted rounds %.2f / 8; changed %.3f"
                   % (it, colour, need[act].mean(), needB[act].mean(), rounds, chg[act].mean()), flush=True)
 print("hypothesis evaluations with compaction: %.1f vs %.1f  -> x%.2f" % (tot_need, tot_full, tot_full / tot_need))
+print("stateless (A + dedupe), wave-level compaction: %.1f vs %.1f -> x%.2f" % (tot_ac, tot_full, tot_full / tot_ac))

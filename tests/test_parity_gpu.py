@@ -408,3 +408,71 @@ def test_n_best_larger_than_number_of_views(hip, tiny_problem):
     o_n4, o_c = OracleState(g).run()
     assert_same(n4, o_n4, "n_best > views norm4")
     assert_same(c, o_c, "n_best > views cost")
+
+
+# ------------------------------------------------------------------------------------------------
+# exact skipping of propagation candidates (sweep_kernel): must never change a result
+# ------------------------------------------------------------------------------------------------
+def test_skipping_matches_exhaustive_evaluation(hip):
+    """same run with every candidate evaluated (GIPUMA_HIP_TUNE bit 64) and with the skip rules:
+    identical bits, on a converging problem where most candidates end up skipped"""
+    gs, _ = synth.build_problem(synth.tiny_config(cols=128, rows=96, n_src=4, blocksize=9, iterations=6,
+                                                  n_best=3))
+    a = runcuda(gs)
+    os.environ["GIPUMA_HIP_TUNE"] = "64"
+    try:
+        b = runcuda(gs)
+    finally:
+        del os.environ["GIPUMA_HIP_TUNE"]
+    assert_same(a[0], b[0], "skip vs exhaustive norm4")
+    assert_same(a[1], b[1], "skip vs exhaustive cost")
+    o = OracleState(gs).run()
+    assert_same(a[0], o[0], "skip vs oracle norm4")
+
+
+def test_inconsistent_installed_costs_are_not_trusted(hip, tiny_problem):
+    """gipuma_hip_set_state may install costs that are NOT the cost of the installed planes; the
+    reference would then re-evaluate a neighbour plane equal to the pixel's own and adopt its
+    (lower) true cost.  Rule (A) must be off for such a session: compare with the oracle, which
+    always evaluates."""
+    gs, _ = tiny_problem
+    o = OracleState(gs)
+    o.init_planes()
+    # make many neighbours share planes, and inflate every stored cost
+    o.norm4[1::2, :] = o.norm4[0:-1:2, :]
+    o.norm4[:, 1::2] = o.norm4[:, 0:-1:2]
+    o.cost[:] = o.eval_cost(o.norm4) * np.float32(1.5) + np.float32(1.0)
+    with Session(gs) as s:
+        s.set_state(o.norm4, o.cost)
+        for it in range(2):
+            for colour in (abi.BLACK, abi.RED):
+                before_n4, before_c = o.norm4.copy(), o.cost.copy()
+                s.sweep(it, colour, abi.STAGE_CLOSE)
+                o.sweep(it, colour, abi.STAGE_CLOSE)
+                n4, c = s.get_state()
+                assert_same(n4, o.norm4, "untrusted it %d colour %d norm4" % (it, colour))
+                assert_same(c, o.cost, "untrusted it %d colour %d cost" % (it, colour))
+                if it == 0 and colour == abi.BLACK:
+                    # the scenario bites: pixels that kept their plane but got a new (true) cost --
+                    # exactly what rule (A) would have missed had it trusted the installed costs
+                    kept = (bits(before_n4) == bits(o.norm4)).all(-1)
+                    assert (kept & (before_c != o.cost)).sum() > 50
+
+
+def test_shared_planes_with_consistent_costs(hip, tiny_problem):
+    """the opposite corner: after init_planes the invariant holds, force many identical neighbour
+    planes through the kernels' own state by running sweeps to convergence and compare each"""
+    gs, _ = synth.build_problem(synth.tiny_config(cols=64, rows=48, n_src=2, blocksize=7, iterations=1))
+    o = OracleState(gs)
+    with Session(gs) as s:
+        s.init_planes()
+        o.init_planes()
+        for it in range(5):
+            for colour in (abi.BLACK, abi.RED):
+                s.sweep(it, colour, abi.STAGE_CLOSE | abi.STAGE_FAR)      # propagation only: planes spread
+                o.sweep(it, colour, abi.STAGE_CLOSE | abi.STAGE_FAR)
+        n4, c = s.get_state()
+        assert_same(n4, o.norm4, "propagation-only norm4")
+        assert_same(c, o.cost, "propagation-only cost")
+        same_as_right = (n4[:, 1:].view(np.uint32) == n4[:, :-1].view(np.uint32)).all(-1).mean()
+        assert same_as_right > 0.3        # the scenario really has shared planes
