@@ -206,7 +206,7 @@ __host__ __device__ constexpr int lut_size()
     return CH == 4 ? 768 : kLutSize;  // colour: |dB|+|dG|+|dR| = 0..765
 }
 
-// sweep kernel scratch per workgroup: [8][256] candidate costs, 2048 u16 task slots, 32 counters
+// sweep kernel scratch per workgroup: [8][256] candidate costs, 2048 u16 task slots, counters
 constexpr int kTaskScratchFloats = 8 * kThreads + (8 * kThreads) / 2 + 32;
 
 template <int CH>
@@ -856,10 +856,9 @@ __global__ __launch_bounds__(kThreads) void init_kernel(const Problem *__restric
 //   can never be accepted (strict <, gipuma.cu:868) and is not evaluated.  On config C the
 //   evaluated candidates drop from 8 to 2.7 per pixel by the last half-sweep.  Because the
 //   per-wavefront MAXIMUM stays near 8, the surviving (pixel, candidate) pairs of the whole
-//   workgroup are compacted -- wavefront ballots + a 32-counter exchange through LDS -- into one
-//   task list (ordered by candidate slot, then lane, so neighbouring lanes still evaluate
-//   neighbouring pixels) and evaluated 256 at a time by whichever lane is free, which also
-//   balances the four wavefronts; the owner lane then replays its accept decisions in the
+//   workgroup are compacted -- a wavefront-level scan plus a 4-counter exchange through LDS -- into
+//   one task list (owner-major: a pixel's surviving candidates are adjacent) and evaluated 256 at a
+//   time by whichever lane is free, which also balances the four wavefronts; the owner lane then replays its accept decisions in the
 //   reference order up, down, left, right (distance 1, then 5) from the stored costs.
 __device__ __forceinline__ bool same_bits(float4 a, float4 b)
 {
@@ -947,27 +946,26 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(const Problem *__restri
             }
         }
     }
-    // workgroup task list, slot-major then lane-minor: per-wavefront ballot counts are exchanged
-    // through LDS, then every lane places its own surviving candidates
+    // workgroup task list, owner-major (all surviving candidates of a pixel adjacent, pixels in lane
+    // order): a wavefront-level inclusive scan of the per-lane counts, wavefront totals exchanged
+    // through LDS.  Measured against slot-major order on config C: 9.97 vs 10.65 ms per sweep --
+    // a round then touches ~1/3 as many distinct pixels, i.e. fewer reference-tile rows and source
+    // cache lines.
+    const int cnt = __popc(needmask);
+    int incl = cnt;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const unsigned long long m = __ballot((needmask >> k) & 1u);
-        if ((threadIdx.x & 63) == 0) wcnt[wave * 8 + k] = __popcll(m);
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if ((int)(threadIdx.x & 63) >= d) incl += up;
     }
+    if ((threadIdx.x & 63) == 63) wcnt[wave] = incl;
     __syncthreads();
-    int n_tasks = 0;
+    const int c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
+    int pos0 = incl - cnt + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
+    const int n_tasks = c0 + c1 + c2 + c3;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const bool b = (needmask >> k) & 1u;
-        const unsigned long long m = __ballot(b);
-        const int c0 = wcnt[k], c1 = wcnt[8 + k], c2 = wcnt[16 + k], c3 = wcnt[24 + k];
-        if (b) {
-            const int before = (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
-            const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            btask[n_tasks + before + below] = (unsigned short)(threadIdx.x | (k << 8));
-        }
-        n_tasks += c0 + c1 + c2 + c3;
-    }
+    for (int k = 0; k < 8; k++)
+        if ((needmask >> k) & 1u) btask[pos0++] = (unsigned short)(threadIdx.x | (k << 8));
     __syncthreads();
     const int prop_rounds = (n_tasks + kThreads - 1) / kThreads;
 
