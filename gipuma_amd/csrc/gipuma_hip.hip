@@ -371,6 +371,13 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     }
     s->lds_sweep = lds_bytes(s, pm::kSweepTileH, !s->combine_reg, true);
     s->lds_dense = lds_bytes(s, pm::kDenseTileH, true, false);
+    if (s->lds_sweep > 160u * 1024u || s->lds_dense > 160u * 1024u) {  // 160 KiB of LDS per CU on gfx950
+        fail(GIPUMA_HIP_ERR_UNSUPPORTED, "window x views needs more than 160 KiB of LDS per workgroup");
+        std::string keep = g_err;
+        gipuma_hip_destroy(s);
+        g_err = keep;
+        return GIPUMA_HIP_ERR_UNSUPPORTED;
+    }
     CREATE_OK(hipStreamSynchronize(s->stream));  // host image buffers may be released by the caller
 #undef CREATE_OK
     *out = s;
