@@ -154,7 +154,11 @@ int gipuma_hip_eval_cost(gipuma_hip_session *s, const float *planes_host, float 
 /* host copies of the state planes (blocking) */
 int gipuma_hip_get_state(gipuma_hip_session *s, float *norm4_host, float *cost_host);
 int gipuma_hip_set_state(gipuma_hip_session *s, const float *norm4_host, const float *cost_host);
-/* device pointers of the state planes (for callers that keep results in HBM) */
+/* device pointers of the state planes (for callers that keep results in HBM).  A caller that
+ * WRITES the planes through these pointers must afterwards call
+ * gipuma_hip_set_state(s, NULL, NULL): like any set_state it tells the session that the stored
+ * costs are no longer known to be the costs of the stored planes (the sweep kernel skips
+ * candidates equal to a pixel's own plane only while that is known). */
 int gipuma_hip_state_device_ptrs(gipuma_hip_session *s, float **norm4_dev, float **cost_dev);
 /* init + iterations x (black, red) + finalize on the session, timed with HIP events.
  * Does not synchronise the host unless `timing` is non-NULL. */
