@@ -65,10 +65,21 @@ def pmc(d, sub="sweep_kernel"):
     print(json.dumps(res, indent=1, sort_keys=True))
 
 
+def series(db, sub="sweep_kernel"):
+    """durations of consecutive dispatches of one kernel, in launch order"""
+    cur = sqlite3.connect(db).cursor()
+    rows = list(cur.execute("select start, duration from kernels where name like ? order by start", ("%" + sub + "%",)))
+    print("# %d dispatches of *%s*: index, duration_ms" % (len(rows), sub))
+    for i, (_, d) in enumerate(rows):
+        print("%3d %8.3f" % (i, d / 1e6))
+
+
 if __name__ == "__main__":
     if len(sys.argv) < 3:
         sys.exit(__doc__)
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "series":
+        series(sys.argv[2], *(sys.argv[3:4]))
     else:
         pmc(sys.argv[2], *(sys.argv[3:4]))
