@@ -163,7 +163,10 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
     const int gy = (s->rows + pm::kSweepTileH - 1) / pm::kSweepTileH;
     const uint32_t phase = 1u + 2u * (uint32_t)iteration + (uint32_t)colour;
     sweep_fn k = pick_sweep(s);
-    const unsigned tune = s->tune | (s->costs_trusted ? 0u : Tune::kUntrustedCosts);
+    unsigned tune = s->tune | (s->costs_trusted ? 0u : Tune::kUntrustedCosts);
+    // task order (performance only): planes are still incoherent in the first two iterations, where
+    // grouping the evaluations of one plane saves cache-line fills; afterwards owner order is faster
+    if (iteration >= 2 && !(tune & Tune::kSourceMajorTasks)) tune |= Tune::kOwnerMajorTasks;
     hipLaunchKernelGGL(k, dim3(gx * gy), dim3(pm::kThreads), s->lds_sweep, s->stream, s->dp, s->norm4,
                        s->cost, colour, phase, stages, tune);
     HIP_OK(hipGetLastError());
@@ -312,6 +315,9 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         CREATE_OK(hipStreamSynchronize(s->stream));
         s->u8 = !not_u8 && !(s->tune & Tune::kNoLut);
         hp.pw = d->cols + 8;
+        // float-encoded window offsets need every entry index of a gray packed plane below 2^21
+        hp.magic_addr = s->u8 && s->ch == 1 && !(s->tune & Tune::kNoMagicAddr) &&
+                        (size_t)(d->rows + 3) * hp.pw <= (size_t)pm::kMagicMaxWords;
         if (s->u8) {
             const size_t words = (size_t)(d->rows + 3) * hp.pw * (s->ch == 4 ? 3 : 1);
             auto pack = s->ch == 4 ? pm::pack_kernel_c4 : pm::pack_kernel;

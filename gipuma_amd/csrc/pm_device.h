@@ -41,6 +41,8 @@ struct Problem {  // lives in device memory, read through scalar loads (wave-uni
     uint32_t seed;
     const float *ref;
     int pw, channels;  // packed layout: texels per row of V (cols + 8); 1 = gray, 4 = colour
+    int magic_addr;    // gray packed planes small enough (< 2^21 words) for float-encoded offsets
+    int pad_;
     RefCam rc;
     ViewCam view[kMaxViews];
 };
@@ -241,7 +243,10 @@ __host__ __device__ constexpr int unroll_j()
 struct Tune {  // experiment switches (GIPUMA_HIP_TUNE), all default off
     static constexpr unsigned kNoLut = 1, kNoInterior = 2, kNoXcdRemap = 4, kGenericBox = 8,
                               kGenericCombine = 16, kRowMajorTiles = 32, kNoSkip = 64,
-                              kUntrustedCosts = 128;  // set by the host after gipuma_hip_set_state
+                              kUntrustedCosts = 128,  // set by the host after gipuma_hip_set_state
+                              kNoMagicAddr = 1u << 30,  // integer window addressing (bits 8..23: band height)
+                              kOwnerMajorTasks = 1u << 29,   // always owner-major task lists
+                              kSourceMajorTasks = 1u << 28;  // always source-major (default: by iteration)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -351,6 +356,22 @@ __global__ __launch_bounds__(kThreads) void rcp_selftest_kernel(unsigned long lo
     if (c) atomicAdd(bad, (unsigned long long)c);
 }
 
+// fminf(x, tau) as the bare v_min_f32.  The compiler's fminf first quiets a possible signalling NaN
+// in `tau` with a v_max(tau, tau) that it re-issues inside the sample loop; here x is always an
+// arithmetic result (never signalling) and for a quiet-NaN x v_min_f32 returns tau like fminf does.
+__device__ __forceinline__ float min_nc(float x, float tau)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(tau));
+    return r;
+}
+__device__ __forceinline__ float min_abs_nc(float x, float tau)  // fminf(fabsf(x), tau)
+{
+    float r;
+    asm("v_min_f32_e64 %0, |%1|, %2" : "=v"(r) : "v"(x), "v"(tau));
+    return r;
+}
+
 // The five bilinear taps of pmCostComputation_shared (gipuma.cu:251-253) from one 4x4 window
 // (M1): centre value and the +-1 texel differences in x and y.  t<row><col>, corners unused.
 struct Taps {
@@ -430,7 +451,15 @@ __device__ __forceinline__ bool window_z_safe(const float *H, float qx0, float q
     return (lo >= 0x1p-100f && hi <= 0x1p100f) || (hi <= -0x1p-100f && lo >= -0x1p100f);
 }
 
-template <int BOX, bool U8, bool INTERIOR, bool FAST>
+// Exponent trick used by the U8 loop: for an integer n in [0, 2^21), the float 2^21 + n has ulp 1/4,
+// so its bit pattern is 0x4a000000 + 4n -- a byte offset of 4-byte entry n, produced by a full-rate
+// fp32 add instead of cvt + shift (conversions, integer min/max and shifts issue at ~60 % of the
+// fp32 rate on gfx950, scripts/ubench/valu_rates.hip).  The constant part moves into the base.
+constexpr uint32_t kMagicBits = 0x4a000000u;  // bits of 2^21
+constexpr float kMagicF = 0x1p21f;
+constexpr int kMagicMaxWords = (1 << 21) - 8;
+
+template <int BOX, bool U8, bool INTERIOR, bool FAST, bool MAGIC>
 __device__ __forceinline__ float view_cost_loop(const Problem *__restrict__ P, const ViewCam &vc,
                                                 const float *__restrict__ H, const float *__restrict__ tp0,
                                                 int tw, const float *__restrict__ lut, int px, int py,
@@ -446,25 +475,30 @@ __device__ __forceinline__ float view_cost_loop(const Problem *__restrict__ P, c
     const float tau_color = P->tau_color, tau_gradient = P->tau_gradient, gamma = P->gamma;
     const float centre = tp0[0];
     const int hr = win.hrad(), vr = win.vrad();
+    // MAGIC: offset of window (Xc, Yc), Xc in [-2, cols], Yc in [-2, rows] (clamped floor
+    // coordinates; entry (Yc+2)*pw + Xc+2 of V), as the bits of fma(Yc, pw, Xc + magic_c)
+    const float pwf = (float)P->pw;
+    const float magic_c = kMagicF + (float)(2 * P->pw + 2);
+    const gptr_bytes magic_base = (gptr_bytes)((uintptr_t)packed - (uintptr_t)kMagicBits);
+    const char *lut_magic = (const char *)lut - kMagicBits;
     float cost = 0.0f;
     // (float)(px + i) == (float)px + (float)i exactly (small integers): full-rate adds, no cvt
-    const float pyf = (float)py;
     float qx = (float)(px - hr);
     for (int i = -hr; i <= hr; i += 2, qx += 2.0f) {
         const float X0 = __builtin_fmaf(H[0], qx, H[2]);
         const float Y0 = __builtin_fmaf(H[3], qx, H[5]);
         const float Z0 = __builtin_fmaf(H[6], qx, H[8]);
+        float qy = (float)(py - vr);
 #pragma unroll unroll_j<BOX>()
-        for (int j = -vr; j <= vr; j += 2) {
+        for (int j = -vr; j <= vr; j += 2, qy += 2.0f) {
             // one ds_read_b128: {I(q), gx1(q), gy1(q)} of the reference tile
             const float4 t4 = *reinterpret_cast<const float4 *>(tp0 + 4 * (j * tw + i));
-            const float qy = pyf + (float)j;
             // weight_cu, gipuma.cu:186-193
             const float leftValue = t4.x;
             const float colorDis = __builtin_fabsf(leftValue - centre);
             float w;
-            if (U8)
-                w = lut[(int)colorDis];  // images are integer valued in [0,255]: 256 possible weights
+            if (U8)  // images are integer valued in [0,255]: 256 possible weights
+                w = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
             else
                 w = exp_model(-colorDis / gamma);
             // getCorrespondingPoint_cu, gipuma.cu:207-217
@@ -477,7 +511,14 @@ __device__ __forceinline__ float view_cost_loop(const Problem *__restrict__ P, c
             const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
             const float a = sx - fx0, b = sy - fy0;
             Taps tp5;
-            if (U8) {  // U8 mode: the whole window is one 16-byte load
+            if (U8 && MAGIC) {  // U8 mode: the whole window is one 16-byte load
+                // v_med3_f32 returns min3 when an input is NaN: NaN -> -2, like the saturating cvt
+                const float Xc = __builtin_amdgcn_fmed3f(fx0, -2.0f, colsf);
+                const float Yc = __builtin_amdgcn_fmed3f(fy0, -2.0f, rowsf);
+                const uint32_t off = __float_as_uint(__builtin_fmaf(Yc, pwf, Xc + magic_c));
+                const u32x4_a4 wv = *(gptr_u32x4)(magic_base + off);
+                tp5 = taps_u8(a, b, wv.x, wv.y, wv.z, wv.w);
+            } else if (U8) {
                 // X = clamp(floor(sx), -2, cols) + 2, same for Y: the +2 is exact wherever the
                 // clamp does not saturate
                 const uint32_t X = min(cvt_u32_sat(fx0 + 2.0f), xmax);
@@ -506,17 +547,108 @@ __device__ __forceinline__ float view_cost_loop(const Problem *__restrict__ P, c
             }
             const float sc = tp5.sc, gx2 = tp5.gx2, gy2 = tp5.gy2;
             // pmCostComputation_shared, gipuma.cu:251-274
-            const float colDiff = __builtin_fabsf(t4.w - sc);  // t4.w == t4.x == I(q)
+            const float colDiff = t4.w - sc;  // t4.w == t4.x == I(q); |.| taken in the min below
             const float gx1 = t4.y;
             const float gy1 = t4.z;
             const float gradX = gx1 - gx2;
             const float gradY = gy1 - gy2;
-            const float gradDis =
-                __builtin_fminf((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
-            const float colDis = __builtin_fminf(colDiff, tau_color);
+            const float gradDis = min_nc((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
+            const float colDis = min_abs_nc(colDiff, tau_color);
             const float dis = __builtin_fmaf(alpha, gradDis, oma * colDis);
             cost = __builtin_fmaf(w, dis, cost);
         }
+    }
+    return cost;
+}
+
+// The same loop for the shipped case (square compile-time box, gray U8 planes with float-encoded
+// offsets), software-pipelined by hand: the window of sample s+2 is requested before sample s is
+// reduced, across column boundaries, so that each wavefront keeps two 16-byte loads in flight
+// instead of waiting for the one it has just issued.  Per sample the arithmetic and the order of
+// the cost accumulation are those of view_cost_loop -- the results are bit-identical.  (The two
+// requests past the last sample fetch clamped, valid addresses and are dropped.)
+struct WinReq {
+    float a, b;
+    u32x4_a4 w;
+};
+template <int BOX, bool FAST>
+__device__ __forceinline__ float view_cost_pipe(const Problem *__restrict__ P, const ViewCam &vc,
+                                                const float *__restrict__ H, const float *__restrict__ tp0,
+                                                int tw, const float *__restrict__ lut, int px, int py)
+{
+    static_assert(BOX > 0, "compile-time window only");
+    constexpr int R = (BOX - 1) / 2, N = R + 1;  // offsets -R, -R+2, ..., R
+    const float colsf = (float)P->cols, rowsf = (float)P->rows;
+    const float alpha = P->alpha, oma = 1.f - P->alpha;
+    const float tau_color = P->tau_color, tau_gradient = P->tau_gradient;
+    const float centre = tp0[0];
+    const float pwf = (float)P->pw;
+    const float magic_c = kMagicF + (float)(2 * P->pw + 2);
+    const gptr_bytes magic_base = (gptr_bytes)((uintptr_t)vc.packed - (uintptr_t)kMagicBits);
+    const char *lut_magic = (const char *)lut - kMagicBits;
+    const float H1 = H[1], H4 = H[4], H7 = H[7];
+
+    auto request = [&](float X0, float Y0, float Z0, float qy) -> WinReq {
+        // getCorrespondingPoint_cu, gipuma.cu:207-217
+        const float X = __builtin_fmaf(H1, qy, X0);
+        const float Y = __builtin_fmaf(H4, qy, Y0);
+        const float Z = __builtin_fmaf(H7, qy, Z0);
+        const float rz = recip<FAST>(Z);
+        const float sx = X * rz, sy = Y * rz;
+        const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
+        WinReq r;
+        r.a = sx - fx0;
+        r.b = sy - fy0;
+        const float Xc = __builtin_amdgcn_fmed3f(fx0, -2.0f, colsf);
+        const float Yc = __builtin_amdgcn_fmed3f(fy0, -2.0f, rowsf);
+        const uint32_t off = __float_as_uint(__builtin_fmaf(Yc, pwf, Xc + magic_c));
+        r.w = *(gptr_u32x4)(magic_base + off);
+        return r;
+    };
+
+    const float qy0 = (float)(py - R);
+    float qx = (float)(px - R);
+    float X0 = __builtin_fmaf(H[0], qx, H[2]);
+    float Y0 = __builtin_fmaf(H[3], qx, H[5]);
+    float Z0 = __builtin_fmaf(H[6], qx, H[8]);
+    WinReq r0 = request(X0, Y0, Z0, qy0), r1 = request(X0, Y0, Z0, qy0 + 2.0f);
+    float cost = 0.0f;
+    const float *tcol = tp0 + 4 * (-R * tw - R);  // texel (-R, -R) of the window
+    for (int c = 0; c < N; c++, tcol += 8) {
+        const float qxn = qx + 2.0f;
+        const float X0n = __builtin_fmaf(H[0], qxn, H[2]);
+        const float Y0n = __builtin_fmaf(H[3], qxn, H[5]);
+        const float Z0n = __builtin_fmaf(H[6], qxn, H[8]);
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const WinReq cur = r0;
+            r0 = r1;
+            // sample k+2 of this column, or the first two of the next one
+            if (k + 2 < N)
+                r1 = request(X0, Y0, Z0, qy0 + (float)(2 * (k + 2)));
+            else
+                r1 = request(X0n, Y0n, Z0n, qy0 + (float)(2 * (k + 2 - N)));
+            __builtin_amdgcn_sched_barrier(0);  // keep the request ahead of this sample's reduction
+            // one ds_read_b128: {I(q), gx1(q), gy1(q), I(q)} of the reference tile
+            const float4 t4 = *reinterpret_cast<const float4 *>(tcol + 8 * k * tw);
+            // weight_cu, gipuma.cu:186-193: 256 possible weights
+            const float colorDis = __builtin_fabsf(t4.x - centre);
+            const float w = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
+            const Taps tp5 = taps_u8(cur.a, cur.b, cur.w.x, cur.w.y, cur.w.z, cur.w.w);
+            // pmCostComputation_shared, gipuma.cu:251-274
+            const float colDiff = t4.w - tp5.sc;
+            const float gradX = t4.y - tp5.gx2;
+            const float gradY = t4.z - tp5.gy2;
+            const float gradDis = min_nc((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
+            const float colDis = min_abs_nc(colDiff, tau_color);
+            const float dis = __builtin_fmaf(alpha, gradDis, oma * colDis);
+            cost = __builtin_fmaf(w, dis, cost);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        qx = qxn;
+        X0 = X0n;
+        Y0 = Y0n;
+        Z0 = Z0n;
     }
     return cost;
 }
@@ -531,8 +663,20 @@ __device__ __forceinline__ float view_cost(const Problem *__restrict__ P, const 
     homography(P->rc.K_inv, vc, pl, H);
     const int hr = win.hrad(), vr = win.vrad();
     const bool safe = window_z_safe(H, (float)(px - hr), (float)(px + hr), (float)(py - vr), (float)(py + vr));
-    if (__all(safe)) return view_cost_loop<BOX, U8, INTERIOR, true>(P, vc, H, tp0, tw, lut, px, py, win);
-    return view_cost_loop<BOX, U8, INTERIOR, false>(P, vc, H, tp0, tw, lut, px, py, win);
+    if constexpr (U8) {
+        if (P->magic_addr) {
+            if constexpr (BOX > 0) {
+                if (__all(safe)) return view_cost_pipe<BOX, true>(P, vc, H, tp0, tw, lut, px, py);
+                return view_cost_pipe<BOX, false>(P, vc, H, tp0, tw, lut, px, py);
+            } else {
+                if (__all(safe))
+                    return view_cost_loop<BOX, U8, INTERIOR, true, true>(P, vc, H, tp0, tw, lut, px, py, win);
+                return view_cost_loop<BOX, U8, INTERIOR, false, true>(P, vc, H, tp0, tw, lut, px, py, win);
+            }
+        }
+    }
+    if (__all(safe)) return view_cost_loop<BOX, U8, INTERIOR, true, false>(P, vc, H, tp0, tw, lut, px, py, win);
+    return view_cost_loop<BOX, U8, INTERIOR, false, false>(P, vc, H, tp0, tw, lut, px, py, win);
 }
 
 // The same patch cost instantiated for T = float4 (-color_processing, gipuma.cu:1965-1968): every
@@ -721,7 +865,7 @@ __device__ __forceinline__ TileXY tile_of(int b, int gx, int gy, unsigned tune)
         o.x = t % gx;
         o.y = t / gx;
     } else {
-        const int bo = (int)(tune >> 8);         // experiment override of the band height
+        const int bo = (int)((tune >> 8) & 0xffffu);         // experiment override of the band height
         const int bh = bo ? min(bo, gy) : (gy + 7) >> 3;  // band height in tile rows
         const int band = t / (bh * gx);
         const int h = min(bh, gy - band * bh);   // the last band may be shorter
@@ -879,8 +1023,9 @@ __device__ __forceinline__ bool neighbour(int k, int px, int py, int rows, int c
     }
 }
 
+// (the packed-gray instantiations are held at 128 VGPRs = 4 wavefronts per SIMD)
 template <int BOX, bool U8, bool COMBINE_REG, bool INTERIOR, int CH>
-__global__ __launch_bounds__(kThreads) void sweep_kernel(const Problem *__restrict__ P,
+__global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kernel(const Problem *__restrict__ P,
                                                          float4 *__restrict__ norm4, float *__restrict__ cost,
                                                          int colour, uint32_t phase, unsigned stages,
                                                          unsigned tune)
@@ -946,27 +1091,92 @@ __global__ __launch_bounds__(kThreads) void sweep_kernel(const Problem *__restri
             }
         }
     }
-    // workgroup task list, owner-major (all surviving candidates of a pixel adjacent, pixels in lane
-    // order): a wavefront-level inclusive scan of the per-lane counts, wavefront totals exchanged
-    // through LDS.  Measured against slot-major order on config C: 9.97 vs 10.65 ms per sweep --
-    // a round then touches ~1/3 as many distinct pixels, i.e. fewer reference-tile rows and source
-    // cache lines.
-    const int cnt = __popc(needmask);
-    int incl = cnt;
+    // Workgroup task list.  Two orders, same set of tasks (the order cannot change a result: a task
+    // is a pure function of (pixel, plane) and its cost lands in bres[slot][owner]):
+    //  * source-major (default): tasks that evaluate the SAME plane -- the plane of other-colour
+    //    pixel q is a candidate of q+-1 and q+-5 in x and y -- are adjacent, so the lanes of a
+    //    wavefront that share a plane read source windows a few pixels apart, i.e. the same cache
+    //    lines, even while the planes themselves are still random.  A divergent window load costs
+    //    the vector L1 two clocks per distinct 128-byte line (scripts/ubench/l1_window_rate.hip);
+    //    the first half-sweeps are bound by exactly that.  Built as a counting sort keyed by q's
+    //    position in the tile extended by the 5-pixel propagation reach.
+    //  * owner-major (Tune::kOwnerMajorTasks): a pixel's surviving candidates adjacent, pixels in
+    //    lane order: a wavefront-level inclusive scan of the per-lane counts.
+    int n_tasks;
+    if (tune & Tune::kOwnerMajorTasks) {
+        const int cnt = __popc(needmask);
+        int incl = cnt;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int up = __shfl_up(incl, d);
-        if ((int)(threadIdx.x & 63) >= d) incl += up;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if ((int)(threadIdx.x & 63) >= d) incl += up;
+        }
+        if ((threadIdx.x & 63) == 63) wcnt[wave] = incl;
+        __syncthreads();
+        const int c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
+        int pos0 = incl - cnt + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
+        n_tasks = c0 + c1 + c2 + c3;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if ((needmask >> k) & 1u) btask[pos0++] = (unsigned short)(threadIdx.x | (k << 8));
+        __syncthreads();
+    } else {
+        constexpr int kReach = 5, kExtW = kTileW + 2 * kReach, kExtH = kSweepTileH + 2 * kReach;
+        constexpr int kCells = kExtW * kExtH, kPerLane = (kCells + kThreads - 1) / kThreads;
+        static_assert(kCells <= 8 * kThreads, "the histogram aliases bres");
+        int *hist = reinterpret_cast<int *>(bres);  // bres is not written before the first round
+        for (int c = threadIdx.x; c < kCells; c += kThreads) hist[c] = 0;
+        __syncthreads();
+        unsigned ranks = 0;  // 3 bits per slot: at most 8 tasks share a source pixel
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if ((needmask >> k) & 1u) {
+                const int dist = k < 4 ? 1 : 5;
+                const int qx = lx + ((k & 3) == 2 ? -dist : (k & 3) == 3 ? dist : 0) + kReach;
+                const int qy = ly + ((k & 3) == 0 ? -dist : (k & 3) == 1 ? dist : 0) + kReach;
+                ranks |= (unsigned)atomicAdd(&hist[qy * kExtW + qx], 1) << (3 * k);
+            }
+        }
+        __syncthreads();
+        // exclusive prefix sum of the histogram, kPerLane consecutive cells per lane
+        int loc[kPerLane];
+        int sum = 0;
+#pragma unroll
+        for (int e = 0; e < kPerLane; e++) {
+            const int c = threadIdx.x * kPerLane + e;
+            loc[e] = c < kCells ? hist[c] : 0;
+            sum += loc[e];
+        }
+        int incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if ((int)(threadIdx.x & 63) >= d) incl += up;
+        }
+        if ((threadIdx.x & 63) == 63) wcnt[wave] = incl;
+        __syncthreads();
+        const int c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
+        int run = incl - sum + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
+        n_tasks = c0 + c1 + c2 + c3;
+#pragma unroll
+        for (int e = 0; e < kPerLane; e++) {
+            const int c = threadIdx.x * kPerLane + e;
+            if (c < kCells) hist[c] = run;
+            run += loc[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if ((needmask >> k) & 1u) {
+                const int dist = k < 4 ? 1 : 5;
+                const int qx = lx + ((k & 3) == 2 ? -dist : (k & 3) == 3 ? dist : 0) + kReach;
+                const int qy = ly + ((k & 3) == 0 ? -dist : (k & 3) == 1 ? dist : 0) + kReach;
+                btask[hist[qy * kExtW + qx] + (int)((ranks >> (3 * k)) & 7u)] =
+                    (unsigned short)(threadIdx.x | (k << 8));
+            }
+        }
+        __syncthreads();  // also orders the last reads of `hist` before bres is written
     }
-    if ((threadIdx.x & 63) == 63) wcnt[wave] = incl;
-    __syncthreads();
-    const int c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
-    int pos0 = incl - cnt + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
-    const int n_tasks = c0 + c1 + c2 + c3;
-#pragma unroll
-    for (int k = 0; k < 8; k++)
-        if ((needmask >> k) & 1u) btask[pos0++] = (unsigned short)(threadIdx.x | (k << 8));
-    __syncthreads();
     const int prop_rounds = (n_tasks + kThreads - 1) / kThreads;
 
     // planeRefinement_cu + getRndDispAndUnitVector_cu, gipuma.cu:928-994, 890-927

@@ -74,11 +74,33 @@ def series(db, sub="sweep_kernel"):
         print("%3d %8.3f" % (i, d / 1e6))
 
 
+def pmcseries(db, sub="sweep_kernel"):
+    """per-dispatch counter values (launch order) next to the dispatch duration"""
+    cur = sqlite3.connect(db).cursor()
+    cols = [d[0] for d in cur.execute("select * from counters_collection limit 1").description]
+    key = "dispatch_id" if "dispatch_id" in cols else ("start" if "start" in cols else None)
+    if key is None:
+        sys.exit("counters_collection columns: %s" % cols)
+    rows = list(cur.execute("select %s, counter_name, sum(value) from counters_collection where kernel_name like ? "
+                            "group by %s, counter_name order by %s" % (key, key, key), ("%" + sub + "%",)))
+    durs = [d for (d,) in cur.execute("select duration from kernels where name like ? order by start", ("%" + sub + "%",))]
+    names = sorted({r[1] for r in rows})
+    table = {}
+    for k, n, v in rows:
+        table.setdefault(k, {})[n] = v
+    print("# idx duration_ms " + " ".join(names))
+    for i, k in enumerate(sorted(table)):
+        d = durs[i] / 1e6 if i < len(durs) else float("nan")
+        print("%3d %8.3f " % (i, d) + " ".join("%.4g" % table[k].get(n, float("nan")) for n in names))
+
+
 if __name__ == "__main__":
     if len(sys.argv) < 3:
         sys.exit(__doc__)
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "pmcseries":
+        pmcseries(sys.argv[2], *(sys.argv[3:4]))
     elif sys.argv[1] == "series":
         series(sys.argv[2], *(sys.argv[3:4]))
     else:

@@ -36,6 +36,20 @@ KERNEL(k_bfe, asm volatile("v_bfe_u32 %0, %4, 8, 8\n v_bfe_u32 %1, %4, 16, 8\n v
 KERNEL(k_divfmas, asm volatile("v_div_fixup_f32 %0, %0, %4, %5\n v_div_fixup_f32 %1, %1, %4, %5\n v_div_fixup_f32 %2, %2, %4, %5\n v_div_fixup_f32 %3, %3, %4, %5" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(a2));)
 KERNEL(k_mov, asm volatile("v_mov_b32 %0, %4\n v_mov_b32 %1, %4\n v_mov_b32 %2, %4\n v_mov_b32 %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
 KERNEL(k_fmamix, asm volatile("v_fma_f32 %0, %4, %5, %0\n v_add_u32 %2, %6, %2\n v_fma_f32 %1, %4, %5, %1\n v_add_u32 %3, %6, %3" : "+v"(a), "+v"(b), "+v"(u), "+v"(v) : "v"(e), "v"(a2), "v"(77));)
+KERNEL(k_fmamixh, asm volatile("v_fma_mix_f32 %0, %4, %5, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n v_fma_mix_f32 %1, %4, %5, %1 op_sel:[0,0,0] op_sel_hi:[0,1,0]\n v_fma_mix_f32 %2, %4, %5, %2 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n v_fma_mix_f32 %3, %4, %5, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(u));)
+KERNEL(k_fmamix3, asm volatile("v_fma_mix_f32 %0, %4, 1.0, -%5 op_sel:[1,0,0] op_sel_hi:[1,0,1]\n v_fma_mix_f32 %1, %4, 1.0, -%5 op_sel:[0,0,1] op_sel_hi:[1,0,1]\n v_fma_mix_f32 %2, %4, 1.0, -%5 op_sel:[1,0,1] op_sel_hi:[1,0,1]\n v_fma_mix_f32 %3, %4, 1.0, -%5 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(a), "=v"(b), "=v"(c), "=v"(d) : "v"(u), "v"(v));)
+KERNEL(k_med3, asm volatile("v_med3_f32 %0, %0, %4, %5\n v_med3_f32 %1, %1, %4, %5\n v_med3_f32 %2, %2, %4, %5\n v_med3_f32 %3, %3, %4, %5" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(a2));)
+KERNEL(k_min3, asm volatile("v_min3_f32 %0, %0, %4, %5\n v_min3_f32 %1, %1, %4, %5\n v_max3_f32 %2, %2, %4, %5\n v_max3_f32 %3, %3, %4, %5" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(a2));)
+KERNEL(k_perm, asm volatile("v_perm_b32 %0, %4, %0, %5\n v_perm_b32 %1, %4, %1, %5\n v_perm_b32 %2, %4, %2, %5\n v_perm_b32 %3, %4, %3, %5" : "+v"(u), "+v"(v), "+v"(w), "+v"(u2) : "v"(0x4b000000u), "s"(0x070c0c01u));)
+KERNEL(k_andor, asm volatile("v_and_or_b32 %0, %0, %4, %5\n v_and_or_b32 %1, %1, %4, %5\n v_and_or_b32 %2, %2, %4, %5\n v_and_or_b32 %3, %3, %4, %5" : "+v"(u), "+v"(v), "+v"(w), "+v"(u2) : "s"(0xffu), "v"(0x4b000000u));)
+KERNEL(k_and, asm volatile("v_and_b32 %0, %4, %0\n v_and_b32 %1, %4, %1\n v_and_b32 %2, %4, %2\n v_and_b32 %3, %4, %3" : "+v"(u), "+v"(v), "+v"(w), "+v"(u2) : "s"(0x3ffu));)
+KERNEL(k_lshladd, asm volatile("v_lshl_add_u32 %0, %0, 2, %4\n v_lshl_add_u32 %1, %1, 2, %4\n v_add_lshl_u32 %2, %2, %4, 2\n v_add_lshl_u32 %3, %3, %4, 2" : "+v"(u), "+v"(v), "+v"(w), "+v"(u2) : "v"(77));)
+KERNEL(k_cvtu32, asm volatile("v_cvt_u32_f32 %0, %4\n v_cvt_u32_f32 %1, %4\n v_cvt_u32_f32 %2, %4\n v_cvt_u32_f32 %3, %4" : "+v"(u), "+v"(v), "+v"(w), "+v"(u2) : "v"(a));)
+KERNEL(k_minu, asm volatile("v_min_u32 %0, %4, %0\n v_min_u32 %1, %4, %1\n v_min_u32 %2, %4, %2\n v_min_u32 %3, %4, %3" : "+v"(u), "+v"(v), "+v"(w), "+v"(u2) : "v"(77));)
+KERNEL(k_subabs, asm volatile("v_sub_f32_e64 %0, |%0|, %4\n v_sub_f32_e64 %1, |%1|, %4\n v_sub_f32_e64 %2, |%2|, %4\n v_sub_f32_e64 %3, |%3|, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
+KERNEL(k_fract, asm volatile("v_fract_f32 %0, %0\n v_fract_f32 %1, %1\n v_fract_f32 %2, %2\n v_fract_f32 %3, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));)
+KERNEL(k_lshr, asm volatile("v_lshrrev_b32 %0, 8, %0\n v_lshrrev_b32 %1, 8, %1\n v_lshlrev_b32 %2, 2, %2\n v_lshlrev_b32 %3, 2, %3" : "+v"(u), "+v"(v), "+v"(w), "+v"(u2));)
+KERNEL(k_cvtf16, asm volatile("v_cvt_f32_f16 %0, %4\n v_cvt_f32_f16 %1, %4\n v_cvt_f32_f16 %2, %4\n v_cvt_f32_f16 %3, %4" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(u));)
 
 template <typename K>
 void run(const char *name, K k, float *d, int waves_per_simd)
@@ -71,6 +85,11 @@ int main()
         run("sub_sdwa", k_sdwa, d, w); run("min/max", k_min, d, w); run("rcp", k_rcp, d, w);
         run("floor", k_floor, d, w); run("bfe", k_bfe, d, w); run("div_fixup", k_divfmas, d, w);
         run("mov", k_mov, d, w); run("fma+addu", k_fmamix, d, w);
+        run("fma_mix_h", k_fmamixh, d, w); run("fma_mix_sub", k_fmamix3, d, w); run("med3", k_med3, d, w);
+        run("min3/max3", k_min3, d, w); run("perm", k_perm, d, w); run("and_or", k_andor, d, w); run("and", k_and, d, w);
+        run("lshl_add", k_lshladd, d, w); run("cvt_u32_f32", k_cvtu32, d, w); run("min_u32", k_minu, d, w);
+        run("sub_abs_e64", k_subabs, d, w); run("fract", k_fract, d, w); run("lshr/lshl", k_lshr, d, w);
+        run("cvt_f32_f16", k_cvtf16, d, w);
     }
     return 0;
 }
