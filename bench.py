@@ -226,8 +226,11 @@ def main():
                 out["roofline_valu"] = {
                     "bound": "valu", "achieved": lane_ops / (ms_launch * 1e-3) / 1e12, "peak": peak / 1e12,
                     "unit": "T lane-instr/s", "frac": lane_ops / (ms_launch * 1e-3) / peak,
-                    "valu_instr_per_patch_sample": pj["SQ_INSTS_VALU"] * 64.0 / (samples_per_frame /
-                                                   (1 + iterations * (8 + r_ref)) * (8 + r_ref) / 2.0),
+                    # per NOMINAL patch sample (E*N*S of SURVEY 8, before the exact skipping) ...
+                    "valu_instr_per_nominal_patch_sample": pj["SQ_INSTS_VALU"] * 64.0 / (
+                        samples_per_frame / (1 + iterations * (8 + r_ref)) * (8 + r_ref) / 2.0),
+                    # ... and per patch sample actually evaluated (one window load each)
+                    "valu_instr_per_window_load": pj["SQ_INSTS_VALU"] / max(1.0, pj.get("SQ_INSTS_VMEM_RD", 0.0)),
                     "source": "profiles/pmc_latest.json (rocprofv3 --pmc SQ_INSTS_VALU, same command)"}
             except Exception:
                 pass
