@@ -10,6 +10,7 @@
 #include <ctime>
 #include <fstream>
 #include <iostream>
+#include <limits>
 #include <sstream>
 
 namespace gipuma_host {
@@ -207,7 +208,8 @@ static void put(float *dst, const double *src, int n)
     for (int k = 0; k < n; k++) dst[k] = (float)src[k];
 }
 
-void get_camera_parameters(const std::vector<double> &P_list, int n, float cam_scale, CameraSet &cs)
+void get_camera_parameters(const std::vector<double> &P_list, int n, float cam_scale, CameraSet &cs,
+                           bool transformP)
 {  // cameraGeometryUtils.h:174-353
     cs.cams.assign(n, gipuma_hip_camera());
     cs.P.assign(12 * n, 0.0);
@@ -231,6 +233,10 @@ void get_camera_parameters(const std::vector<double> &P_list, int n, float cam_s
         for (int c = 0; c < 3; c++) R0t[3 * r + c] = R[3 * c + r];
     mulv(R0t, &t[0], t0i);
     for (int k = 0; k < 3; k++) t0i[k] = -t0i[k];
+    if (!transformP) {  // transform = identity: cameras stay in the world frame (:270)
+        for (int k = 0; k < 9; k++) R0t[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        t0i[0] = t0i[1] = t0i[2] = 0.0;
+    }
     for (int i = 0; i < n; i++) {
         double Ki[9], Kinv[9], Rn[9], tn[3], Pn[12], Minv[9], Mm[9], Rinv[9];
         scaleK(&K[9 * i], Ki);
@@ -409,6 +415,41 @@ bool read_dmb(const std::string &path, std::vector<float> &data, int &rows, int 
 }
 
 // ------------------------------------------------------------------------------------------ runGipuma
+int write_ply_binary(const std::string &path, const float *depth, const float *normals3, const float *gray,
+                     int gray_stride, int rows, int cols, const gipuma_hip_camera &cam)
+{  // storePlyFileBinary, displayUtils.h:78-159 (the reference's OpenMP loop writes the vertices in
+   // whatever order its threads reach the critical section; here: its loop order, x outer, y inner)
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return -1;
+    fprintf(f, "ply\nformat binary_little_endian 1.0\nelement vertex %d\n", rows * cols);
+    fprintf(f, "property float x\nproperty float y\nproperty float z\n");
+    fprintf(f, "property float nx\nproperty float ny\nproperty float nz\n");
+    fprintf(f, "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n");
+    std::vector<unsigned char> buf((size_t)rows * cols * 27);
+    unsigned char *o = buf.data();
+    for (int x = 0; x < cols; x++)
+        for (int y = 0; y < rows; y++) {
+            const size_t k = (size_t)y * cols + x;
+            // get3Dpoint, cameraGeometryUtils.h:51-61: M_inv * (depth * (x, y, 1) - P.col(3))
+            const float d = depth[k];
+            const float v[3] = {d * (float)x - cam.P_col34[0], d * (float)y - cam.P_col34[1], d - cam.P_col34[2]};
+            float X[3];
+            for (int r = 0; r < 3; r++)
+                X[r] = cam.M_inv[3 * r] * v[0] + cam.M_inv[3 * r + 1] * v[1] + cam.M_inv[3 * r + 2] * v[2];
+            const float big = std::numeric_limits<float>::max();
+            if (!(X[0] < big && X[0] > -big) || !(X[1] < big && X[1] > -big) || !(X[2] < big && X[2] >= -big))
+                X[0] = X[1] = X[2] = 0.0f;
+            memcpy(o, X, 12);
+            memcpy(o + 12, normals3 + 3 * k, 12);
+            const float g = gray[(size_t)y * gray_stride * cols + (size_t)x * gray_stride];
+            o[24] = o[25] = o[26] = (unsigned char)g;  // the gray value three times (:141-143)
+            o += 27;
+        }
+    const size_t w = fwrite(buf.data(), 1, buf.size(), f);
+    fclose(f);
+    return w == buf.size() ? 0 : -1;
+}
+
 int run_gipuma(const InputFiles &in, const OutputFiles &out, AlgorithmParameters &ap, std::string *folder)
 {
     if (in.img_filenames.size() < 2) {
@@ -502,6 +543,20 @@ int run_gipuma(const InputFiles &in, const OutputFiles &out, AlgorithmParameters
     write_dmb(of + "/normals.dmb", nrm3.data(), rows, cols, 3);
     write_dmb(of + "/cost.dmb", cost.data(), rows, cols, 1);         // extra: the cost plane (cudacost.png in the reference)
     if (!out.disparity_filename.empty()) write_dmb(out.disparity_filename, disp.data(), rows, cols, 1);
+    {   // 3d_model0.ply: points through the NOT re-centred camera 0, main.cpp:1018-1025
+        CameraSet world;
+        get_camera_parameters(P, n, ap.cam_scale, world, false);
+        std::vector<float> gray;
+        const float *g = imgs[0].data();
+        int stride = 1;
+        if (ap.color_processing) {  // the reference passes img_grayscale[] (BT.601 of B, G, R)
+            gray.resize((size_t)rows * cols);
+            for (size_t k = 0; k < gray.size(); k++)
+                gray[k] = std::floor(0.114f * g[4 * k] + 0.587f * g[4 * k + 1] + 0.299f * g[4 * k + 2] + 0.5f);
+            g = gray.data();
+        }
+        write_ply_binary(of + "/3d_model0.ply", disp.data(), nrm3.data(), g, stride, rows, cols, world.cams[0]);
+    }
     if (folder) *folder = of;
     return 0;
 }
@@ -531,6 +586,20 @@ int gipuma_host_select_views(const double *P_list, int n, float cam_scale, int c
     for (size_t k = 0; k < s.size(); k++) subset[k] = s[k];
     *depth_min = ap.depthMin; *depth_max = ap.depthMax;
     return (int)s.size();
+}
+
+int gipuma_host_write_ply(const char *path, const float *depth, const float *normals3, const float *gray, int rows,
+                          int cols, const gipuma_hip_camera *cam)
+{
+    return gipuma_host::write_ply_binary(path, depth, normals3, gray, 1, rows, cols, *cam);
+}
+
+int gipuma_host_camera_parameters_world(const double *P_list, int n, float cam_scale, gipuma_hip_camera *out)
+{
+    gipuma_host::CameraSet cs;
+    gipuma_host::get_camera_parameters(std::vector<double>(P_list, P_list + 12 * n), n, cam_scale, cs, false);
+    for (int i = 0; i < n; i++) out[i] = cs.cams[i];
+    return 0;
 }
 
 int gipuma_host_write_dmb(const char *path, const float *data, int rows, int cols, int nb)

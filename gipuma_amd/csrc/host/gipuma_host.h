@@ -9,6 +9,7 @@
 //   depth range -> disparity range    main.cpp:898-906
 //   disp.dmb / normals.dmb            fileIoUtils.h:320-368, main.cpp:1001-1015
 //   result folder <out>/<timestamp>_<refname>/   main.cpp:717-723
+//   3d_model0.ply                     displayUtils.h:78-159, main.cpp:1018-1025
 //
 // Images are read as binary PGM/PPM (8 bit) instead of through OpenCV's imread; PPM is converted
 // with the BT.601 weights imread(IMREAD_GRAYSCALE) uses.  OpenCV's decomposeProjectionMatrix is
@@ -64,7 +65,9 @@ struct CameraSet {
     std::vector<double> C;                // 3 per view: centre of P
     float f = 0.0f;
 };
-void get_camera_parameters(const std::vector<double> &P_list, int n, float cam_scale, CameraSet &cs);
+// transformP = false keeps the cameras in the world frame (getCameraParameters(..., false), used for the PLY)
+void get_camera_parameters(const std::vector<double> &P_list, int n, float cam_scale, CameraSet &cs,
+                           bool transformP = true);
 // returns the selected subset; fills depthMin/depthMax when they are -1
 std::vector<int> select_views(const CameraSet &cs, int cols, int rows, AlgorithmParameters &ap);
 
@@ -73,6 +76,10 @@ bool read_pnm_gray(const std::string &path, std::vector<float> &img, int &rows, 
 bool read_pnm_colour(const std::string &path, std::vector<float> &img, int &rows, int &cols);
 int write_dmb(const std::string &path, const float *data, int rows, int cols, int nb);
 bool read_dmb(const std::string &path, std::vector<float> &data, int &rows, int &cols, int &nb);
+// 3d_model<i>.ply of storePlyFileBinary (displayUtils.h:78-159): per pixel the world point of its depth,
+// the normal and the gray value three times; x outer, y inner.  `cam` = the NOT re-centred camera.
+int write_ply_binary(const std::string &path, const float *depth, const float *normals3, const float *gray,
+                     int gray_stride, int rows, int cols, const gipuma_hip_camera &cam);
 
 // the whole of runGipuma (main.cpp:694-1199) minus visualisation: returns 0 and the folder written
 int run_gipuma(const InputFiles &in, const OutputFiles &out, AlgorithmParameters &ap, std::string *folder);
@@ -85,5 +92,8 @@ int gipuma_host_camera_parameters(const double *P_list, int n, float cam_scale, 
 int gipuma_host_select_views(const double *P_list, int n, float cam_scale, int cols, int rows, float min_angle,
                              float max_angle, unsigned max_views, float *depth_min, float *depth_max, int *subset);
 int gipuma_host_write_dmb(const char *path, const float *data, int rows, int cols, int nb);
+int gipuma_host_write_ply(const char *path, const float *depth, const float *normals3, const float *gray, int rows,
+                          int cols, const gipuma_hip_camera *cam);
+int gipuma_host_camera_parameters_world(const double *P_list, int n, float cam_scale, gipuma_hip_camera *out);
 int gipuma_host_main(int argc, char **argv);
 }

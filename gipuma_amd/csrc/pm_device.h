@@ -689,14 +689,12 @@ __device__ __forceinline__ float l1_3(float x, float y, float z)
     return (__builtin_fabsf(x) + __builtin_fabsf(y) + __builtin_fabsf(z)) * 0.3333333f;
 }
 
-template <int BOX, bool U8>
-__device__ __forceinline__ float view_cost_c4(const Problem *__restrict__ P, const ViewCam &vc,
-                                              const float *__restrict__ tp0, int tw,
-                                              const float *__restrict__ lut, int px, int py, float4 pl,
-                                              const Win<BOX> &win)
+template <int BOX, bool U8, bool FAST>
+__device__ __forceinline__ float view_cost_c4_loop(const Problem *__restrict__ P, const ViewCam &vc,
+                                                   const float *__restrict__ H, const float *__restrict__ tp0,
+                                                   int tw, const float *__restrict__ lut, int px, int py,
+                                                   const Win<BOX> &win)
 {
-    float H[9];
-    homography(P->rc.K_inv, vc, pl, H);
     const gptr_f32 img = (gptr_f32)vc.img;
     const uint32_t *__restrict__ packed = vc.packed;
     const uint32_t pw = (uint32_t)P->pw;
@@ -708,15 +706,14 @@ __device__ __forceinline__ float view_cost_c4(const Problem *__restrict__ P, con
     const float4 centre = *reinterpret_cast<const float4 *>(tp0);
     const int hr = win.hrad(), vr = win.vrad();
     float cost = 0.0f;
-    const float pyf = (float)py;
     float qx = (float)(px - hr);
     for (int i = -hr; i <= hr; i += 2, qx += 2.0f) {
         const float X0 = __builtin_fmaf(H[0], qx, H[2]);
         const float Y0 = __builtin_fmaf(H[3], qx, H[5]);
         const float Z0 = __builtin_fmaf(H[6], qx, H[8]);
-        for (int j = -vr; j <= vr; j += 2) {
+        float qy = (float)(py - vr);
+        for (int j = -vr; j <= vr; j += 2, qy += 2.0f) {
             const float *tp = tp0 + 4 * (j * tw + i);
-            const float qy = pyf + (float)j;
             const float4 lv = *reinterpret_cast<const float4 *>(tp);
             float w;
             if (U8) {
@@ -729,7 +726,7 @@ __device__ __forceinline__ float view_cost_c4(const Problem *__restrict__ P, con
             const float X = __builtin_fmaf(H[1], qy, X0);
             const float Y = __builtin_fmaf(H[4], qy, Y0);
             const float Z = __builtin_fmaf(H[7], qy, Z0);
-            const float rz = 1.0f / Z;
+            const float rz = recip<FAST>(Z);
             const float sx = X * rz, sy = Y * rz;
             const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
             const float a = sx - fx0, b = sy - fy0;
@@ -766,13 +763,27 @@ __device__ __forceinline__ float view_cost_c4(const Problem *__restrict__ P, con
                                   (right.z - left.z) - t[2].gx2);
             const float gY = l1_3((down.x - up.x) - t[0].gy2, (down.y - up.y) - t[1].gy2,
                                   (down.z - up.z) - t[2].gy2);
-            const float gradDis = __builtin_fminf((gX + gY) * 0.0625f, tau_gradient);
-            const float colDis = __builtin_fminf(colDiff, tau_color);
+            const float gradDis = min_nc((gX + gY) * 0.0625f, tau_gradient);
+            const float colDis = min_nc(colDiff, tau_color);
             const float dis = __builtin_fmaf(alpha, gradDis, oma * colDis);
             cost = __builtin_fmaf(w, dis, cost);
         }
     }
     return cost;
+}
+
+template <int BOX, bool U8>
+__device__ __forceinline__ float view_cost_c4(const Problem *__restrict__ P, const ViewCam &vc,
+                                              const float *__restrict__ tp0, int tw,
+                                              const float *__restrict__ lut, int px, int py, float4 pl,
+                                              const Win<BOX> &win)
+{
+    float H[9];
+    homography(P->rc.K_inv, vc, pl, H);
+    const int hr = win.hrad(), vr = win.vrad();
+    const bool safe = window_z_safe(H, (float)(px - hr), (float)(px + hr), (float)(py - vr), (float)(py + vr));
+    if (__all(safe)) return view_cost_c4_loop<BOX, U8, true>(P, vc, H, tp0, tw, lut, px, py, win);
+    return view_cost_c4_loop<BOX, U8, false>(P, vc, H, tp0, tw, lut, px, py, win);
 }
 
 // pmCostMultiview_cu, gipuma.cu:720-806.  COMBINE_REG: best-N with n_best <= 4 keeps the four

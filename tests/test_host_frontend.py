@@ -24,6 +24,10 @@ def host_lib():
                                            C.c_float, C.c_float, C.c_uint, C.POINTER(C.c_float),
                                            C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.gipuma_host_write_dmb.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int]
+    L.gipuma_host_write_ply.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                        C.c_int, C.c_int, C.POINTER(abi.Camera)]
+    L.gipuma_host_camera_parameters_world.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_float,
+                                                      C.POINTER(abi.Camera)]
     return L
 
 
@@ -88,6 +92,46 @@ def test_dmb_layout(tmp_path):
     dmb.write_dmb(p2, a[..., 0])
     assert open(p2, "rb").read()[:16] == np.array([1, 2, 3, 1], dtype=np.int32).tobytes()
     assert np.array_equal(dmb.read_dmb(p2), a[..., 0])
+
+
+def test_ply_layout_and_points(tmp_path):
+    """3d_model0.ply (storePlyFileBinary, displayUtils.h:78-159): header, 27-byte vertices in x-outer
+    order, world points through the NOT re-centred camera; C++ writer == Python writer, and the points
+    re-project onto their pixels at their depth."""
+    allP = synth.dtu_projection_matrices()
+    ids = [14, 15, 16]
+    flat = np.ascontiguousarray(np.stack([allP[k] for k in ids]).reshape(-1), dtype=np.float64)
+    cams = (abi.Camera * 3)()
+    assert host_lib().gipuma_host_camera_parameters_world(flat.ctypes.data_as(C.POINTER(C.c_double)), 3,
+                                                          1.0, cams) == 0
+    rows, cols = 5, 7
+    rng = np.random.default_rng(3)
+    depth = rng.uniform(500, 700, (rows, cols)).astype(np.float32)
+    depth[2, 3] = np.inf                                   # non-finite point -> (0, 0, 0)
+    normals = rng.normal(size=(rows, cols, 3)).astype(np.float32)
+    gray = rng.integers(0, 256, (rows, cols)).astype(np.float32)
+    p_cpp, p_py = str(tmp_path / "a.ply"), str(tmp_path / "b.ply")
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    assert host_lib().gipuma_host_write_ply(p_cpp.encode(), fp(depth), fp(normals), fp(gray), rows, cols,
+                                            C.byref(cams[0])) == 0
+    dmb.write_ply_binary(p_py, depth, normals, gray, list(cams[0].M_inv), list(cams[0].P_col34))
+    raw = open(p_cpp, "rb").read()
+    assert raw.startswith(b"ply\nformat binary_little_endian 1.0\nelement vertex 35\n")
+    assert len(raw) == raw.index(b"end_header\n") + 11 + 35 * 27
+    a, b = dmb.read_ply_binary(p_cpp), dmb.read_ply_binary(p_py)
+    for name in ("nx", "ny", "nz", "red", "green", "blue"):
+        assert np.array_equal(a[name], b[name])
+    for name in ("x", "y", "z"):
+        assert np.allclose(a[name], b[name], rtol=1e-5, atol=1e-3)
+    v = a.reshape(cols, rows)                              # x outer, y inner
+    assert v["red"][3, 2] == np.uint8(gray[2, 3]) and v["nx"][6, 4] == normals[4, 6, 0]
+    assert (v["x"][3, 2], v["y"][3, 2], v["z"][3, 2]) == (0.0, 0.0, 0.0)
+    # world point of pixel (x=5, y=1) projects back to (5, 1) with w = depth (float64 check)
+    P = allP[14]
+    X = np.array([v["x"][5, 1], v["y"][5, 1], v["z"][5, 1], 1.0], dtype=np.float64)
+    # the front-end re-composes P as K0 [R|t]; same camera up to scale: compare pixel coordinates
+    q = P @ X
+    assert abs(q[0] / q[2] - 5.0) < 0.05 and abs(q[1] / q[2] - 1.0) < 0.05
 
 
 def write_scene(tmp, gs, view_ids):
@@ -172,3 +216,14 @@ def test_cli_end_to_end_dmb_matches_oracle(hip, tmp_path, colour):
     assert np.array_equal(disp.view(np.uint32), n4[..., 3].view(np.uint32))
     assert np.array_equal(normals.view(np.uint32), np.ascontiguousarray(n4[..., :3]).view(np.uint32))
     assert np.array_equal(cost.view(np.uint32), c.view(np.uint32))
+    # 3d_model0.ply (main.cpp:1018-1025): one vertex per pixel, normals = normals.dmb, depth-consistent points
+    ply = dmb.read_ply_binary(str(folder / "3d_model0.ply")).reshape(cfg["cols"], cfg["rows"])
+    assert np.array_equal(ply["nx"].T.view(np.uint32), np.ascontiguousarray(normals[..., 0]).view(np.uint32))
+    Pw = P_txt[0].copy()
+    Pw[:2] /= float(np.float32(cfg["cam_scale"]))          # image scaled by 1/cam_scale (scaleK)
+    X = np.stack([ply["x"].T, ply["y"].T, ply["z"].T, np.ones_like(ply["x"].T)], axis=-1).astype(np.float64)
+    q = X @ Pw.T
+    yy, xx = np.mgrid[0:cfg["rows"], 0:cfg["cols"]]
+    ok = disp > 0
+    assert ok.mean() > 0.9
+    assert np.abs(q[..., 0] / q[..., 2] - xx)[ok].max() < 0.05 and np.abs(q[..., 1] / q[..., 2] - yy)[ok].max() < 0.05
