@@ -211,6 +211,51 @@ def test_device_resident_images_with_pitch(hip):
     assert_same(c, o_c, "device images cost")
 
 
+@pytest.mark.parametrize("tune", [1 << 30, 1 << 29, 1 << 28, (1 << 30) | (1 << 28)])
+def test_kernel_variants_are_bit_identical(hip, tune):
+    """the performance-only choices of the sweep kernel -- float-encoded window offsets + the
+    hand-pipelined loop (off: bit 30), task order owner-major (bit 29) / source-major (bit 28) in
+    every iteration instead of switching after iteration 1 -- must not change a single bit.  Box 15
+    (the pipelined instantiation), 4 iterations so that the default run uses both task orders."""
+    gs, _ = synth.build_problem(synth.tiny_config(cols=160, rows=112, n_src=4, blocksize=15, iterations=4,
+                                                  n_best=3))
+    a = runcuda(gs)
+    os.environ["GIPUMA_HIP_TUNE"] = str(tune)
+    try:
+        b = runcuda(gs)
+    finally:
+        del os.environ["GIPUMA_HIP_TUNE"]
+    assert_same(a[0], b[0], "variant %d norm4" % tune)
+    assert_same(a[1], b[1], "variant %d cost" % tune)
+    if tune == 1 << 30:
+        o = OracleState(gs).run()
+        assert_same(a[0], o[0], "default vs oracle norm4")
+        assert_same(a[1], o[1], "default vs oracle cost")
+
+
+def test_packed_plane_beyond_the_float_offset_range(hip):
+    """a packed plane of more than 2^21 entries cannot use float-encoded offsets: the session must
+    fall back to integer addressing by itself.  1800x1200 is too large for the oracle to run whole,
+    so: stored cost == fresh evaluation, and spot checks against the oracle's single-pixel cost,
+    biased towards the far corner where the offsets are largest."""
+    gs, _ = synth.build_problem("C", cols=1800, rows=1200, n_src=3, iterations=1, n_best=2)
+    assert (gs.rows + 3) * (gs.cols + 8) > (1 << 21)
+    with Session(gs) as s:
+        s.init_planes()
+        s.sweep(0, abi.BLACK)
+        s.sweep(0, abi.RED)
+        n4, c = s.get_state()
+        assert_same(c, s.eval_cost(n4), "stored cost == cost of stored plane")
+    from tests.oracle_lib import lib, fptr
+    rng = np.random.default_rng(1)
+    pts = [(gs.cols - 1 - int(rng.integers(0, 40)), gs.rows - 1 - int(rng.integers(0, 40))) for _ in range(24)]
+    pts += [(int(rng.integers(0, gs.cols)), int(rng.integers(0, gs.rows))) for _ in range(24)]
+    for x, y in pts:
+        pl = np.ascontiguousarray(n4[y, x])
+        want = lib().gipuma_oracle_multiview_cost(C.byref(gs.desc), x, y, fptr(pl))
+        assert np.float32(want).view(np.uint32) == c[y, x].view(np.uint32), (x, y, want, c[y, x])
+
+
 def test_config_a_full_size(hip):
     """BASELINE.json configs[0]: 320x240, 2 source views, 4 iterations -- the CPU-runnable case"""
     gs, info = synth.build_problem("A")
