@@ -61,6 +61,7 @@ struct gipuma_hip_session {
     int box = 0;             // specialised window size, 0 = runtime
     int ch = 1;              // 1 = gray (T=float), 4 = colour (T=float4)
     unsigned tune = 0;
+    int cols_launches = 3;   // leading half-sweeps (2*iteration + colour) evaluated column-per-lane
     size_t lds_sweep = 0, lds_dense = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
@@ -167,6 +168,15 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
     // task order (performance only): planes are still incoherent in the first two iterations, where
     // grouping the evaluations of one plane saves cache-line fills; afterwards owner order is faster
     if (iteration >= 2 && !(tune & Tune::kSourceMajorTasks)) tune |= Tune::kOwnerMajorTasks;
+    // ... and in those iterations the evaluations themselves are done column-per-lane (8 lanes per
+    // (pixel, plane) pair, pm::sweep_cols_kernel) when the problem has that instantiation
+    // (box 15 only: its 8 window columns fill the 8 lanes of a group; box 11, 6 of 8 lanes, measured
+    // slower than one lane per pixel on config B: 18.0 vs 19.8 Mpix/s)
+    const bool cols_ok = s->u8 && s->ch == 1 && s->hp.magic_addr && s->box == 15 &&
+                         !(tune & (Tune::kNoColsKernel | Tune::kNoInterior));
+    if (cols_ok && (2 * iteration + colour < s->cols_launches || (tune & Tune::kColsAlways))) {
+        k = s->combine_reg ? pm::sweep_cols_kernel<15, true> : pm::sweep_cols_kernel<15, false>;
+    }
     hipLaunchKernelGGL(k, dim3(gx * gy), dim3(pm::kThreads), s->lds_sweep, s->stream, s->dp, s->norm4,
                        s->cost, colour, phase, stages, tune);
     HIP_OK(hipGetLastError());
@@ -250,6 +260,7 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     s->iterations = d->params.iterations;
     s->unfused = (d->flags & GIPUMA_HIP_FLAG_UNFUSED) != 0;
     if (const char *t = getenv("GIPUMA_HIP_TUNE")) s->tune = (unsigned)strtoul(t, nullptr, 0);
+    if (const char *t = getenv("GIPUMA_HIP_COLS_LAUNCHES")) s->cols_launches = atoi(t);  // experiment
     if (d->stream) {
         s->stream = (hipStream_t)d->stream;
     } else {

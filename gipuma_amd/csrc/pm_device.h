@@ -246,7 +246,9 @@ struct Tune {  // experiment switches (GIPUMA_HIP_TUNE), all default off
                               kUntrustedCosts = 128,  // set by the host after gipuma_hip_set_state
                               kNoMagicAddr = 1u << 30,  // integer window addressing (bits 8..23: band height)
                               kOwnerMajorTasks = 1u << 29,   // always owner-major task lists
-                              kSourceMajorTasks = 1u << 28;  // always source-major (default: by iteration)
+                              kSourceMajorTasks = 1u << 28,  // always source-major (default: by iteration)
+                              kNoColsKernel = 1u << 27,      // never the column-per-lane kernel
+                              kColsAlways = 1u << 26;        // ... or in every iteration (default: 0 and 1)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -849,6 +851,173 @@ __device__ __forceinline__ float multiview_cost(const Problem *__restrict__ P, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// Column-per-lane evaluation, used for the first iterations (planes still random).
+//
+// With one lane per pixel, the 64 lanes of a window load sit in 64 different cache lines as long as
+// neighbouring pixels hold unrelated planes, and the vector L1 needs two clocks per distinct
+// 128-byte line (scripts/ubench/l1_window_rate.hip): launches 0-3 run at 2.2x their VALU bound.
+// Here 8 consecutive lanes evaluate ONE (pixel, plane) pair, lane c taking window column c: at
+// each of the N row steps the 8 lanes sample the same plane at points 2 pixels apart, i.e. windows
+// that share one to three lines, and a wavefront (8 pairs) touches ~20 lines per load instead of
+// ~64.  Every sample is computed by the same instruction sequence as in view_cost_pipe.  The
+// reference's summation order (columns outer, rows inner, one fmaf per sample into a single
+// accumulator, gipuma.cu:633-676) is kept by a relay: each lane stores the N (w, dis) pairs of its
+// column; in relay step c every lane re-runs its N fmafs starting from the value its left
+// neighbour produced in step c-1, so after step c lane c holds the exact prefix over columns 0..c
+// (the other lanes' values are never used).  N*(N+1) extra instructions per N samples per lane --
+// irrelevant where the launch is bound by line fills.
+// ---------------------------------------------------------------------------------------------
+constexpr int kColGroup = 8;                        // lanes per (pixel, plane) pair
+constexpr int kColTasks = kThreads / kColGroup;     // pairs evaluated concurrently by a workgroup
+
+template <int BOX, bool FAST>
+__device__ __forceinline__ float view_cost_cols(const Problem *__restrict__ P, const ViewCam &vc,
+                                                const float *__restrict__ H, const float *__restrict__ tp0,
+                                                int tw, const float *__restrict__ lut, int px, int py, int col)
+{
+    constexpr int R = (BOX - 1) / 2, N = R + 1;
+    static_assert(BOX > 0 && N <= kColGroup, "one lane per window column");
+    const float colsf = (float)P->cols, rowsf = (float)P->rows;
+    const float alpha = P->alpha, oma = 1.f - P->alpha;
+    const float tau_color = P->tau_color, tau_gradient = P->tau_gradient;
+    const float centre = tp0[0];
+    const float pwf = (float)P->pw;
+    const float magic_c = kMagicF + (float)(2 * P->pw + 2);
+    const gptr_bytes magic_base = (gptr_bytes)((uintptr_t)vc.packed - (uintptr_t)kMagicBits);
+    const char *lut_magic = (const char *)lut - kMagicBits;
+    const float H1 = H[1], H4 = H[4], H7 = H[7];
+    const int mycol = col < N ? col : N - 1;  // spare lanes of a smaller box shadow the last column
+    const float qx = (float)(px - R + 2 * mycol);
+    const float X0 = __builtin_fmaf(H[0], qx, H[2]);
+    const float Y0 = __builtin_fmaf(H[3], qx, H[5]);
+    const float Z0 = __builtin_fmaf(H[6], qx, H[8]);
+
+    auto request = [&](float qy) -> WinReq {
+        const float X = __builtin_fmaf(H1, qy, X0);
+        const float Y = __builtin_fmaf(H4, qy, Y0);
+        const float Z = __builtin_fmaf(H7, qy, Z0);
+        const float rz = recip<FAST>(Z);
+        const float sx = X * rz, sy = Y * rz;
+        const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
+        WinReq r;
+        r.a = sx - fx0;
+        r.b = sy - fy0;
+        const float Xc = __builtin_amdgcn_fmed3f(fx0, -2.0f, colsf);
+        const float Yc = __builtin_amdgcn_fmed3f(fy0, -2.0f, rowsf);
+        const uint32_t off = __float_as_uint(__builtin_fmaf(Yc, pwf, Xc + magic_c));
+        r.w = *(gptr_u32x4)(magic_base + off);
+        return r;
+    };
+
+    const float qy0 = (float)(py - R);
+    const float *tcol = tp0 + 4 * (-R * tw - R + 2 * mycol);  // texel (column, -R) of the window
+    float wgt[N], dis[N];
+    WinReq r0 = request(qy0), r1 = request(qy0 + 2.0f);
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const WinReq cur = r0;
+        r0 = r1;
+        if (k + 2 < N) r1 = request(qy0 + (float)(2 * (k + 2)));
+        const float4 t4 = *reinterpret_cast<const float4 *>(tcol + 8 * k * tw);
+        const float colorDis = __builtin_fabsf(t4.x - centre);
+        wgt[k] = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
+        const Taps tp5 = taps_u8(cur.a, cur.b, cur.w.x, cur.w.y, cur.w.z, cur.w.w);
+        const float colDiff = t4.w - tp5.sc;
+        const float gradX = t4.y - tp5.gx2;
+        const float gradY = t4.z - tp5.gy2;
+        const float gradDis = min_nc((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
+        const float colDis = min_abs_nc(colDiff, tau_color);
+        dis[k] = __builtin_fmaf(alpha, gradDis, oma * colDis);
+    }
+    // relay: after step c, lane c of the group holds the sum over columns 0..c in reference order
+    float out = 0.0f;
+#pragma unroll
+    for (int c = 0; c < N; c++) {
+        // lane i takes lane i-1's value: DPP row_shr:1 (groups of 8 never straddle a row of 16)
+        float acc = c == 0 ? 0.0f
+                           : __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(out), 0x111, 0xf, 0xf, false));
+#pragma unroll
+        for (int k = 0; k < N; k++) acc = __builtin_fmaf(wgt[k], dis[k], acc);
+        out = acc;
+    }
+    return out;  // exact in lane N-1 of the group
+}
+
+// pmCostMultiview_cu for one (pixel, plane) pair evaluated by a group of kColGroup lanes; the
+// result is exact in every lane of the group (same combination code as multiview_cost)
+template <int BOX, bool COMBINE_REG>
+__device__ __forceinline__ float multiview_cost_cols(const Problem *__restrict__ P, const float *__restrict__ tp0,
+                                                     int tw, const float *__restrict__ lut, float *cv, int px,
+                                                     int py, float4 pl, int col)
+{
+    constexpr int R = (BOX - 1) / 2, N = R + 1;
+    const int n = P->n_sel;
+    int numValid = 0;
+    float b0 = kMaxCost, b1 = kMaxCost, b2 = kMaxCost, b3 = kMaxCost;
+    const int grp_lane0 = (int)(threadIdx.x & 63u & ~(unsigned)(kColGroup - 1));
+    const int src_lane = grp_lane0 + (N - 1);
+    // the homography of a (plane, view) pair is the same for the 8 lanes of a group: lane c computes
+    // it for view vb + c (the literal arithmetic of homography()), the lanes then pass them round
+    for (int vb = 0; vb < n; vb += kColGroup) {
+        float Hl[9];
+        homography(P->rc.K_inv, P->view[min(vb + col, n - 1)], pl, Hl);
+        const int vend = min(vb + kColGroup, n);
+        for (int v = vb; v < vend; v++) {
+            float H[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) H[k] = __shfl(Hl[k], grp_lane0 + (v - vb));
+            const bool safe = window_z_safe(H, (float)(px - R), (float)(px + R), (float)(py - R), (float)(py + R));
+            float c;
+            if (__all(safe))
+                c = view_cost_cols<BOX, true>(P, P->view[v], H, tp0, tw, lut, px, py, col);
+            else
+                c = view_cost_cols<BOX, false>(P, P->view[v], H, tp0, tw, lut, px, py, col);
+            c = __shfl(c, src_lane);  // the group's exact value
+            if (c < kMaxCost)
+                numValid++;
+            else
+                c = kMaxCost;
+            if (COMBINE_REG) {
+                float t = c, lo;
+                lo = __builtin_fminf(b0, t); t = __builtin_fmaxf(b0, t); b0 = lo;
+                lo = __builtin_fminf(b1, t); t = __builtin_fmaxf(b1, t); b1 = lo;
+                lo = __builtin_fminf(b2, t); t = __builtin_fmaxf(b2, t); b2 = lo;
+                b3 = __builtin_fminf(b3, t);
+            } else {
+                int j = v;
+                for (; j >= 1 && c < cv[(j - 1) * kThreads]; j--) cv[j * kThreads] = cv[(j - 1) * kThreads];
+                cv[j * kThreads] = c;
+            }
+        }
+    }
+    float cost = 0.0f;
+    int numConsidered = 0;
+    if (COMBINE_REG) {
+        const int numBest = min(numValid, P->n_best);
+        if (numBest > 0) cost = cost + b0;
+        if (numBest > 1) cost = cost + b1;
+        if (numBest > 2) cost = cost + b2;
+        if (numBest > 3) cost = cost + b3;
+        numConsidered = numBest;
+    } else {
+        int numBest = numValid;
+        if (P->cost_comb == 1) numBest = min(numBest, P->n_best);  // COMB_BEST_N
+        if (P->cost_comb == 3) numBest = n;                        // COMB_GOOD
+        const float costThresh = (n > 0 ? cv[0] : 0.0f) * P->good_factor;
+        for (int i = 0; i < numBest; i++) {
+            numConsidered++;
+            float c = cv[i * kThreads];
+            if (P->cost_comb == 3) c = __builtin_fminf(c, costThresh);
+            cost = cost + c;
+        }
+    }
+    cost = cost / ((float)numConsidered);
+    if (numConsidered < 1) cost = kMaxCost;
+    if (cost != cost || cost > kMaxCost || cost < 0) cost = kMaxCost;
+    return cost;
+}
+
+// ---------------------------------------------------------------------------------------------
 // workgroup helpers
 // ---------------------------------------------------------------------------------------------
 // Workgroup id -> tile coordinates.
@@ -1278,6 +1447,274 @@ __global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kerne
             if (r < prop_rounds) {
                 bres[slot * kThreads + owner] = c;
             } else if (c < cst) {  // refinement has no depth-range test, :986
+                depth = d_new;
+                pl = cand;
+                cst = c;
+            }
+        }
+    }
+
+    // write back (gipuma.cu:1585-1587): 16 B + 4 B per active pixel
+    if (active) {
+        cost[center] = cst;
+        norm4[center] = pl;
+    }
+}
+
+// The same half-sweep with the column-per-lane evaluation (see view_cost_cols): state, candidate
+// selection, task list, accept replay and refinement candidates are computed per pixel by its owner
+// lane exactly as in sweep_kernel; only the cost evaluations are done by groups of kColGroup lanes,
+// kColTasks (pixel, plane) pairs at a time, exchanging planes and costs through LDS.  Gray packed
+// planes with float-encoded offsets and a compile-time box of at most 15 only (the host uses it for
+// box 15, whose 8 columns fill a group).
+template <int BOX, bool COMBINE_REG>
+__global__ __launch_bounds__(kThreads) void sweep_cols_kernel(const Problem *__restrict__ P,
+                                                         float4 *__restrict__ norm4, float *__restrict__ cost,
+                                                         int colour, uint32_t phase, unsigned stages,
+                                                         unsigned tune)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const Win<BOX> win(P);
+    const RefCam &rc = P->rc;
+    const int rows = P->rows, cols = P->cols;
+    const int gx = (cols + kTileW - 1) / kTileW;
+    const int gy = (rows + kSweepTileH - 1) / kSweepTileH;
+    const TileXY txy = tile_of(blockIdx.x, gx, gy, tune);
+    const int x0 = txy.x * kTileW, y0 = txy.y * kSweepTileH;
+    constexpr int CH = 1;
+    stage_tile<BOX, CH>(P, lds, x0, y0, kSweepTileH, win, true);
+    const int hw = win.halo_w(), hh = win.halo_h();
+    const int tw = kTileW + 2 * hw, th = kSweepTileH + 2 * hh;
+    const float *tile = lds + lut_size<CH>();
+    float *work = lds + lut_size<CH>() + 4 * tw * th;
+    float *cv = work + work_floats<CH>(tw * th, true) + threadIdx.x;
+    // (gray: the staging plane inside `work` is dead after stage_tile's last barrier)
+    const int wave = threadIdx.x >> 6;
+    float *bres = work;                                                           // [8][256] costs
+    unsigned short *btask = reinterpret_cast<unsigned short *>(work + 8 * kThreads);  // [2048] tid | slot << 8
+    int *wcnt = reinterpret_cast<int *>(work + 8 * kThreads + (8 * kThreads) / 2);  // [4 waves][8 slots]
+
+    // lane -> pixel: 16 pixels of the colour per tile row; a wavefront covers 4 rows x 32 columns
+    const int ly = threadIdx.x >> 4;
+    const int lx = 2 * (threadIdx.x & 15) + ((ly + colour) & 1);  // tile origin is even in x and y
+    const int px = x0 + lx, py = y0 + ly;
+    const bool active = px < cols && py < rows;
+    const int center = py * cols + px;
+    const bool trust = !(tune & Tune::kUntrustedCosts);
+
+    // read state (gipuma.cu:1527-1530)
+    float4 pl = make_float4(0.f, 0.f, 0.f, 0.f);
+    float cst = 0.f, depth = 0.f;
+    unsigned needmask = 0;  // candidate slots of this pixel that must be evaluated
+    if (active) {
+        pl = norm4[center];
+        cst = cost[center];
+        depth = depth_from_plane(rc, pl, px, py);
+        float4 cands[8];
+        unsigned valid = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            int nb;
+            const bool ok = neighbour(k, px, py, rows, cols, center, nb) && (stages & (k < 4 ? 1u : 2u));
+            if (ok) {
+                cands[k] = norm4[nb];
+                valid |= 1u << k;
+            }
+        }
+        if (tune & Tune::kNoSkip) {
+            needmask = valid;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                bool fresh = (valid >> k) & 1u;
+                if (fresh && trust && same_bits(cands[k], pl)) fresh = false;  // (A)
+#pragma unroll
+                for (int j = 0; j < k; j++)
+                    if (fresh && ((valid >> j) & 1u) && same_bits(cands[k], cands[j])) fresh = false;  // (D)
+                if (fresh) needmask |= 1u << k;
+            }
+        }
+    }
+    // Workgroup task list.  Two orders, same set of tasks (the order cannot change a result: a task
+    // is a pure function of (pixel, plane) and its cost lands in bres[slot][owner]):
+    //  * source-major (default): tasks that evaluate the SAME plane -- the plane of other-colour
+    //    pixel q is a candidate of q+-1 and q+-5 in x and y -- are adjacent, so the lanes of a
+    //    wavefront that share a plane read source windows a few pixels apart, i.e. the same cache
+    //    lines, even while the planes themselves are still random.  A divergent window load costs
+    //    the vector L1 two clocks per distinct 128-byte line (scripts/ubench/l1_window_rate.hip);
+    //    the first half-sweeps are bound by exactly that.  Built as a counting sort keyed by q's
+    //    position in the tile extended by the 5-pixel propagation reach.
+    //  * owner-major (Tune::kOwnerMajorTasks): a pixel's surviving candidates adjacent, pixels in
+    //    lane order: a wavefront-level inclusive scan of the per-lane counts.
+    int n_tasks;
+    if (tune & Tune::kOwnerMajorTasks) {
+        const int cnt = __popc(needmask);
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if ((int)(threadIdx.x & 63) >= d) incl += up;
+        }
+        if ((threadIdx.x & 63) == 63) wcnt[wave] = incl;
+        __syncthreads();
+        const int c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
+        int pos0 = incl - cnt + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
+        n_tasks = c0 + c1 + c2 + c3;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if ((needmask >> k) & 1u) btask[pos0++] = (unsigned short)(threadIdx.x | (k << 8));
+        __syncthreads();
+    } else {
+        constexpr int kReach = 5, kExtW = kTileW + 2 * kReach, kExtH = kSweepTileH + 2 * kReach;
+        constexpr int kCells = kExtW * kExtH, kPerLane = (kCells + kThreads - 1) / kThreads;
+        static_assert(kCells <= 8 * kThreads, "the histogram aliases bres");
+        int *hist = reinterpret_cast<int *>(bres);  // bres is not written before the first round
+        for (int c = threadIdx.x; c < kCells; c += kThreads) hist[c] = 0;
+        __syncthreads();
+        unsigned ranks = 0;  // 3 bits per slot: at most 8 tasks share a source pixel
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if ((needmask >> k) & 1u) {
+                const int dist = k < 4 ? 1 : 5;
+                const int qx = lx + ((k & 3) == 2 ? -dist : (k & 3) == 3 ? dist : 0) + kReach;
+                const int qy = ly + ((k & 3) == 0 ? -dist : (k & 3) == 1 ? dist : 0) + kReach;
+                ranks |= (unsigned)atomicAdd(&hist[qy * kExtW + qx], 1) << (3 * k);
+            }
+        }
+        __syncthreads();
+        // exclusive prefix sum of the histogram, kPerLane consecutive cells per lane
+        int loc[kPerLane];
+        int sum = 0;
+#pragma unroll
+        for (int e = 0; e < kPerLane; e++) {
+            const int c = threadIdx.x * kPerLane + e;
+            loc[e] = c < kCells ? hist[c] : 0;
+            sum += loc[e];
+        }
+        int incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if ((int)(threadIdx.x & 63) >= d) incl += up;
+        }
+        if ((threadIdx.x & 63) == 63) wcnt[wave] = incl;
+        __syncthreads();
+        const int c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
+        int run = incl - sum + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
+        n_tasks = c0 + c1 + c2 + c3;
+#pragma unroll
+        for (int e = 0; e < kPerLane; e++) {
+            const int c = threadIdx.x * kPerLane + e;
+            if (c < kCells) hist[c] = run;
+            run += loc[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if ((needmask >> k) & 1u) {
+                const int dist = k < 4 ? 1 : 5;
+                const int qx = lx + ((k & 3) == 2 ? -dist : (k & 3) == 3 ? dist : 0) + kReach;
+                const int qy = ly + ((k & 3) == 0 ? -dist : (k & 3) == 1 ? dist : 0) + kReach;
+                btask[hist[qy * kExtW + qx] + (int)((ranks >> (3 * k)) & 7u)] =
+                    (unsigned short)(threadIdx.x | (k << 8));
+            }
+        }
+        __syncthreads();  // also orders the last reads of `hist` before bres is written
+    }
+
+    // planeRefinement_cu + getRndDispAndUnitVector_cu, gipuma.cu:928-994, 890-927
+    const float min_disp = P->min_disp, max_disp = P->max_disp;
+    int nref = 0;  // number of refinement steps: deltaZ = max_disp/2, /10 ... >= 0.01 (:958-959)
+    if (stages & 4u)
+        for (float dz = max_disp / 2.0f; dz >= 0.01f; dz = dz / 10.0f) nref++;
+    Vec3 view = {0.f, 0.f, 0.f};
+    uint32_t pre = 0, draw = 0;
+    float deltaN = 1.0f, deltaZ = max_disp / 2.0f;
+
+    // propagation: kColTasks tasks per round, one group of lanes each
+    const int grp = threadIdx.x / kColGroup, col = threadIdx.x % kColGroup;
+    const int prop_rounds_c = (n_tasks + kColTasks - 1) / kColTasks;
+    for (int r = 0; r < prop_rounds_c; r++) {
+        const int pos = r * kColTasks + grp;
+        const bool have = pos < n_tasks;
+        const unsigned t = btask[have ? pos : 0];
+        const int owner = (int)(t & 255u), slot = (int)(t >> 8);
+        const int oly = owner >> 4;
+        const int olx = 2 * (owner & 15) + ((oly + colour) & 1);
+        const int epx = x0 + olx, epy = y0 + oly;
+        int nb;
+        neighbour(slot, epx, epy, rows, cols, epy * cols + epx, nb);
+        const float4 cand = norm4[nb];
+        const float *etp0 = tile + ((oly + hh) * tw + (olx + hw)) * 4;
+        const float c = multiview_cost_cols<BOX, COMBINE_REG>(P, etp0, tw, lds, cv, epx, epy, cand, col);
+        if (have && col == 0) bres[slot * kThreads + owner] = c;
+    }
+    __syncthreads();
+    // replay: spatialPropagation_cu's accept test (gipuma.cu:865-872) in slot order, by the owner
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if ((needmask >> k) & 1u) {
+            int nb;
+            neighbour(k, px, py, rows, cols, center, nb);
+            const float4 cand = norm4[nb];
+            const float c = bres[k * kThreads + threadIdx.x];
+            const float d_new = depth_from_plane(rc, cand, px, py);
+            if (d_new >= rc.depth_min && d_new <= rc.depth_max && c < cst) {  // :829-830, :868
+                depth = d_new;
+                pl = cand;
+                cst = c;
+            }
+        }
+    }
+    if (nref > 0 && active) {
+        depth = depth_from_plane(rc, pl, px, py);  // the refine kernel re-derives it, :1660
+        view = view_vector(rc, px, py);
+        pre = rng_prefix(P->seed, phase, (uint32_t)px, (uint32_t)py);
+    }
+    // refinement steps: the owner draws its candidate, groups evaluate all 256, the owner accepts
+    float4 *candbuf = reinterpret_cast<float4 *>(btask);  // the task list is dead now (same 4 KB)
+    for (int step = 0; step < nref; step++) {
+        float4 cand = make_float4(0.f, 0.f, -1.f, 1.f);
+        float d_new = 0.f;
+        if (active) {
+            const float disp = disp_depth(rc.f, rc.baseline, depth);
+            const float minDelta = -__builtin_fminf(deltaZ, min_disp + disp);  // sic, :909
+            const float maxDelta = __builtin_fminf(deltaZ, max_disp - disp);
+            const float u0 = rng_uniform(pre, draw++);
+            const float u1 = rng_uniform(pre, draw++);
+            const float u2 = rng_uniform(pre, draw++);
+            const float u3 = rng_uniform(pre, draw++);
+            const float dz = between(u0, minDelta, maxDelta);
+            const float dispOut = __builtin_fminf(__builtin_fmaxf(disp + dz, min_disp), max_disp);
+            d_new = disp_depth(rc.f, rc.baseline, dispOut);
+            Vec3 n;
+            n.x = pl.x + between(u1, -deltaN, deltaN);
+            n.y = pl.y + between(u2, -deltaN, deltaN);
+            n.z = pl.z + between(u3, -deltaN, deltaN);
+            n = on_hemisphere(normalize3(n), view);
+            cand = make_float4(n.x, n.y, n.z, plane_d(rc, n, px, py, d_new));
+        }
+        deltaN = deltaN / 4.0f;
+        deltaZ = deltaZ / 10.0f;
+        __syncthreads();  // the previous step's reads of bres / candbuf are done
+        candbuf[threadIdx.x] = cand;
+        __syncthreads();
+        for (int r = 0; r < kThreads / kColTasks; r++) {
+            const int owner = r * kColTasks + grp;
+            const int oly = owner >> 4;
+            const int olx = 2 * (owner & 15) + ((oly + colour) & 1);
+            // pixels outside the image (ragged last tile) evaluate their dummy plane at the clamped
+            // position: harmless, never read back
+            const int epx = min(x0 + olx, cols - 1), epy = min(y0 + oly, rows - 1);
+            const float4 ecand = candbuf[owner];
+            const float *etp0 = tile + (((epy - y0) + hh) * tw + ((epx - x0) + hw)) * 4;
+            const float c = multiview_cost_cols<BOX, COMBINE_REG>(P, etp0, tw, lds, cv, epx, epy, ecand, col);
+            if (col == 0) bres[owner] = c;
+        }
+        __syncthreads();
+        if (active) {
+            const float c = bres[threadIdx.x];
+            if (c < cst) {  // refinement has no depth-range test, :986
                 depth = d_new;
                 pl = cand;
                 cst = c;
