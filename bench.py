@@ -207,7 +207,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": "GB per launch (L2<->fabric incl. Infinity Cache hits)",
-                         "kernel": "pm::sweep_kernel (one colour: close+far+refine fused)",
+                         "kernel": "one half-sweep launch (one colour: close+far+refine fused); mean over the 16 of a "
+                                   "view: pm::sweep_cols_kernel x3 + pm::sweep_kernel x13 on config C",
                          "kernel_ms": ms_launch,
                          "algorithmic_bytes_per_launch": alg,
                          "note": "compute/gather bound by construction (SURVEY F5): "

@@ -22,7 +22,10 @@ FETCH_SIZE
 WRITE_SIZE
 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT
 LIST
-python $R/scripts/rocprof_summary.py pmc $OUT sweep_kernel > $OUT/pmc_summary.json
+# all 16 half-sweep launches of a view (both kernels), then each kernel on its own
+python $R/scripts/rocprof_summary.py pmc $OUT sweep_ > $OUT/pmc_summary.json
+python $R/scripts/rocprof_summary.py pmc $OUT sweep_kernel > $OUT/pmc_summary_pixel_per_lane.json
+python $R/scripts/rocprof_summary.py pmc $OUT sweep_cols_kernel > $OUT/pmc_summary_column_per_lane.json
 python $R/scripts/rocprof_summary.py pmc $OUT init_kernel > $OUT/pmc_summary_init.json
 rm -f $OUT/*.db
 ls -la $OUT | head -30
