@@ -188,6 +188,10 @@ int launch_dense(gipuma_hip_session *s, bool generate, float4 *planes, float *co
     const int gx = (s->cols + pm::kTileW - 1) / pm::kTileW;
     const int gy = (s->rows + pm::kDenseTileH - 1) / pm::kDenseTileH;
     init_fn k = generate ? pick_init<true>(s) : pick_init<false>(s);
+    // random (or arbitrary caller-supplied) planes: column-per-lane evaluation where it exists
+    if (s->u8 && s->ch == 1 && s->hp.magic_addr && s->box == 15 &&
+        !(s->tune & (Tune::kNoColsKernel | Tune::kNoInterior)))
+        k = generate ? pm::init_cols_kernel<15, true> : pm::init_cols_kernel<15, false>;
     hipLaunchKernelGGL(k, dim3(gx * gy), dim3(pm::kThreads), s->lds_dense, s->stream, s->dp, planes,
                        cost_out, s->tune);
     HIP_OK(hipGetLastError());

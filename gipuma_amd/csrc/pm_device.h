@@ -217,7 +217,8 @@ __host__ __device__ constexpr int work_floats(int tile_texels, bool sweep)
     // gray staging plane (tile_texels floats, dead after stage_tile) and the sweep kernel's
     // per-wavefront task scratch share one region
     const int plane = CH == 1 ? tile_texels : 0;
-    const int tasks = sweep ? kTaskScratchFloats : 0;
+    // dense kernels: 256 planes + 256 costs exchanged by the column-per-lane evaluation
+    const int tasks = sweep ? kTaskScratchFloats : 5 * kThreads;
     return plane > tasks ? plane : tasks;
 }
 
@@ -1160,6 +1161,77 @@ __global__ __launch_bounds__(kThreads) void init_kernel(const Problem *__restric
     else
         c = multiview_cost<BOX, U8, true, COMBINE_REG, CH>(P, tp0, tw, lds, cv, px, py, pl, win);
     cost[center] = c;
+}
+
+// init_kernel with the column-per-lane evaluation (view_cost_cols): every lane draws / reads the
+// plane of its own pixel as above, the 256 planes of the tile go through LDS and are evaluated by
+// groups of kColGroup lanes -- random planes are the worst case for one lane per pixel.
+template <int BOX, bool GENERATE>
+__global__ __launch_bounds__(kThreads) void init_cols_kernel(const Problem *__restrict__ P,
+                                                             float4 *__restrict__ norm4, float *__restrict__ cost,
+                                                             unsigned tune)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int CH = 1;
+    const Win<BOX> win(P);
+    const int gx = (P->cols + kTileW - 1) / kTileW;
+    const int gy = (P->rows + kDenseTileH - 1) / kDenseTileH;
+    const TileXY txy = tile_of(blockIdx.x, gx, gy, tune);
+    const int x0 = txy.x * kTileW, y0 = txy.y * kDenseTileH;
+    stage_tile<BOX, CH>(P, lds, x0, y0, kDenseTileH, win, true);
+    const int hw = win.halo_w(), hh = win.halo_h();
+    const int tw = kTileW + 2 * hw, th = kDenseTileH + 2 * hh;
+    const float *tile = lds + lut_size<CH>();
+    float *work = lds + lut_size<CH>() + 4 * tw * th;  // the staging plane is dead now
+    float4 *candbuf = reinterpret_cast<float4 *>(work);
+    float *bres = work + 4 * kThreads;
+    float *cv = work + work_floats<CH>(tw * th, false) + threadIdx.x;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int px = x0 + lx, py = y0 + ly;
+    const bool active = px < P->cols && py < P->rows;
+    const int center = py * P->cols + px;
+    float4 pl = make_float4(0.f, 0.f, -1.f, 1.f);
+    if (active) {
+        if (GENERATE) {
+            const RefCam &rc = P->rc;
+            const uint32_t pre = rng_prefix(P->seed, 0u, (uint32_t)px, (uint32_t)py);
+            uint32_t draw = 0;
+            const Vec3 view = view_vector(rc, px, py);
+            const float disp = between(rng_uniform(pre, draw++), P->min_disp, P->max_disp);
+            // rndUnitVectorSphereMarsaglia_cu, gipuma.cu:148-164
+            float rx = 1.0f, ry = 1.0f, sum = 2.0f;
+            while (sum >= 1.0f) {
+                rx = between(rng_uniform(pre, draw++), -1.0f, 1.0f);
+                ry = between(rng_uniform(pre, draw++), -1.0f, 1.0f);
+                sum = rx * rx + ry * ry;
+            }
+            const float sq = __builtin_sqrtf(1.0f - sum);
+            Vec3 n;
+            n.x = 2.0f * rx * sq;
+            n.y = 2.0f * ry * sq;
+            n.z = 1.0f - 2.0f * sum;
+            n = on_hemisphere(n, view);
+            const float depth = disp_depth(rc.f, rc.baseline, disp);
+            pl = make_float4(n.x, n.y, n.z, plane_d(rc, n, px, py, depth));
+            norm4[center] = pl;
+        } else {
+            pl = norm4[center];
+        }
+    }
+    candbuf[threadIdx.x] = pl;
+    __syncthreads();
+    const int grp = threadIdx.x / kColGroup, col = threadIdx.x % kColGroup;
+    for (int r = 0; r < kThreads / kColTasks; r++) {
+        const int owner = r * kColTasks + grp;
+        // pixels outside the image evaluate their dummy plane at the clamped position (never stored)
+        const int epx = min(x0 + (owner & 31), P->cols - 1), epy = min(y0 + (owner >> 5), P->rows - 1);
+        const float4 ecand = candbuf[owner];
+        const float *etp0 = tile + (((epy - y0) + hh) * tw + ((epx - x0) + hw)) * 4;
+        const float c = multiview_cost_cols<BOX, false>(P, etp0, tw, lds, cv, epx, epy, ecand, col);
+        if (col == 0) bres[owner] = c;
+    }
+    __syncthreads();
+    if (active) cost[center] = bres[threadIdx.x];
 }
 
 // One colour of one iteration: the bodies of gipuma_checkerboard_spatialPropClose_cu
