@@ -397,6 +397,23 @@ def test_ragged_and_tiny_images(hip, cols, rows):
     assert_same(c, o_c, "ragged %dx%d cost" % (cols, rows))
 
 
+@pytest.mark.parametrize("cols,rows,sel,over", [
+    (21, 9, [1, 2, 3], dict(cost_comb=abi.COMB_ALL)),            # image smaller than the window
+    (70, 40, [1, 2, 3, 4] * 3, dict(n_best=5)),                  # 12 views: two exchange blocks; LDS combiner
+    (37, 33, [1, 2, 3, 4, 1, 2, 3, 4, 1], dict(cost_comb=abi.COMB_GOOD)),  # 9 views, ragged, GOOD
+])
+def test_column_per_lane_kernel_edge_cases(hip, cols, rows, sel, over):
+    """box 15 on packed gray planes runs its first three half-sweeps (and init) column-per-lane:
+    ragged / tiny images, more views than one group exchanges at once, every combiner"""
+    gs, _ = synth.build_problem(synth.tiny_config(cols=96, rows=64, n_src=4, blocksize=15, iterations=2))
+    imgs = [np.ascontiguousarray(im[:rows, :cols]) for im in gs.images]
+    g = _problem_from(gs, imgs, sel, **over)
+    n4, c = runcuda(g)
+    o_n4, o_c = OracleState(g).run()
+    assert_same(n4, o_n4, "cols %dx%d norm4" % (cols, rows))
+    assert_same(c, o_c, "cols %dx%d cost" % (cols, rows))
+
+
 def test_maximum_number_of_views(hip):
     """32 selected views = the reference's costVector[32] limit (gipuma.cu:736), ALL combiner"""
     from gipuma_amd.cameras import CameraSet
