@@ -38,11 +38,17 @@ with Session(gs) as s:
                     ok = (ys + dy >= 0) & (ys + dy < R) & (xs + dx >= 0) & (xs + dx < Cc)
                     cands.append((np.roll(b, (-dy, -dx), axis=(0, 1)), ok))
             needAC = np.zeros((R, Cc), np.int32)
-            for k, (ck, okk) in enumerate(cands):
-                fresh = okk & ~(ck == b).all(-1)
-                for j in range(k):
-                    fresh &= ~(cands[j][1] & (cands[j][0] == ck).all(-1))
-                needAC += fresh
+            needACB = np.zeros((R, Cc), np.int32)  # stateless rules AND the history rule B
+            k = 0
+            for dist in (1, 5):
+                for dy, dx in ((-dist, 0), (dist, 0), (0, -dist), (0, dist)):
+                    ck, okk = cands[k]
+                    fresh = okk & ~(ck == b).all(-1)
+                    for j in range(k):
+                        fresh &= ~(cands[j][1] & (cands[j][0] == ck).all(-1))
+                    needAC += fresh
+                    needACB += fresh & np.roll(changed, (-dy, -dx), axis=(0, 1))
+                    k += 1
             for dist in (1, 5):
                 for dy, dx in ((-dist, 0), (dist, 0), (0, -dist), (0, dist)):
                     ok = (ys + dy >= 0) & (ys + dy < R) & (xs + dx >= 0) & (xs + dx < Cc)
@@ -62,7 +68,8 @@ with Session(gs) as s:
             wave = np.where(act, needAC, 0)[:Rt // 4 * 4, :Ct].reshape(Rt // 4, 4, Ct // 32, 32).transpose(0, 2, 1, 3).reshape(-1, 128).sum(1)
             tot_ac = globals().get("tot_ac", 0.0) + np.ceil(wave / 64.0).mean() + 3
             globals()["tot_ac"] = tot_ac
-            print("   stateless A+dedupe: %.2f / 8 per pixel; wave-compacted rounds %.2f" % (needAC[act].mean(), np.ceil(wave / 64.0).mean()))
+            print("   stateless A+dedupe: %.2f / 8 per pixel; with history rule B as well: %.2f; wave-compacted rounds %.2f"
+                  % (needAC[act].mean(), needACB[act].mean(), np.ceil(wave / 64.0).mean()))
             tot_need += rounds + 3
             tot_full += 11
             print("it %d colour %d: need eval (A+B) %.2f / 8 per pixel (B only %.2f); compacted rounds %.2f / 8; changed %.3f"
