@@ -538,3 +538,33 @@ def test_shared_planes_with_consistent_costs(hip, tiny_problem):
         assert_same(c, o.cost, "propagation-only cost")
         same_as_right = (n4[:, 1:].view(np.uint32) == n4[:, :-1].view(np.uint32)).all(-1).mean()
         assert same_as_right > 0.3        # the scenario really has shared planes
+
+
+# ------------------------------------------------------------------------------------------------
+# the HIP path against the committed outputs of the REFERENCE's own device code (tests/golden/)
+# ------------------------------------------------------------------------------------------------
+def test_hip_against_reference_golden_fixture(hip):
+    """tests/golden/ref_tiny64.npz holds what /root/reference/gipuma.cu itself (compiled for the CPU,
+    oracle/ref_shim) produced on this input: the initial planes must be bit-identical, the costs
+    agree to the level two implementations of the same fp32 formulas can (see costs_close), a sweep
+    started from the reference's own state reproduces its planes, and the free-running result is
+    inside BASELINE.json's tolerance (1e-4 relative depth, 1e-3 normals)."""
+    from tests.test_oracle_vs_ref import golden_problem, costs_close, rel
+    gs, g = golden_problem()
+    with Session(gs) as s:
+        s.init_planes()
+        n4, c = s.get_state()
+        assert_same(n4, g["init_norm4"], "HIP init planes vs reference")
+        assert costs_close(g["init_cost"], c)
+        s.set_state(g["init_norm4"], g["init_cost"])
+        s.sweep(0, abi.BLACK)
+        b4, bc = s.get_state()
+        same = (bits(b4) == bits(g["black0_norm4"])).all(-1)
+        assert same.mean() > 0.999
+        assert costs_close(g["black0_cost"][same], bc[same])
+    f4, fc = runcuda(gs)
+    d_rel = rel(g["final_norm4"][..., 3], f4[..., 3])
+    n_err = np.abs(g["final_norm4"][..., :3] - f4[..., :3]).max(-1)
+    ok = (d_rel < 1e-4) & (n_err < 1e-3)
+    assert ok.mean() > 0.995
+    assert costs_close(g["final_cost"][ok], fc[ok])
