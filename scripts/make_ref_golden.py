@@ -22,8 +22,16 @@ from gipuma_amd import abi, synth  # noqa: E402
 from tests.ref_lib import RefState  # noqa: E402
 
 
-def main():
-    gs, info = synth.build_problem(synth.tiny_config(cols=64, rows=64, n_src=3, blocksize=7, iterations=2))
+FIXTURES = {
+    # name: tiny_config arguments
+    "ref_tiny64": dict(cols=64, rows=64, n_src=3, blocksize=7, iterations=2),
+    # the shipped fast-path geometry: box 15 (8x8 samples), best-3 of 4 views (the reference needs sizes that are multiples of 32)
+    "ref_box15": dict(cols=96, rows=64, n_src=4, blocksize=15, iterations=2, n_best=3),
+}
+
+
+def make(name, cfg):
+    gs, info = synth.build_problem(synth.tiny_config(**cfg))
     r = RefState(gs, tex_mode=0)
     r.init_planes()
     init_n4, init_c = r.get_state()
@@ -41,7 +49,7 @@ def main():
                   cost_comb=p.cost_comb, alpha=p.alpha, tau_color=p.tau_color, tau_gradient=p.tau_gradient,
                   gamma=p.gamma, min_disparity=p.min_disparity, max_disparity=p.max_disparity,
                   good_factor=p.good_factor)
-    out = os.path.join(ROOT, "tests", "golden", "ref_tiny64.npz")
+    out = os.path.join(ROOT, "tests", "golden", name + ".npz")
     np.savez_compressed(
         out, images=np.stack(gs.images).astype(np.uint8), cameras=cams,
         selected=np.array(gs.selected, dtype=np.int32), seed=np.uint32(gs.desc.seed),
@@ -49,6 +57,11 @@ def main():
         init_norm4=init_n4, init_cost=init_c, black0_norm4=b_n4, black0_cost=b_c,
         presweep_final_norm4=pre_n4, final_norm4=fin_n4, final_cost=fin_c)
     print("wrote", out, os.path.getsize(out), "bytes")
+
+
+def main():
+    for name, cfg in FIXTURES.items():
+        make(name, cfg)
 
 
 if __name__ == "__main__":

@@ -25,7 +25,10 @@ from gipuma_amd.problem import AlgorithmParameters, GlobalState
 from tests import ref_lib
 from tests.oracle_lib import OracleState, farr, fptr, lib as olib
 
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_tiny64.npz")
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDEN_NAMES = ["ref_tiny64", "ref_box15"]   # scripts/make_ref_golden.py: box 7 (generic window) and box 15
+GOLDEN = os.path.join(GOLDEN_DIR, "ref_tiny64.npz")
+each_golden = pytest.mark.parametrize("fixture", GOLDEN_NAMES)
 COST_RTOL = 2e-5
 
 needs_ref = pytest.mark.skipif(not ref_lib.available(), reason="oracle/_ref not built (no reference tree)")
@@ -47,11 +50,13 @@ def costs_close(a, b):
     return r.size == 0 or (np.quantile(r, 0.999) < COST_RTOL and r.max() < 1e-3)
 
 
-def golden_problem():
-    g = np.load(GOLDEN)
+def golden_problem(fixture="ref_tiny64"):
+    g = np.load(os.path.join(GOLDEN_DIR, fixture + ".npz"))
     n = g["cameras"].shape[0]
     cs = CameraSet(n)
-    C.memmove(cs.c_array, np.ascontiguousarray(g["cameras"]).ctypes.data, C.sizeof(cs.c_array))
+    cams = np.ascontiguousarray(g["cameras"])  # keep the buffer alive across the copy
+    assert cams.nbytes == C.sizeof(cs.c_array)
+    C.memmove(cs.c_array, cams.ctypes.data, cams.nbytes)
     cs.f = cs.c_array[0].f
     pv = dict(zip([str(k) for k in g["param_names"]], g["param_values"]))
     ap = AlgorithmParameters(iterations=int(pv["iterations"]), n_best=int(pv["n_best"]),
@@ -69,17 +74,19 @@ def golden_problem():
 
 
 # ------------------------------------------------------------------ against the committed fixture
-def test_golden_init_planes_bit_identical_and_costs_close():
-    gs, g = golden_problem()
+@each_golden
+def test_golden_init_planes_bit_identical_and_costs_close(fixture):
+    gs, g = golden_problem(fixture)
     o = OracleState(gs)
     o.init_planes()
     assert np.array_equal(bits(o.norm4), bits(g["init_norm4"]))
     assert costs_close(g["init_cost"], o.cost)
 
 
-def test_golden_black_sweep_from_reference_state():
+@each_golden
+def test_golden_black_sweep_from_reference_state(fixture):
     """start from the reference's post-init state, run one black sweep: same planes, close costs"""
-    gs, g = golden_problem()
+    gs, g = golden_problem(fixture)
     o = OracleState(gs)
     o.norm4[:] = g["init_norm4"]
     o.cost[:] = g["init_cost"]
@@ -89,10 +96,11 @@ def test_golden_black_sweep_from_reference_state():
     assert costs_close(g["black0_cost"][same], o.cost[same])
 
 
-def test_golden_full_run_within_north_star_tolerance():
+@each_golden
+def test_golden_full_run_within_north_star_tolerance(fixture):
     """free-running 2 iterations + final conversion vs the reference's dump: depth within 1e-4
     relative, normals within 1e-3 (BASELINE.json), here in fact identical"""
-    gs, g = golden_problem()
+    gs, g = golden_problem(fixture)
     n4, c = OracleState(gs).run()
     d_rel = rel(g["final_norm4"][..., 3], n4[..., 3])
     n_err = np.abs(g["final_norm4"][..., :3] - n4[..., :3]).max(-1)
@@ -101,8 +109,9 @@ def test_golden_full_run_within_north_star_tolerance():
     assert costs_close(g["final_cost"][ok], c[ok])
 
 
-def test_golden_final_conversion_bit_identical():
-    gs, g = golden_problem()
+@each_golden
+def test_golden_final_conversion_bit_identical(fixture):
+    gs, g = golden_problem(fixture)
     n4 = np.ascontiguousarray(g["presweep_final_norm4"]).copy()
     assert olib().gipuma_oracle_finalize(C.byref(gs.desc), fptr(n4), fptr(np.ascontiguousarray(g["final_cost"]))) == 0
     assert np.array_equal(bits(n4), bits(g["final_norm4"]))
@@ -196,8 +205,9 @@ def test_ref_free_running_full_run():
 
 
 @needs_ref
-def test_golden_fixture_is_what_the_reference_produces_now():
-    gs, g = golden_problem()
+@each_golden
+def test_golden_fixture_is_what_the_reference_produces_now(fixture):
+    gs, g = golden_problem(fixture)
     rn, rc = ref_lib.RefState(gs).run()
     assert np.array_equal(bits(rn), bits(g["final_norm4"]))
     assert np.array_equal(bits(rc), bits(g["final_cost"]))

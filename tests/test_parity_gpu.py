@@ -543,14 +543,16 @@ def test_shared_planes_with_consistent_costs(hip, tiny_problem):
 # ------------------------------------------------------------------------------------------------
 # the HIP path against the committed outputs of the REFERENCE's own device code (tests/golden/)
 # ------------------------------------------------------------------------------------------------
-def test_hip_against_reference_golden_fixture(hip):
-    """tests/golden/ref_tiny64.npz holds what /root/reference/gipuma.cu itself (compiled for the CPU,
-    oracle/ref_shim) produced on this input: the initial planes must be bit-identical, the costs
+@pytest.mark.parametrize("fixture", ["ref_tiny64", "ref_box15"])
+def test_hip_against_reference_golden_fixture(hip, fixture):
+    """tests/golden/*.npz hold what /root/reference/gipuma.cu itself (compiled for the CPU,
+    oracle/ref_shim) produced on two inputs (box 7: the runtime-sized kernels; box 15: the
+    column-per-lane and pipelined kernels): the initial planes must be bit-identical, the costs
     agree to the level two implementations of the same fp32 formulas can (see costs_close), a sweep
     started from the reference's own state reproduces its planes, and the free-running result is
     inside BASELINE.json's tolerance (1e-4 relative depth, 1e-3 normals)."""
     from tests.test_oracle_vs_ref import golden_problem, costs_close, rel
-    gs, g = golden_problem()
+    gs, g = golden_problem(fixture)
     with Session(gs) as s:
         s.init_planes()
         n4, c = s.get_state()
