@@ -1275,6 +1275,276 @@ __device__ __forceinline__ bool neighbour(int k, int px, int py, int rows, int c
     }
 }
 
+// ---- pieces of a half-sweep shared by sweep_kernel and sweep_cols_kernel ----
+// Per-lane context: the lane's pixel inside the workgroup tile, the LDS carve, and the pixel's state.
+struct SweepLane {
+    int x0, y0, hw, hh, tw;           // tile origin, halo, tile row length (texels)
+    int lx, ly, px, py, center;      // pixel inside the tile / in the image
+    bool active;                      // inside the image
+    const float *tile;                // reference tile (float4 per texel)
+    float *bres;                      // [8][256] candidate costs
+    unsigned short *btask;            // [2048] tasks: owner tid | slot << 8
+    int *wcnt;                        // per-wavefront counters
+    float *cv;                        // this lane's column of view costs (generic combiner)
+    float4 pl;                        // current plane
+    float cst, depth;                 // its cost and depth
+    unsigned needmask;                // candidate slots that must be evaluated
+    int n_tasks;                      // surviving (pixel, candidate) pairs of the workgroup
+};
+
+// tile staging, lane -> pixel mapping, state read (gipuma.cu:1527-1530), exact skipping rules and
+// the workgroup task list
+template <int BOX, int CH>
+__device__ __forceinline__ void sweep_setup(SweepLane &L, const Problem *__restrict__ P, float *lds,
+                                            const float4 *__restrict__ norm4, const float *__restrict__ cost,
+                                            int colour, unsigned stages, unsigned tune, bool want_lut)
+{
+    const Win<BOX> win(P);
+    const RefCam &rc = P->rc;
+    const int rows = P->rows, cols = P->cols;
+    const int gx = (cols + kTileW - 1) / kTileW;
+    const int gy = (rows + kSweepTileH - 1) / kSweepTileH;
+    const TileXY txy = tile_of(blockIdx.x, gx, gy, tune);
+    L.x0 = txy.x * kTileW;
+    L.y0 = txy.y * kSweepTileH;
+    stage_tile<BOX, CH>(P, lds, L.x0, L.y0, kSweepTileH, win, want_lut);
+    L.hw = win.halo_w();
+    L.hh = win.halo_h();
+    L.tw = kTileW + 2 * L.hw;
+    const int th = kSweepTileH + 2 * L.hh;
+    L.tile = lds + lut_size<CH>();
+    float *work = lds + lut_size<CH>() + 4 * L.tw * th;
+    L.cv = work + work_floats<CH>(L.tw * th, true) + threadIdx.x;
+    // (gray: the staging plane inside `work` is dead after stage_tile's last barrier)
+    L.bres = work;                                                                  // [8][256] costs
+    L.btask = reinterpret_cast<unsigned short *>(work + 8 * kThreads);              // [2048] tid | slot << 8
+    L.wcnt = reinterpret_cast<int *>(work + 8 * kThreads + (8 * kThreads) / 2);     // [4 waves][8 slots]
+
+    // lane -> pixel: 16 pixels of the colour per tile row; a wavefront covers 4 rows x 32 columns
+    L.ly = threadIdx.x >> 4;
+    L.lx = 2 * (threadIdx.x & 15) + ((L.ly + colour) & 1);  // tile origin is even in x and y
+    L.px = L.x0 + L.lx;
+    L.py = L.y0 + L.ly;
+    L.active = L.px < cols && L.py < rows;
+    L.center = L.py * cols + L.px;
+    const bool trust = !(tune & Tune::kUntrustedCosts);
+
+    // read state (gipuma.cu:1527-1530)
+    L.pl = make_float4(0.f, 0.f, 0.f, 0.f);
+    L.cst = 0.f;
+    L.depth = 0.f;
+    L.needmask = 0;
+    if (L.active) {
+        const float4 pl = norm4[L.center];
+        L.pl = pl;
+        L.cst = cost[L.center];
+        L.depth = depth_from_plane(rc, pl, L.px, L.py);
+        float4 cands[8];
+        unsigned valid = 0, needmask = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            int nb;
+            const bool ok = neighbour(k, L.px, L.py, rows, cols, L.center, nb) && (stages & (k < 4 ? 1u : 2u));
+            if (ok) {
+                cands[k] = norm4[nb];
+                valid |= 1u << k;
+            }
+        }
+        if (tune & Tune::kNoSkip) {
+            needmask = valid;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                bool fresh = (valid >> k) & 1u;
+                if (fresh && trust && same_bits(cands[k], pl)) fresh = false;  // (A)
+#pragma unroll
+                for (int j = 0; j < k; j++)
+                    if (fresh && ((valid >> j) & 1u) && same_bits(cands[k], cands[j])) fresh = false;  // (D)
+                if (fresh) needmask |= 1u << k;
+            }
+        }
+        L.needmask = needmask;
+    }
+    // Workgroup task list.  Two orders, same set of tasks (the order cannot change a result: a task
+    // is a pure function of (pixel, plane) and its cost lands in bres[slot][owner]):
+    //  * source-major (default): tasks that evaluate the SAME plane -- the plane of other-colour
+    //    pixel q is a candidate of q+-1 and q+-5 in x and y -- are adjacent, so the lanes of a
+    //    wavefront that share a plane read source windows a few pixels apart, i.e. the same cache
+    //    lines, even while the planes themselves are still random.  A divergent window load costs
+    //    the vector L1 two clocks per distinct 128-byte line (scripts/ubench/l1_window_rate.hip);
+    //    the first half-sweeps are bound by exactly that.  Built as a counting sort keyed by q's
+    //    position in the tile extended by the 5-pixel propagation reach.
+    //  * owner-major (Tune::kOwnerMajorTasks): a pixel's surviving candidates adjacent, pixels in
+    //    lane order: a wavefront-level inclusive scan of the per-lane counts.
+    int n_tasks;
+    const unsigned needmask = L.needmask;
+    const int lx = L.lx, ly = L.ly, wave = threadIdx.x >> 6;
+    float *bres = L.bres;
+    unsigned short *btask = L.btask;
+    int *wcnt = L.wcnt;
+    if (tune & Tune::kOwnerMajorTasks) {
+        const int cnt = __popc(needmask);
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if ((int)(threadIdx.x & 63) >= d) incl += up;
+        }
+        if ((threadIdx.x & 63) == 63) wcnt[wave] = incl;
+        __syncthreads();
+        const int c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
+        int pos0 = incl - cnt + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
+        n_tasks = c0 + c1 + c2 + c3;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if ((needmask >> k) & 1u) btask[pos0++] = (unsigned short)(threadIdx.x | (k << 8));
+        __syncthreads();
+    } else {
+        constexpr int kReach = 5, kExtW = kTileW + 2 * kReach, kExtH = kSweepTileH + 2 * kReach;
+        constexpr int kCells = kExtW * kExtH, kPerLane = (kCells + kThreads - 1) / kThreads;
+        static_assert(kCells <= 8 * kThreads, "the histogram aliases bres");
+        int *hist = reinterpret_cast<int *>(bres);  // bres is not written before the first round
+        for (int c = threadIdx.x; c < kCells; c += kThreads) hist[c] = 0;
+        __syncthreads();
+        unsigned ranks = 0;  // 3 bits per slot: at most 8 tasks share a source pixel
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if ((needmask >> k) & 1u) {
+                const int dist = k < 4 ? 1 : 5;
+                const int qx = lx + ((k & 3) == 2 ? -dist : (k & 3) == 3 ? dist : 0) + kReach;
+                const int qy = ly + ((k & 3) == 0 ? -dist : (k & 3) == 1 ? dist : 0) + kReach;
+                ranks |= (unsigned)atomicAdd(&hist[qy * kExtW + qx], 1) << (3 * k);
+            }
+        }
+        __syncthreads();
+        // exclusive prefix sum of the histogram, kPerLane consecutive cells per lane
+        int loc[kPerLane];
+        int sum = 0;
+#pragma unroll
+        for (int e = 0; e < kPerLane; e++) {
+            const int c = threadIdx.x * kPerLane + e;
+            loc[e] = c < kCells ? hist[c] : 0;
+            sum += loc[e];
+        }
+        int incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if ((int)(threadIdx.x & 63) >= d) incl += up;
+        }
+        if ((threadIdx.x & 63) == 63) wcnt[wave] = incl;
+        __syncthreads();
+        const int c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
+        int run = incl - sum + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
+        n_tasks = c0 + c1 + c2 + c3;
+#pragma unroll
+        for (int e = 0; e < kPerLane; e++) {
+            const int c = threadIdx.x * kPerLane + e;
+            if (c < kCells) hist[c] = run;
+            run += loc[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if ((needmask >> k) & 1u) {
+                const int dist = k < 4 ? 1 : 5;
+                const int qx = lx + ((k & 3) == 2 ? -dist : (k & 3) == 3 ? dist : 0) + kReach;
+                const int qy = ly + ((k & 3) == 0 ? -dist : (k & 3) == 1 ? dist : 0) + kReach;
+                btask[hist[qy * kExtW + qx] + (int)((ranks >> (3 * k)) & 7u)] =
+                    (unsigned short)(threadIdx.x | (k << 8));
+            }
+        }
+        __syncthreads();  // also orders the last reads of `hist` before bres is written
+    }
+    L.n_tasks = n_tasks;
+}
+
+// replay: spatialPropagation_cu's accept test (gipuma.cu:865-872) in slot order, by the owner lane,
+// from the costs the rounds left in bres
+__device__ __forceinline__ void sweep_replay(SweepLane &L, const Problem *__restrict__ P,
+                                             const float4 *__restrict__ norm4)
+{
+    const RefCam &rc = P->rc;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if ((L.needmask >> k) & 1u) {
+            int nb;
+            neighbour(k, L.px, L.py, P->rows, P->cols, L.center, nb);
+            const float4 cand = norm4[nb];
+            const float c = L.bres[k * kThreads + threadIdx.x];
+            const float d_new = depth_from_plane(rc, cand, L.px, L.py);
+            if (d_new >= rc.depth_min && d_new <= rc.depth_max && c < L.cst) {  // :829-830, :868
+                L.depth = d_new;
+                L.pl = cand;
+                L.cst = c;
+            }
+        }
+    }
+}
+
+// planeRefinement_cu + getRndDispAndUnitVector_cu, gipuma.cu:928-994, 890-927
+struct RefineDraws {
+    int nref;  // number of refinement steps: deltaZ = max_disp/2, /10 ... >= 0.01 (:958-959)
+    Vec3 view;
+    uint32_t pre, draw;
+    float deltaN, deltaZ;
+};
+__device__ __forceinline__ void refine_init(RefineDraws &R, const Problem *__restrict__ P, unsigned stages)
+{
+    R.nref = 0;
+    if (stages & 4u)
+        for (float dz = P->max_disp / 2.0f; dz >= 0.01f; dz = dz / 10.0f) R.nref++;
+    R.view.x = R.view.y = R.view.z = 0.f;
+    R.pre = 0;
+    R.draw = 0;
+    R.deltaN = 1.0f;
+    R.deltaZ = P->max_disp / 2.0f;
+}
+// after the propagation accepts: the refine kernel re-derives the depth (:1660) and seeds its draws
+__device__ __forceinline__ void refine_begin(RefineDraws &R, SweepLane &L, const Problem *__restrict__ P,
+                                             uint32_t phase)
+{
+    if (R.nref > 0 && L.active) {
+        L.depth = depth_from_plane(P->rc, L.pl, L.px, L.py);
+        R.view = view_vector(P->rc, L.px, L.py);
+        R.pre = rng_prefix(P->seed, phase, (uint32_t)L.px, (uint32_t)L.py);
+    }
+}
+// the candidate of the current step for an active lane (four draws)
+__device__ __forceinline__ float4 refine_candidate(RefineDraws &R, const SweepLane &L,
+                                                   const Problem *__restrict__ P, float &d_new)
+{
+    const RefCam &rc = P->rc;
+    const float min_disp = P->min_disp, max_disp = P->max_disp;
+    const float disp = disp_depth(rc.f, rc.baseline, L.depth);
+    const float minDelta = -__builtin_fminf(R.deltaZ, min_disp + disp);  // sic, :909
+    const float maxDelta = __builtin_fminf(R.deltaZ, max_disp - disp);
+    const float u0 = rng_uniform(R.pre, R.draw++);
+    const float u1 = rng_uniform(R.pre, R.draw++);
+    const float u2 = rng_uniform(R.pre, R.draw++);
+    const float u3 = rng_uniform(R.pre, R.draw++);
+    const float dz = between(u0, minDelta, maxDelta);
+    const float dispOut = __builtin_fminf(__builtin_fmaxf(disp + dz, min_disp), max_disp);
+    d_new = disp_depth(rc.f, rc.baseline, dispOut);
+    Vec3 n;
+    n.x = L.pl.x + between(u1, -R.deltaN, R.deltaN);
+    n.y = L.pl.y + between(u2, -R.deltaN, R.deltaN);
+    n.z = L.pl.z + between(u3, -R.deltaN, R.deltaN);
+    n = on_hemisphere(normalize3(n), R.view);
+    return make_float4(n.x, n.y, n.z, plane_d(rc, n, L.px, L.py, d_new));
+}
+__device__ __forceinline__ void refine_next_step(RefineDraws &R)
+{
+    R.deltaN = R.deltaN / 4.0f;
+    R.deltaZ = R.deltaZ / 10.0f;
+}
+// pixel of task-list owner `owner` (a lane id of this workgroup)
+__device__ __forceinline__ void owner_pixel(const SweepLane &L, int owner, int colour, int &olx, int &oly)
+{
+    oly = owner >> 4;
+    olx = 2 * (owner & 15) + ((oly + colour) & 1);
+}
+
 // (the packed-gray instantiations are held at 128 VGPRs = 4 wavefronts per SIMD)
 template <int BOX, bool U8, bool COMBINE_REG, bool INTERIOR, int CH>
 __global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kernel(const Problem *__restrict__ P,
@@ -1284,520 +1554,147 @@ __global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kerne
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const Win<BOX> win(P);
-    const RefCam &rc = P->rc;
     const int rows = P->rows, cols = P->cols;
-    const int gx = (cols + kTileW - 1) / kTileW;
-    const int gy = (rows + kSweepTileH - 1) / kSweepTileH;
-    const TileXY txy = tile_of(blockIdx.x, gx, gy, tune);
-    const int x0 = txy.x * kTileW, y0 = txy.y * kSweepTileH;
-    stage_tile<BOX, CH>(P, lds, x0, y0, kSweepTileH, win, U8);
-    const int hw = win.halo_w(), hh = win.halo_h();
-    const int tw = kTileW + 2 * hw, th = kSweepTileH + 2 * hh;
-    const float *tile = lds + lut_size<CH>();
-    float *work = lds + lut_size<CH>() + 4 * tw * th;
-    float *cv = work + work_floats<CH>(tw * th, true) + threadIdx.x;
-    // (gray: the staging plane inside `work` is dead after stage_tile's last barrier)
-    const int wave = threadIdx.x >> 6;
-    float *bres = work;                                                           // [8][256] costs
-    unsigned short *btask = reinterpret_cast<unsigned short *>(work + 8 * kThreads);  // [2048] tid | slot << 8
-    int *wcnt = reinterpret_cast<int *>(work + 8 * kThreads + (8 * kThreads) / 2);  // [4 waves][8 slots]
-
-    // lane -> pixel: 16 pixels of the colour per tile row; a wavefront covers 4 rows x 32 columns
-    const int ly = threadIdx.x >> 4;
-    const int lx = 2 * (threadIdx.x & 15) + ((ly + colour) & 1);  // tile origin is even in x and y
-    const int px = x0 + lx, py = y0 + ly;
-    const bool active = px < cols && py < rows;
-    const int center = py * cols + px;
-    const bool trust = !(tune & Tune::kUntrustedCosts);
-
-    // read state (gipuma.cu:1527-1530)
-    float4 pl = make_float4(0.f, 0.f, 0.f, 0.f);
-    float cst = 0.f, depth = 0.f;
-    unsigned needmask = 0;  // candidate slots of this pixel that must be evaluated
-    if (active) {
-        pl = norm4[center];
-        cst = cost[center];
-        depth = depth_from_plane(rc, pl, px, py);
-        float4 cands[8];
-        unsigned valid = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            int nb;
-            const bool ok = neighbour(k, px, py, rows, cols, center, nb) && (stages & (k < 4 ? 1u : 2u));
-            if (ok) {
-                cands[k] = norm4[nb];
-                valid |= 1u << k;
-            }
-        }
-        if (tune & Tune::kNoSkip) {
-            needmask = valid;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                bool fresh = (valid >> k) & 1u;
-                if (fresh && trust && same_bits(cands[k], pl)) fresh = false;  // (A)
-#pragma unroll
-                for (int j = 0; j < k; j++)
-                    if (fresh && ((valid >> j) & 1u) && same_bits(cands[k], cands[j])) fresh = false;  // (D)
-                if (fresh) needmask |= 1u << k;
-            }
-        }
-    }
-    // Workgroup task list.  Two orders, same set of tasks (the order cannot change a result: a task
-    // is a pure function of (pixel, plane) and its cost lands in bres[slot][owner]):
-    //  * source-major (default): tasks that evaluate the SAME plane -- the plane of other-colour
-    //    pixel q is a candidate of q+-1 and q+-5 in x and y -- are adjacent, so the lanes of a
-    //    wavefront that share a plane read source windows a few pixels apart, i.e. the same cache
-    //    lines, even while the planes themselves are still random.  A divergent window load costs
-    //    the vector L1 two clocks per distinct 128-byte line (scripts/ubench/l1_window_rate.hip);
-    //    the first half-sweeps are bound by exactly that.  Built as a counting sort keyed by q's
-    //    position in the tile extended by the 5-pixel propagation reach.
-    //  * owner-major (Tune::kOwnerMajorTasks): a pixel's surviving candidates adjacent, pixels in
-    //    lane order: a wavefront-level inclusive scan of the per-lane counts.
-    int n_tasks;
-    if (tune & Tune::kOwnerMajorTasks) {
-        const int cnt = __popc(needmask);
-        int incl = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int up = __shfl_up(incl, d);
-            if ((int)(threadIdx.x & 63) >= d) incl += up;
-        }
-        if ((threadIdx.x & 63) == 63) wcnt[wave] = incl;
-        __syncthreads();
-        const int c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
-        int pos0 = incl - cnt + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
-        n_tasks = c0 + c1 + c2 + c3;
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            if ((needmask >> k) & 1u) btask[pos0++] = (unsigned short)(threadIdx.x | (k << 8));
-        __syncthreads();
-    } else {
-        constexpr int kReach = 5, kExtW = kTileW + 2 * kReach, kExtH = kSweepTileH + 2 * kReach;
-        constexpr int kCells = kExtW * kExtH, kPerLane = (kCells + kThreads - 1) / kThreads;
-        static_assert(kCells <= 8 * kThreads, "the histogram aliases bres");
-        int *hist = reinterpret_cast<int *>(bres);  // bres is not written before the first round
-        for (int c = threadIdx.x; c < kCells; c += kThreads) hist[c] = 0;
-        __syncthreads();
-        unsigned ranks = 0;  // 3 bits per slot: at most 8 tasks share a source pixel
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if ((needmask >> k) & 1u) {
-                const int dist = k < 4 ? 1 : 5;
-                const int qx = lx + ((k & 3) == 2 ? -dist : (k & 3) == 3 ? dist : 0) + kReach;
-                const int qy = ly + ((k & 3) == 0 ? -dist : (k & 3) == 1 ? dist : 0) + kReach;
-                ranks |= (unsigned)atomicAdd(&hist[qy * kExtW + qx], 1) << (3 * k);
-            }
-        }
-        __syncthreads();
-        // exclusive prefix sum of the histogram, kPerLane consecutive cells per lane
-        int loc[kPerLane];
-        int sum = 0;
-#pragma unroll
-        for (int e = 0; e < kPerLane; e++) {
-            const int c = threadIdx.x * kPerLane + e;
-            loc[e] = c < kCells ? hist[c] : 0;
-            sum += loc[e];
-        }
-        int incl = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int up = __shfl_up(incl, d);
-            if ((int)(threadIdx.x & 63) >= d) incl += up;
-        }
-        if ((threadIdx.x & 63) == 63) wcnt[wave] = incl;
-        __syncthreads();
-        const int c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
-        int run = incl - sum + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
-        n_tasks = c0 + c1 + c2 + c3;
-#pragma unroll
-        for (int e = 0; e < kPerLane; e++) {
-            const int c = threadIdx.x * kPerLane + e;
-            if (c < kCells) hist[c] = run;
-            run += loc[e];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if ((needmask >> k) & 1u) {
-                const int dist = k < 4 ? 1 : 5;
-                const int qx = lx + ((k & 3) == 2 ? -dist : (k & 3) == 3 ? dist : 0) + kReach;
-                const int qy = ly + ((k & 3) == 0 ? -dist : (k & 3) == 1 ? dist : 0) + kReach;
-                btask[hist[qy * kExtW + qx] + (int)((ranks >> (3 * k)) & 7u)] =
-                    (unsigned short)(threadIdx.x | (k << 8));
-            }
-        }
-        __syncthreads();  // also orders the last reads of `hist` before bres is written
-    }
-    const int prop_rounds = (n_tasks + kThreads - 1) / kThreads;
-
-    // planeRefinement_cu + getRndDispAndUnitVector_cu, gipuma.cu:928-994, 890-927
-    const float min_disp = P->min_disp, max_disp = P->max_disp;
-    int nref = 0;  // number of refinement steps: deltaZ = max_disp/2, /10 ... >= 0.01 (:958-959)
-    if (stages & 4u)
-        for (float dz = max_disp / 2.0f; dz >= 0.01f; dz = dz / 10.0f) nref++;
-    Vec3 view = {0.f, 0.f, 0.f};
-    uint32_t pre = 0, draw = 0;
-    float deltaN = 1.0f, deltaZ = max_disp / 2.0f;
+    SweepLane L;
+    sweep_setup<BOX, CH>(L, P, lds, norm4, cost, colour, stages, tune, U8);
+    const int prop_rounds = (L.n_tasks + kThreads - 1) / kThreads;
+    RefineDraws R;
+    refine_init(R, P, stages);
 
     // One loop, one call site of the cost function: rounds [0, prop_rounds) evaluate compacted
     // propagation tasks (possibly of another lane's pixel), then the owner replays its accepts,
     // then rounds [prop_rounds, prop_rounds + nref) are the lane's own refinement steps.
-    for (int r = 0; r <= prop_rounds + nref; r++) {
+    for (int r = 0; r <= prop_rounds + R.nref; r++) {
         if (r == prop_rounds) {
-            // replay: spatialPropagation_cu's accept test (gipuma.cu:865-872) in slot order
             __syncthreads();  // every wavefront runs the same number of rounds, so this is uniform
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                if ((needmask >> k) & 1u) {
-                    int nb;
-                    neighbour(k, px, py, rows, cols, center, nb);
-                    const float4 cand = norm4[nb];
-                    const float c = bres[k * kThreads + threadIdx.x];
-                    const float d_new = depth_from_plane(rc, cand, px, py);
-                    if (d_new >= rc.depth_min && d_new <= rc.depth_max && c < cst) {  // :829-830, :868
-                        depth = d_new;
-                        pl = cand;
-                        cst = c;
-                    }
-                }
-            }
-            if (nref > 0 && active) {
-                depth = depth_from_plane(rc, pl, px, py);  // the refine kernel re-derives it, :1660
-                view = view_vector(rc, px, py);
-                pre = rng_prefix(P->seed, phase, (uint32_t)px, (uint32_t)py);
-            }
+            sweep_replay(L, P, norm4);
+            refine_begin(R, L, P, phase);
         }
-        if (r == prop_rounds + nref) break;
+        if (r == prop_rounds + R.nref) break;
 
         bool do_eval;
         float4 cand = make_float4(0.f, 0.f, -1.f, 1.f);
-        int epx = px, epy = py, slot = 0, owner = threadIdx.x;
+        int epx = L.px, epy = L.py, slot = 0, owner = threadIdx.x;
         float d_new = 0.f;
         if (r < prop_rounds) {
             const int pos = r * kThreads + threadIdx.x;
-            do_eval = pos < n_tasks;
+            do_eval = pos < L.n_tasks;
             if (do_eval) {
-                const unsigned t = btask[pos];
+                const unsigned t = L.btask[pos];
                 owner = (int)(t & 255u);
                 slot = (int)(t >> 8);
-                const int oly = owner >> 4;
-                const int olx = 2 * (owner & 15) + ((oly + colour) & 1);
-                epx = x0 + olx;
-                epy = y0 + oly;
+                int olx, oly;
+                owner_pixel(L, owner, colour, olx, oly);
+                epx = L.x0 + olx;
+                epy = L.y0 + oly;
                 int nb;
                 neighbour(slot, epx, epy, rows, cols, epy * cols + epx, nb);
                 cand = norm4[nb];
             }
         } else {
-            do_eval = active;
-            if (do_eval) {
-                const float disp = disp_depth(rc.f, rc.baseline, depth);
-                const float minDelta = -__builtin_fminf(deltaZ, min_disp + disp);  // sic, :909
-                const float maxDelta = __builtin_fminf(deltaZ, max_disp - disp);
-                const float u0 = rng_uniform(pre, draw++);
-                const float u1 = rng_uniform(pre, draw++);
-                const float u2 = rng_uniform(pre, draw++);
-                const float u3 = rng_uniform(pre, draw++);
-                const float dz = between(u0, minDelta, maxDelta);
-                const float dispOut = __builtin_fminf(__builtin_fmaxf(disp + dz, min_disp), max_disp);
-                d_new = disp_depth(rc.f, rc.baseline, dispOut);
-                Vec3 n;
-                n.x = pl.x + between(u1, -deltaN, deltaN);
-                n.y = pl.y + between(u2, -deltaN, deltaN);
-                n.z = pl.z + between(u3, -deltaN, deltaN);
-                n = on_hemisphere(normalize3(n), view);
-                cand = make_float4(n.x, n.y, n.z, plane_d(rc, n, px, py, d_new));
-            }
-            deltaN = deltaN / 4.0f;
-            deltaZ = deltaZ / 10.0f;
+            do_eval = L.active;
+            if (do_eval) cand = refine_candidate(R, L, P, d_new);
+            refine_next_step(R);
         }
         if (do_eval) {
-            const float *etp0 = tile + (((epy - y0) + hh) * tw + ((epx - x0) + hw)) * 4;
+            const float *etp0 = L.tile + (((epy - L.y0) + L.hh) * L.tw + ((epx - L.x0) + L.hw)) * 4;
             const float c =
-                multiview_cost<BOX, U8, INTERIOR, COMBINE_REG, CH>(P, etp0, tw, lds, cv, epx, epy, cand, win);
+                multiview_cost<BOX, U8, INTERIOR, COMBINE_REG, CH>(P, etp0, L.tw, lds, L.cv, epx, epy, cand, win);
             if (r < prop_rounds) {
-                bres[slot * kThreads + owner] = c;
-            } else if (c < cst) {  // refinement has no depth-range test, :986
-                depth = d_new;
-                pl = cand;
-                cst = c;
+                L.bres[slot * kThreads + owner] = c;
+            } else if (c < L.cst) {  // refinement has no depth-range test, :986
+                L.depth = d_new;
+                L.pl = cand;
+                L.cst = c;
             }
         }
     }
 
     // write back (gipuma.cu:1585-1587): 16 B + 4 B per active pixel
-    if (active) {
-        cost[center] = cst;
-        norm4[center] = pl;
+    if (L.active) {
+        cost[L.center] = L.cst;
+        norm4[L.center] = L.pl;
     }
 }
 
 // The same half-sweep with the column-per-lane evaluation (see view_cost_cols): state, candidate
 // selection, task list, accept replay and refinement candidates are computed per pixel by its owner
-// lane exactly as in sweep_kernel; only the cost evaluations are done by groups of kColGroup lanes,
-// kColTasks (pixel, plane) pairs at a time, exchanging planes and costs through LDS.  Gray packed
-// planes with float-encoded offsets and a compile-time box of at most 15 only (the host uses it for
-// box 15, whose 8 columns fill a group).
+// lane exactly as in sweep_kernel (the shared helpers above); only the cost evaluations are done by
+// groups of kColGroup lanes, kColTasks (pixel, plane) pairs at a time, exchanging planes and costs
+// through LDS.  Gray packed planes with float-encoded offsets and a compile-time box of at most 15
+// only (the host uses it for box 15, whose 8 columns fill a group).
 template <int BOX, bool COMBINE_REG>
 __global__ __launch_bounds__(kThreads) void sweep_cols_kernel(const Problem *__restrict__ P,
-                                                         float4 *__restrict__ norm4, float *__restrict__ cost,
-                                                         int colour, uint32_t phase, unsigned stages,
-                                                         unsigned tune)
+                                                              float4 *__restrict__ norm4, float *__restrict__ cost,
+                                                              int colour, uint32_t phase, unsigned stages,
+                                                              unsigned tune)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const Win<BOX> win(P);
-    const RefCam &rc = P->rc;
-    const int rows = P->rows, cols = P->cols;
-    const int gx = (cols + kTileW - 1) / kTileW;
-    const int gy = (rows + kSweepTileH - 1) / kSweepTileH;
-    const TileXY txy = tile_of(blockIdx.x, gx, gy, tune);
-    const int x0 = txy.x * kTileW, y0 = txy.y * kSweepTileH;
     constexpr int CH = 1;
-    stage_tile<BOX, CH>(P, lds, x0, y0, kSweepTileH, win, true);
-    const int hw = win.halo_w(), hh = win.halo_h();
-    const int tw = kTileW + 2 * hw, th = kSweepTileH + 2 * hh;
-    const float *tile = lds + lut_size<CH>();
-    float *work = lds + lut_size<CH>() + 4 * tw * th;
-    float *cv = work + work_floats<CH>(tw * th, true) + threadIdx.x;
-    // (gray: the staging plane inside `work` is dead after stage_tile's last barrier)
-    const int wave = threadIdx.x >> 6;
-    float *bres = work;                                                           // [8][256] costs
-    unsigned short *btask = reinterpret_cast<unsigned short *>(work + 8 * kThreads);  // [2048] tid | slot << 8
-    int *wcnt = reinterpret_cast<int *>(work + 8 * kThreads + (8 * kThreads) / 2);  // [4 waves][8 slots]
-
-    // lane -> pixel: 16 pixels of the colour per tile row; a wavefront covers 4 rows x 32 columns
-    const int ly = threadIdx.x >> 4;
-    const int lx = 2 * (threadIdx.x & 15) + ((ly + colour) & 1);  // tile origin is even in x and y
-    const int px = x0 + lx, py = y0 + ly;
-    const bool active = px < cols && py < rows;
-    const int center = py * cols + px;
-    const bool trust = !(tune & Tune::kUntrustedCosts);
-
-    // read state (gipuma.cu:1527-1530)
-    float4 pl = make_float4(0.f, 0.f, 0.f, 0.f);
-    float cst = 0.f, depth = 0.f;
-    unsigned needmask = 0;  // candidate slots of this pixel that must be evaluated
-    if (active) {
-        pl = norm4[center];
-        cst = cost[center];
-        depth = depth_from_plane(rc, pl, px, py);
-        float4 cands[8];
-        unsigned valid = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            int nb;
-            const bool ok = neighbour(k, px, py, rows, cols, center, nb) && (stages & (k < 4 ? 1u : 2u));
-            if (ok) {
-                cands[k] = norm4[nb];
-                valid |= 1u << k;
-            }
-        }
-        if (tune & Tune::kNoSkip) {
-            needmask = valid;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                bool fresh = (valid >> k) & 1u;
-                if (fresh && trust && same_bits(cands[k], pl)) fresh = false;  // (A)
-#pragma unroll
-                for (int j = 0; j < k; j++)
-                    if (fresh && ((valid >> j) & 1u) && same_bits(cands[k], cands[j])) fresh = false;  // (D)
-                if (fresh) needmask |= 1u << k;
-            }
-        }
-    }
-    // Workgroup task list.  Two orders, same set of tasks (the order cannot change a result: a task
-    // is a pure function of (pixel, plane) and its cost lands in bres[slot][owner]):
-    //  * source-major (default): tasks that evaluate the SAME plane -- the plane of other-colour
-    //    pixel q is a candidate of q+-1 and q+-5 in x and y -- are adjacent, so the lanes of a
-    //    wavefront that share a plane read source windows a few pixels apart, i.e. the same cache
-    //    lines, even while the planes themselves are still random.  A divergent window load costs
-    //    the vector L1 two clocks per distinct 128-byte line (scripts/ubench/l1_window_rate.hip);
-    //    the first half-sweeps are bound by exactly that.  Built as a counting sort keyed by q's
-    //    position in the tile extended by the 5-pixel propagation reach.
-    //  * owner-major (Tune::kOwnerMajorTasks): a pixel's surviving candidates adjacent, pixels in
-    //    lane order: a wavefront-level inclusive scan of the per-lane counts.
-    int n_tasks;
-    if (tune & Tune::kOwnerMajorTasks) {
-        const int cnt = __popc(needmask);
-        int incl = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int up = __shfl_up(incl, d);
-            if ((int)(threadIdx.x & 63) >= d) incl += up;
-        }
-        if ((threadIdx.x & 63) == 63) wcnt[wave] = incl;
-        __syncthreads();
-        const int c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
-        int pos0 = incl - cnt + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
-        n_tasks = c0 + c1 + c2 + c3;
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            if ((needmask >> k) & 1u) btask[pos0++] = (unsigned short)(threadIdx.x | (k << 8));
-        __syncthreads();
-    } else {
-        constexpr int kReach = 5, kExtW = kTileW + 2 * kReach, kExtH = kSweepTileH + 2 * kReach;
-        constexpr int kCells = kExtW * kExtH, kPerLane = (kCells + kThreads - 1) / kThreads;
-        static_assert(kCells <= 8 * kThreads, "the histogram aliases bres");
-        int *hist = reinterpret_cast<int *>(bres);  // bres is not written before the first round
-        for (int c = threadIdx.x; c < kCells; c += kThreads) hist[c] = 0;
-        __syncthreads();
-        unsigned ranks = 0;  // 3 bits per slot: at most 8 tasks share a source pixel
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if ((needmask >> k) & 1u) {
-                const int dist = k < 4 ? 1 : 5;
-                const int qx = lx + ((k & 3) == 2 ? -dist : (k & 3) == 3 ? dist : 0) + kReach;
-                const int qy = ly + ((k & 3) == 0 ? -dist : (k & 3) == 1 ? dist : 0) + kReach;
-                ranks |= (unsigned)atomicAdd(&hist[qy * kExtW + qx], 1) << (3 * k);
-            }
-        }
-        __syncthreads();
-        // exclusive prefix sum of the histogram, kPerLane consecutive cells per lane
-        int loc[kPerLane];
-        int sum = 0;
-#pragma unroll
-        for (int e = 0; e < kPerLane; e++) {
-            const int c = threadIdx.x * kPerLane + e;
-            loc[e] = c < kCells ? hist[c] : 0;
-            sum += loc[e];
-        }
-        int incl = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int up = __shfl_up(incl, d);
-            if ((int)(threadIdx.x & 63) >= d) incl += up;
-        }
-        if ((threadIdx.x & 63) == 63) wcnt[wave] = incl;
-        __syncthreads();
-        const int c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
-        int run = incl - sum + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
-        n_tasks = c0 + c1 + c2 + c3;
-#pragma unroll
-        for (int e = 0; e < kPerLane; e++) {
-            const int c = threadIdx.x * kPerLane + e;
-            if (c < kCells) hist[c] = run;
-            run += loc[e];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if ((needmask >> k) & 1u) {
-                const int dist = k < 4 ? 1 : 5;
-                const int qx = lx + ((k & 3) == 2 ? -dist : (k & 3) == 3 ? dist : 0) + kReach;
-                const int qy = ly + ((k & 3) == 0 ? -dist : (k & 3) == 1 ? dist : 0) + kReach;
-                btask[hist[qy * kExtW + qx] + (int)((ranks >> (3 * k)) & 7u)] =
-                    (unsigned short)(threadIdx.x | (k << 8));
-            }
-        }
-        __syncthreads();  // also orders the last reads of `hist` before bres is written
-    }
-
-    // planeRefinement_cu + getRndDispAndUnitVector_cu, gipuma.cu:928-994, 890-927
-    const float min_disp = P->min_disp, max_disp = P->max_disp;
-    int nref = 0;  // number of refinement steps: deltaZ = max_disp/2, /10 ... >= 0.01 (:958-959)
-    if (stages & 4u)
-        for (float dz = max_disp / 2.0f; dz >= 0.01f; dz = dz / 10.0f) nref++;
-    Vec3 view = {0.f, 0.f, 0.f};
-    uint32_t pre = 0, draw = 0;
-    float deltaN = 1.0f, deltaZ = max_disp / 2.0f;
+    const int rows = P->rows, cols = P->cols;
+    SweepLane L;
+    sweep_setup<BOX, CH>(L, P, lds, norm4, cost, colour, stages, tune, true);
+    RefineDraws R;
+    refine_init(R, P, stages);
 
     // propagation: kColTasks tasks per round, one group of lanes each
     const int grp = threadIdx.x / kColGroup, col = threadIdx.x % kColGroup;
-    const int prop_rounds_c = (n_tasks + kColTasks - 1) / kColTasks;
+    const int prop_rounds_c = (L.n_tasks + kColTasks - 1) / kColTasks;
     for (int r = 0; r < prop_rounds_c; r++) {
         const int pos = r * kColTasks + grp;
-        const bool have = pos < n_tasks;
-        const unsigned t = btask[have ? pos : 0];
+        const bool have = pos < L.n_tasks;
+        const unsigned t = L.btask[have ? pos : 0];
         const int owner = (int)(t & 255u), slot = (int)(t >> 8);
-        const int oly = owner >> 4;
-        const int olx = 2 * (owner & 15) + ((oly + colour) & 1);
-        const int epx = x0 + olx, epy = y0 + oly;
+        int olx, oly;
+        owner_pixel(L, owner, colour, olx, oly);
+        const int epx = L.x0 + olx, epy = L.y0 + oly;
         int nb;
         neighbour(slot, epx, epy, rows, cols, epy * cols + epx, nb);
         const float4 cand = norm4[nb];
-        const float *etp0 = tile + ((oly + hh) * tw + (olx + hw)) * 4;
-        const float c = multiview_cost_cols<BOX, COMBINE_REG>(P, etp0, tw, lds, cv, epx, epy, cand, col);
-        if (have && col == 0) bres[slot * kThreads + owner] = c;
+        const float *etp0 = L.tile + ((oly + L.hh) * L.tw + (olx + L.hw)) * 4;
+        const float c = multiview_cost_cols<BOX, COMBINE_REG>(P, etp0, L.tw, lds, L.cv, epx, epy, cand, col);
+        if (have && col == 0) L.bres[slot * kThreads + owner] = c;
     }
     __syncthreads();
-    // replay: spatialPropagation_cu's accept test (gipuma.cu:865-872) in slot order, by the owner
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        if ((needmask >> k) & 1u) {
-            int nb;
-            neighbour(k, px, py, rows, cols, center, nb);
-            const float4 cand = norm4[nb];
-            const float c = bres[k * kThreads + threadIdx.x];
-            const float d_new = depth_from_plane(rc, cand, px, py);
-            if (d_new >= rc.depth_min && d_new <= rc.depth_max && c < cst) {  // :829-830, :868
-                depth = d_new;
-                pl = cand;
-                cst = c;
-            }
-        }
-    }
-    if (nref > 0 && active) {
-        depth = depth_from_plane(rc, pl, px, py);  // the refine kernel re-derives it, :1660
-        view = view_vector(rc, px, py);
-        pre = rng_prefix(P->seed, phase, (uint32_t)px, (uint32_t)py);
-    }
+    sweep_replay(L, P, norm4);
+    refine_begin(R, L, P, phase);
     // refinement steps: the owner draws its candidate, groups evaluate all 256, the owner accepts
-    float4 *candbuf = reinterpret_cast<float4 *>(btask);  // the task list is dead now (same 4 KB)
-    for (int step = 0; step < nref; step++) {
+    float4 *candbuf = reinterpret_cast<float4 *>(L.btask);  // the task list is dead now (same 4 KB)
+    for (int step = 0; step < R.nref; step++) {
         float4 cand = make_float4(0.f, 0.f, -1.f, 1.f);
         float d_new = 0.f;
-        if (active) {
-            const float disp = disp_depth(rc.f, rc.baseline, depth);
-            const float minDelta = -__builtin_fminf(deltaZ, min_disp + disp);  // sic, :909
-            const float maxDelta = __builtin_fminf(deltaZ, max_disp - disp);
-            const float u0 = rng_uniform(pre, draw++);
-            const float u1 = rng_uniform(pre, draw++);
-            const float u2 = rng_uniform(pre, draw++);
-            const float u3 = rng_uniform(pre, draw++);
-            const float dz = between(u0, minDelta, maxDelta);
-            const float dispOut = __builtin_fminf(__builtin_fmaxf(disp + dz, min_disp), max_disp);
-            d_new = disp_depth(rc.f, rc.baseline, dispOut);
-            Vec3 n;
-            n.x = pl.x + between(u1, -deltaN, deltaN);
-            n.y = pl.y + between(u2, -deltaN, deltaN);
-            n.z = pl.z + between(u3, -deltaN, deltaN);
-            n = on_hemisphere(normalize3(n), view);
-            cand = make_float4(n.x, n.y, n.z, plane_d(rc, n, px, py, d_new));
-        }
-        deltaN = deltaN / 4.0f;
-        deltaZ = deltaZ / 10.0f;
+        if (L.active) cand = refine_candidate(R, L, P, d_new);
+        refine_next_step(R);
         __syncthreads();  // the previous step's reads of bres / candbuf are done
         candbuf[threadIdx.x] = cand;
         __syncthreads();
         for (int r = 0; r < kThreads / kColTasks; r++) {
             const int owner = r * kColTasks + grp;
-            const int oly = owner >> 4;
-            const int olx = 2 * (owner & 15) + ((oly + colour) & 1);
+            int olx, oly;
+            owner_pixel(L, owner, colour, olx, oly);
             // pixels outside the image (ragged last tile) evaluate their dummy plane at the clamped
             // position: harmless, never read back
-            const int epx = min(x0 + olx, cols - 1), epy = min(y0 + oly, rows - 1);
+            const int epx = min(L.x0 + olx, cols - 1), epy = min(L.y0 + oly, rows - 1);
             const float4 ecand = candbuf[owner];
-            const float *etp0 = tile + (((epy - y0) + hh) * tw + ((epx - x0) + hw)) * 4;
-            const float c = multiview_cost_cols<BOX, COMBINE_REG>(P, etp0, tw, lds, cv, epx, epy, ecand, col);
-            if (col == 0) bres[owner] = c;
+            const float *etp0 = L.tile + (((epy - L.y0) + L.hh) * L.tw + ((epx - L.x0) + L.hw)) * 4;
+            const float c = multiview_cost_cols<BOX, COMBINE_REG>(P, etp0, L.tw, lds, L.cv, epx, epy, ecand, col);
+            if (col == 0) L.bres[owner] = c;
         }
         __syncthreads();
-        if (active) {
-            const float c = bres[threadIdx.x];
-            if (c < cst) {  // refinement has no depth-range test, :986
-                depth = d_new;
-                pl = cand;
-                cst = c;
+        if (L.active) {
+            const float c = L.bres[threadIdx.x];
+            if (c < L.cst) {  // refinement has no depth-range test, :986
+                L.depth = d_new;
+                L.pl = cand;
+                L.cst = c;
             }
         }
     }
 
-    // write back (gipuma.cu:1585-1587): 16 B + 4 B per active pixel
-    if (active) {
-        cost[center] = cst;
-        norm4[center] = pl;
+    // write back (gipuma.cu:1585-1587)
+    if (L.active) {
+        cost[L.center] = L.cst;
+        norm4[L.center] = L.pl;
     }
 }
 
