@@ -789,24 +789,17 @@ __device__ __forceinline__ float view_cost_c4(const Problem *__restrict__ P, con
     return view_cost_c4_loop<BOX, U8, false>(P, vc, H, tp0, tw, lut, px, py, win);
 }
 
-// pmCostMultiview_cu, gipuma.cu:720-806.  COMBINE_REG: best-N with n_best <= 4 keeps the four
-// smallest view costs in registers (a sorting-network insert per view, same values and the same
-// ascending summation order as sort_small + the loop at :781-797); otherwise the view costs go
-// through a per-lane LDS column and the literal insertion sort.
-template <int BOX, bool U8, bool INTERIOR, bool COMBINE_REG, int CH>
-__device__ __forceinline__ float multiview_cost(const Problem *__restrict__ P, const float *__restrict__ tp0,
-                                                int tw, const float *__restrict__ lut, float *cv, int px,
-                                                int py, float4 pl, const Win<BOX> &win)
-{
-    const int n = P->n_sel;
+// Accumulation of the per-view costs of pmCostMultiview_cu (gipuma.cu:771-805), shared by the
+// pixel-per-lane and the column-per-lane evaluation.  COMBINE_REG: best-N with n_best <= 4 keeps the
+// four smallest view costs in registers (a sorting-network insert per view, same values and the
+// same ascending summation order as sort_small + the loop at :781-797); otherwise the view costs go
+// through a per-lane LDS column `cv` and the literal insertion sort.
+template <bool COMBINE_REG>
+struct ViewCombiner {
     int numValid = 0;
     float b0 = kMaxCost, b1 = kMaxCost, b2 = kMaxCost, b3 = kMaxCost;
-    for (int v = 0; v < n; v++) {
-        float c;
-        if (CH == 4)
-            c = view_cost_c4<BOX, U8>(P, P->view[v], tp0, tw, lut, px, py, pl, win);
-        else
-            c = view_cost<BOX, U8, INTERIOR>(P, P->view[v], tp0, tw, lut, px, py, pl, win);
+    __device__ __forceinline__ void add(float c, int v, float *cv)
+    {
         if (c < kMaxCost)
             numValid++;
         else
@@ -824,31 +817,53 @@ __device__ __forceinline__ float multiview_cost(const Problem *__restrict__ P, c
             cv[j * kThreads] = c;
         }
     }
-    float cost = 0.0f;
-    int numConsidered = 0;
-    if (COMBINE_REG) {
-        const int numBest = min(numValid, P->n_best);
-        if (numBest > 0) cost = cost + b0;
-        if (numBest > 1) cost = cost + b1;
-        if (numBest > 2) cost = cost + b2;
-        if (numBest > 3) cost = cost + b3;
-        numConsidered = numBest;
-    } else {
-        int numBest = numValid;
-        if (P->cost_comb == 1) numBest = min(numBest, P->n_best);  // COMB_BEST_N
-        if (P->cost_comb == 3) numBest = n;                        // COMB_GOOD
-        const float costThresh = (n > 0 ? cv[0] : 0.0f) * P->good_factor;
-        for (int i = 0; i < numBest; i++) {
-            numConsidered++;
-            float c = cv[i * kThreads];
-            if (P->cost_comb == 3) c = __builtin_fminf(c, costThresh);
-            cost = cost + c;
+    __device__ __forceinline__ float finish(const Problem *__restrict__ P, int n, const float *cv) const
+    {
+        float cost = 0.0f;
+        int numConsidered = 0;
+        if (COMBINE_REG) {
+            const int numBest = min(numValid, P->n_best);
+            if (numBest > 0) cost = cost + b0;
+            if (numBest > 1) cost = cost + b1;
+            if (numBest > 2) cost = cost + b2;
+            if (numBest > 3) cost = cost + b3;
+            numConsidered = numBest;
+        } else {
+            int numBest = numValid;
+            if (P->cost_comb == 1) numBest = min(numBest, P->n_best);  // COMB_BEST_N
+            if (P->cost_comb == 3) numBest = n;                        // COMB_GOOD
+            const float costThresh = (n > 0 ? cv[0] : 0.0f) * P->good_factor;
+            for (int i = 0; i < numBest; i++) {
+                numConsidered++;
+                float c = cv[i * kThreads];
+                if (P->cost_comb == 3) c = __builtin_fminf(c, costThresh);
+                cost = cost + c;
+            }
         }
+        cost = cost / ((float)numConsidered);
+        if (numConsidered < 1) cost = kMaxCost;
+        if (cost != cost || cost > kMaxCost || cost < 0) cost = kMaxCost;
+        return cost;
     }
-    cost = cost / ((float)numConsidered);
-    if (numConsidered < 1) cost = kMaxCost;
-    if (cost != cost || cost > kMaxCost || cost < 0) cost = kMaxCost;
-    return cost;
+};
+
+// pmCostMultiview_cu, gipuma.cu:720-806
+template <int BOX, bool U8, bool INTERIOR, bool COMBINE_REG, int CH>
+__device__ __forceinline__ float multiview_cost(const Problem *__restrict__ P, const float *__restrict__ tp0,
+                                                int tw, const float *__restrict__ lut, float *cv, int px,
+                                                int py, float4 pl, const Win<BOX> &win)
+{
+    const int n = P->n_sel;
+    ViewCombiner<COMBINE_REG> comb;
+    for (int v = 0; v < n; v++) {
+        float c;
+        if (CH == 4)
+            c = view_cost_c4<BOX, U8>(P, P->view[v], tp0, tw, lut, px, py, pl, win);
+        else
+            c = view_cost<BOX, U8, INTERIOR>(P, P->view[v], tp0, tw, lut, px, py, pl, win);
+        comb.add(c, v, cv);
+    }
+    return comb.finish(P, n, cv);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -945,7 +960,7 @@ __device__ __forceinline__ float view_cost_cols(const Problem *__restrict__ P, c
 }
 
 // pmCostMultiview_cu for one (pixel, plane) pair evaluated by a group of kColGroup lanes; the
-// result is exact in every lane of the group (same combination code as multiview_cost)
+// result is exact in every lane of the group
 template <int BOX, bool COMBINE_REG>
 __device__ __forceinline__ float multiview_cost_cols(const Problem *__restrict__ P, const float *__restrict__ tp0,
                                                      int tw, const float *__restrict__ lut, float *cv, int px,
@@ -953,8 +968,7 @@ __device__ __forceinline__ float multiview_cost_cols(const Problem *__restrict__
 {
     constexpr int R = (BOX - 1) / 2, N = R + 1;
     const int n = P->n_sel;
-    int numValid = 0;
-    float b0 = kMaxCost, b1 = kMaxCost, b2 = kMaxCost, b3 = kMaxCost;
+    ViewCombiner<COMBINE_REG> comb;
     const int grp_lane0 = (int)(threadIdx.x & 63u & ~(unsigned)(kColGroup - 1));
     const int src_lane = grp_lane0 + (N - 1);
     // the homography of a (plane, view) pair is the same for the 8 lanes of a group: lane c computes
@@ -973,49 +987,10 @@ __device__ __forceinline__ float multiview_cost_cols(const Problem *__restrict__
                 c = view_cost_cols<BOX, true>(P, P->view[v], H, tp0, tw, lut, px, py, col);
             else
                 c = view_cost_cols<BOX, false>(P, P->view[v], H, tp0, tw, lut, px, py, col);
-            c = __shfl(c, src_lane);  // the group's exact value
-            if (c < kMaxCost)
-                numValid++;
-            else
-                c = kMaxCost;
-            if (COMBINE_REG) {
-                float t = c, lo;
-                lo = __builtin_fminf(b0, t); t = __builtin_fmaxf(b0, t); b0 = lo;
-                lo = __builtin_fminf(b1, t); t = __builtin_fmaxf(b1, t); b1 = lo;
-                lo = __builtin_fminf(b2, t); t = __builtin_fmaxf(b2, t); b2 = lo;
-                b3 = __builtin_fminf(b3, t);
-            } else {
-                int j = v;
-                for (; j >= 1 && c < cv[(j - 1) * kThreads]; j--) cv[j * kThreads] = cv[(j - 1) * kThreads];
-                cv[j * kThreads] = c;
-            }
+            comb.add(__shfl(c, src_lane), v, cv);  // the group's exact value
         }
     }
-    float cost = 0.0f;
-    int numConsidered = 0;
-    if (COMBINE_REG) {
-        const int numBest = min(numValid, P->n_best);
-        if (numBest > 0) cost = cost + b0;
-        if (numBest > 1) cost = cost + b1;
-        if (numBest > 2) cost = cost + b2;
-        if (numBest > 3) cost = cost + b3;
-        numConsidered = numBest;
-    } else {
-        int numBest = numValid;
-        if (P->cost_comb == 1) numBest = min(numBest, P->n_best);  // COMB_BEST_N
-        if (P->cost_comb == 3) numBest = n;                        // COMB_GOOD
-        const float costThresh = (n > 0 ? cv[0] : 0.0f) * P->good_factor;
-        for (int i = 0; i < numBest; i++) {
-            numConsidered++;
-            float c = cv[i * kThreads];
-            if (P->cost_comb == 3) c = __builtin_fminf(c, costThresh);
-            cost = cost + c;
-        }
-    }
-    cost = cost / ((float)numConsidered);
-    if (numConsidered < 1) cost = kMaxCost;
-    if (cost != cost || cost > kMaxCost || cost < 0) cost = kMaxCost;
-    return cost;
+    return comb.finish(P, n, cv);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1106,6 +1081,32 @@ __device__ __forceinline__ void stage_tile(const Problem *__restrict__ P, float 
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
+// the random plane of gipuma_init_cu2 for pixel (px, py): disparity uniform in the range, normal by
+// Marsaglia's method flipped towards the camera (gipuma.cu:1019-1034, 148-164, 131-137)
+__device__ __forceinline__ float4 random_plane(const Problem *__restrict__ P, int px, int py)
+{
+    const RefCam &rc = P->rc;
+    const uint32_t pre = rng_prefix(P->seed, 0u, (uint32_t)px, (uint32_t)py);
+    uint32_t draw = 0;
+    const Vec3 view = view_vector(rc, px, py);
+    const float disp = between(rng_uniform(pre, draw++), P->min_disp, P->max_disp);
+    // rndUnitVectorSphereMarsaglia_cu, gipuma.cu:148-164
+    float rx = 1.0f, ry = 1.0f, sum = 2.0f;
+    while (sum >= 1.0f) {
+        rx = between(rng_uniform(pre, draw++), -1.0f, 1.0f);
+        ry = between(rng_uniform(pre, draw++), -1.0f, 1.0f);
+        sum = rx * rx + ry * ry;
+    }
+    const float sq = __builtin_sqrtf(1.0f - sum);
+    Vec3 n;
+    n.x = 2.0f * rx * sq;
+    n.y = 2.0f * ry * sq;
+    n.z = 1.0f - 2.0f * sum;
+    n = on_hemisphere(n, view);
+    const float depth = disp_depth(rc.f, rc.baseline, disp);
+    return make_float4(n.x, n.y, n.z, plane_d(rc, n, px, py, depth));
+}
+
 // gipuma_init_cu2 (gipuma.cu:996-1051) when GENERATE, else the cost of a given plane field
 // (gipuma_initial_cost, :1052-1079).  32x8 tile, one lane per pixel.
 template <int BOX, bool U8, bool COMBINE_REG, bool GENERATE, int CH>
@@ -1131,26 +1132,7 @@ __global__ __launch_bounds__(kThreads) void init_kernel(const Problem *__restric
     const int center = py * P->cols + px;
     float4 pl;
     if (GENERATE) {
-        const RefCam &rc = P->rc;
-        const uint32_t pre = rng_prefix(P->seed, 0u, (uint32_t)px, (uint32_t)py);
-        uint32_t draw = 0;
-        const Vec3 view = view_vector(rc, px, py);
-        const float disp = between(rng_uniform(pre, draw++), P->min_disp, P->max_disp);
-        // rndUnitVectorSphereMarsaglia_cu, gipuma.cu:148-164
-        float rx = 1.0f, ry = 1.0f, sum = 2.0f;
-        while (sum >= 1.0f) {
-            rx = between(rng_uniform(pre, draw++), -1.0f, 1.0f);
-            ry = between(rng_uniform(pre, draw++), -1.0f, 1.0f);
-            sum = rx * rx + ry * ry;
-        }
-        const float sq = __builtin_sqrtf(1.0f - sum);
-        Vec3 n;
-        n.x = 2.0f * rx * sq;
-        n.y = 2.0f * ry * sq;
-        n.z = 1.0f - 2.0f * sum;
-        n = on_hemisphere(n, view);
-        const float depth = disp_depth(rc.f, rc.baseline, disp);
-        pl = make_float4(n.x, n.y, n.z, plane_d(rc, n, px, py, depth));
+        pl = random_plane(P, px, py);
         norm4[center] = pl;
     } else {
         pl = norm4[center];
@@ -1193,26 +1175,7 @@ __global__ __launch_bounds__(kThreads) void init_cols_kernel(const Problem *__re
     float4 pl = make_float4(0.f, 0.f, -1.f, 1.f);
     if (active) {
         if (GENERATE) {
-            const RefCam &rc = P->rc;
-            const uint32_t pre = rng_prefix(P->seed, 0u, (uint32_t)px, (uint32_t)py);
-            uint32_t draw = 0;
-            const Vec3 view = view_vector(rc, px, py);
-            const float disp = between(rng_uniform(pre, draw++), P->min_disp, P->max_disp);
-            // rndUnitVectorSphereMarsaglia_cu, gipuma.cu:148-164
-            float rx = 1.0f, ry = 1.0f, sum = 2.0f;
-            while (sum >= 1.0f) {
-                rx = between(rng_uniform(pre, draw++), -1.0f, 1.0f);
-                ry = between(rng_uniform(pre, draw++), -1.0f, 1.0f);
-                sum = rx * rx + ry * ry;
-            }
-            const float sq = __builtin_sqrtf(1.0f - sum);
-            Vec3 n;
-            n.x = 2.0f * rx * sq;
-            n.y = 2.0f * ry * sq;
-            n.z = 1.0f - 2.0f * sum;
-            n = on_hemisphere(n, view);
-            const float depth = disp_depth(rc.f, rc.baseline, disp);
-            pl = make_float4(n.x, n.y, n.z, plane_d(rc, n, px, py, depth));
+            pl = random_plane(P, px, py);
             norm4[center] = pl;
         } else {
             pl = norm4[center];
