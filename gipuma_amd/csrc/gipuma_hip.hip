@@ -61,7 +61,7 @@ struct gipuma_hip_session {
     int box = 0;             // specialised window size, 0 = runtime
     int ch = 1;              // 1 = gray (T=float), 4 = colour (T=float4)
     unsigned tune = 0;
-    int cols_launches = 3;   // leading half-sweeps (2*iteration + colour) evaluated column-per-lane
+    int cols_launches = 4;   // leading half-sweeps (2*iteration + colour) evaluated column-per-lane
     size_t lds_sweep = 0, lds_dense = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };

@@ -883,6 +883,9 @@ __device__ __forceinline__ float multiview_cost(const Problem *__restrict__ P, c
 // (the other lanes' values are never used).  N*(N+1) extra instructions per N samples per lane --
 // irrelevant where the launch is bound by line fills.
 // ---------------------------------------------------------------------------------------------
+#ifndef PM_COLS_PD
+#define PM_COLS_PD 8
+#endif
 constexpr int kColGroup = 8;                        // lanes per (pixel, plane) pair
 constexpr int kColTasks = kThreads / kColGroup;     // pairs evaluated concurrently by a workgroup
 
@@ -928,12 +931,16 @@ __device__ __forceinline__ float view_cost_cols(const Problem *__restrict__ P, c
     const float qy0 = (float)(py - R);
     const float *tcol = tp0 + 4 * (-R * tw - R + 2 * mycol);  // texel (column, -R) of the window
     float wgt[N], dis[N];
-    WinReq r0 = request(qy0), r1 = request(qy0 + 2.0f);
+    // PD window requests in flight (these launches wait on L2 misses, and the kernel has registers
+    // to spare below its 3-wavefront budget)
+    constexpr int PD = PM_COLS_PD < N ? PM_COLS_PD : N;
+    WinReq req[PD];
+#pragma unroll
+    for (int p = 0; p < PD; p++) req[p] = request(qy0 + (float)(2 * p));
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        const WinReq cur = r0;
-        r0 = r1;
-        if (k + 2 < N) r1 = request(qy0 + (float)(2 * (k + 2)));
+        const WinReq cur = req[k % PD];
+        if (k + PD < N) req[k % PD] = request(qy0 + (float)(2 * (k + PD)));
         const float4 t4 = *reinterpret_cast<const float4 *>(tcol + 8 * k * tw);
         const float colorDis = __builtin_fabsf(t4.x - centre);
         wgt[k] = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
