@@ -211,12 +211,15 @@ def test_device_resident_images_with_pitch(hip):
     assert_same(c, o_c, "device images cost")
 
 
-@pytest.mark.parametrize("tune", [1 << 30, 1 << 29, 1 << 28, (1 << 30) | (1 << 28)])
+@pytest.mark.parametrize("tune", [1 << 30, 1 << 29, 1 << 28, (1 << 30) | (1 << 28), 1 << 27, 1 << 26,
+                                  (1 << 26) | (1 << 29)])
 def test_kernel_variants_are_bit_identical(hip, tune):
-    """the performance-only choices of the sweep kernel -- float-encoded window offsets + the
+    """the performance-only choices of the sweep kernels -- float-encoded window offsets + the
     hand-pipelined loop (off: bit 30), task order owner-major (bit 29) / source-major (bit 28) in
-    every iteration instead of switching after iteration 1 -- must not change a single bit.  Box 15
-    (the pipelined instantiation), 4 iterations so that the default run uses both task orders."""
+    every iteration instead of switching after iteration 1, the column-per-lane kernel never (bit
+    27) / in every half-sweep (bit 26) instead of the first four -- must not change a single bit.
+    Box 15 (the pipelined and column-per-lane instantiations), 4 iterations so that the default run
+    uses both kernels and both task orders."""
     gs, _ = synth.build_problem(synth.tiny_config(cols=160, rows=112, n_src=4, blocksize=15, iterations=4,
                                                   n_best=3))
     a = runcuda(gs)
