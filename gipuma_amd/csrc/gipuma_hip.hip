@@ -58,6 +58,10 @@ struct gipuma_hip_session {
     // state invariant cost[p] == cost(p, plane[p]): true once init_planes has run, not assumed after
     // gipuma_hip_set_state (the caller may install any pair); the sweep kernel's skip rule (A) needs it
     bool costs_trusted = false;
+    // history rule bookkeeping: colours of the last two launches that were full-stage, fused, trusted
+    // half-sweeps (-1 otherwise); the rule is valid for colour c iff prev1 == 1-c and prev2 == c
+    int prev1 = -1, prev2 = -1;
+    unsigned char *changed = nullptr;  // device, one byte per pixel
     int box = 0;             // specialised window size, 0 = runtime
     int ch = 1;              // 1 = gray (T=float), 4 = colour (T=float4)
     unsigned tune = 0;
@@ -165,6 +169,13 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
     const uint32_t phase = 1u + 2u * (uint32_t)iteration + (uint32_t)colour;
     sweep_fn k = pick_sweep(s);
     unsigned tune = s->tune | (s->costs_trusted ? 0u : Tune::kUntrustedCosts);
+    // history rule (exact skipping (H) in pm_device.h): only inside a strictly alternating sequence of
+    // full half-sweeps on trusted costs, as gipuma_hip_solve produces from its second iteration on
+    const bool qualifies = stages == GIPUMA_STAGE_ALL && !s->unfused && s->costs_trusted;
+    if (qualifies && s->prev1 == 1 - colour && s->prev2 == colour && !(tune & (Tune::kNoHistory | Tune::kNoSkip)))
+        tune |= Tune::kHistorySkip;
+    s->prev2 = s->prev1;
+    s->prev1 = qualifies ? colour : -1;
     // task order (performance only): planes are still incoherent in the first two iterations, where
     // grouping the evaluations of one plane saves cache-line fills; afterwards owner order is faster
     if (iteration >= 2 && !(tune & Tune::kSourceMajorTasks)) tune |= Tune::kOwnerMajorTasks;
@@ -370,6 +381,9 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         copy9(hp.view[i].R, c.R);
         copy3(hp.view[i].t, c.t);
     }
+    CREATE_OK(hipMalloc(&s->changed, np));
+    CREATE_OK(hipMemsetAsync(s->changed, 1, np, s->stream));
+    hp.changed = s->changed;
     CREATE_OK(hipMalloc(&s->dp, sizeof(pm::Problem)));
     CREATE_OK(hipMemcpyAsync(s->dp, &hp, sizeof(pm::Problem), hipMemcpyHostToDevice, s->stream));
 
@@ -414,6 +428,7 @@ int gipuma_hip_destroy(gipuma_hip_session *s)
     for (uint32_t *p : s->packed) (void)hipFree(p);
     if (s->flag) (void)hipFree(s->flag);
     if (s->dp) (void)hipFree(s->dp);
+    if (s->changed) (void)hipFree(s->changed);
     if (s->norm4) (void)hipFree(s->norm4);
     if (s->cost) (void)hipFree(s->cost);
     for (auto &e : s->ev)
@@ -429,6 +444,7 @@ int gipuma_hip_init_planes(gipuma_hip_session *s)
     HIP_OK(hipSetDevice(s->device));
     const int rc = launch_dense(s, true, s->norm4, s->cost);
     if (!rc) s->costs_trusted = true;
+    s->prev1 = s->prev2 = -1;
     return rc;
 }
 
@@ -509,6 +525,7 @@ int gipuma_hip_set_state(gipuma_hip_session *s, const float *norm4_host, const f
         HIP_OK(hipMemcpyAsync(s->cost, cost_host, np * sizeof(float), hipMemcpyHostToDevice, s->stream));
     HIP_OK(hipStreamSynchronize(s->stream));
     s->costs_trusted = false;
+    s->prev1 = s->prev2 = -1;
     return 0;
 }
 

@@ -43,6 +43,7 @@ struct Problem {  // lives in device memory, read through scalar loads (wave-uni
     int pw, channels;  // packed layout: texels per row of V (cols + 8); 1 = gray, 4 = colour
     int magic_addr;    // gray packed planes small enough (< 2^21 words) for float-encoded offsets
     int pad_;
+    unsigned char *changed;  // per pixel: did its plane change in its colour's last half-sweep (history rule)
     RefCam rc;
     ViewCam view[kMaxViews];
 };
@@ -249,7 +250,9 @@ struct Tune {  // experiment switches (GIPUMA_HIP_TUNE), all default off
                               kOwnerMajorTasks = 1u << 29,   // always owner-major task lists
                               kSourceMajorTasks = 1u << 28,  // always source-major (default: by iteration)
                               kNoColsKernel = 1u << 27,      // never the column-per-lane kernel
-                              kColsAlways = 1u << 26;        // ... or in every iteration (default: 0 and 1)
+                              kColsAlways = 1u << 26,        // ... or in every iteration (default: 0 and 1)
+                              kHistorySkip = 1u << 24,       // set by the host when the history rule is valid
+                              kNoHistory = 1u << 23;         // never use it
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1219,6 +1222,12 @@ __global__ __launch_bounds__(kThreads) void init_cols_kernel(const Problem *__re
 //         assumed after gipuma_hip_set_state, see `trust`), so `c < cost_now` is false; or
 //     (D) an earlier candidate of the same pixel -- same cost and same depth test; if the earlier
 //         one was accepted then c == cost_now, if it was rejected then c >= cost_then >= cost_now
+//     (H) the unchanged plane of a neighbour: if this pixel's colour and the neighbour's colour
+//         have been swept strictly alternately with all stages (the host checks the sequence and
+//         sets Tune::kHistorySkip), and the neighbour's plane did not change in its last half-sweep
+//         (Problem::changed), then this pixel met exactly that plane one half-sweep ago and did
+//         not end up with it at a lower cost -- it was rejected against a cost that has only
+//         decreased since, or accepted and improved upon
 //   can never be accepted (strict <, gipuma.cu:868) and is not evaluated.  On config C the
 //   evaluated candidates drop from 8 to 2.7 per pixel by the last half-sweep.  Because the
 //   per-wavefront MAXIMUM stays near 8, the surviving (pixel, candidate) pairs of the whole
@@ -1259,6 +1268,7 @@ struct SweepLane {
     float4 pl;                        // current plane
     float cst, depth;                 // its cost and depth
     unsigned needmask;                // candidate slots that must be evaluated
+    unsigned chg;                     // the plane changed in this half-sweep
     int n_tasks;                      // surviving (pixel, candidate) pairs of the workgroup
 };
 
@@ -1304,6 +1314,8 @@ __device__ __forceinline__ void sweep_setup(SweepLane &L, const Problem *__restr
     L.cst = 0.f;
     L.depth = 0.f;
     L.needmask = 0;
+    L.chg = 0;
+    const bool history = (tune & Tune::kHistorySkip) != 0;
     if (L.active) {
         const float4 pl = norm4[L.center];
         L.pl = pl;
@@ -1327,6 +1339,11 @@ __device__ __forceinline__ void sweep_setup(SweepLane &L, const Problem *__restr
             for (int k = 0; k < 8; k++) {
                 bool fresh = (valid >> k) & 1u;
                 if (fresh && trust && same_bits(cands[k], pl)) fresh = false;  // (A)
+                if (fresh && history) {                                        // (H)
+                    int nb;
+                    neighbour(k, L.px, L.py, rows, cols, L.center, nb);
+                    if (P->changed[nb] == 0) fresh = false;
+                }
 #pragma unroll
                 for (int j = 0; j < k; j++)
                     if (fresh && ((valid >> j) & 1u) && same_bits(cands[k], cands[j])) fresh = false;  // (D)
@@ -1447,6 +1464,7 @@ __device__ __forceinline__ void sweep_replay(SweepLane &L, const Problem *__rest
                 L.depth = d_new;
                 L.pl = cand;
                 L.cst = c;
+                L.chg = 1;
             }
         }
     }
@@ -1576,14 +1594,16 @@ __global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kerne
                 L.depth = d_new;
                 L.pl = cand;
                 L.cst = c;
+                L.chg = 1;
             }
         }
     }
 
-    // write back (gipuma.cu:1585-1587): 16 B + 4 B per active pixel
+    // write back (gipuma.cu:1585-1587): 16 B + 4 B per active pixel (+ the history flag)
     if (L.active) {
         cost[L.center] = L.cst;
         norm4[L.center] = L.pl;
+        P->changed[L.center] = (unsigned char)L.chg;
     }
 }
 
@@ -1657,6 +1677,7 @@ __global__ __launch_bounds__(kThreads) void sweep_cols_kernel(const Problem *__r
                 L.depth = d_new;
                 L.pl = cand;
                 L.cst = c;
+                L.chg = 1;
             }
         }
     }
@@ -1665,6 +1686,7 @@ __global__ __launch_bounds__(kThreads) void sweep_cols_kernel(const Problem *__r
     if (L.active) {
         cost[L.center] = L.cst;
         norm4[L.center] = L.pl;
+        P->changed[L.center] = (unsigned char)L.chg;
     }
 }
 

@@ -212,12 +212,13 @@ def test_device_resident_images_with_pitch(hip):
 
 
 @pytest.mark.parametrize("tune", [1 << 30, 1 << 29, 1 << 28, (1 << 30) | (1 << 28), 1 << 27, 1 << 26,
-                                  (1 << 26) | (1 << 29)])
+                                  (1 << 26) | (1 << 29), 1 << 23])
 def test_kernel_variants_are_bit_identical(hip, tune):
     """the performance-only choices of the sweep kernels -- float-encoded window offsets + the
     hand-pipelined loop (off: bit 30), task order owner-major (bit 29) / source-major (bit 28) in
     every iteration instead of switching after iteration 1, the column-per-lane kernel never (bit
-    27) / in every half-sweep (bit 26) instead of the first four -- must not change a single bit.
+    27) / in every half-sweep (bit 26) instead of the first four, the history skip rule off (bit
+    23) -- must not change a single bit.
     Box 15 (the pipelined and column-per-lane instantiations), 4 iterations so that the default run
     uses both kernels and both task orders."""
     gs, _ = synth.build_problem(synth.tiny_config(cols=160, rows=112, n_src=4, blocksize=15, iterations=4,
@@ -234,6 +235,37 @@ def test_kernel_variants_are_bit_identical(hip, tune):
         o = OracleState(gs).run()
         assert_same(a[0], o[0], "default vs oracle norm4")
         assert_same(a[1], o[1], "default vs oracle cost")
+
+
+@pytest.mark.parametrize("seq", [
+    # (iteration, colour, stages) or "set" = write the state back through set_state
+    [(0, 0, 7), (0, 1, 7), (1, 0, 7), (1, 0, 7), (1, 1, 7), (1, 1, 7), (2, 0, 7), (2, 1, 7), (3, 0, 7), (3, 1, 7)],
+    [(0, 0, 7), (0, 1, 7), (1, 0, 7), (1, 1, 7), (2, 1, 1), (2, 0, 7), (2, 1, 7), (3, 0, 7), (3, 1, 7), (4, 0, 7)],
+    [(0, 0, 7), (0, 1, 7), (1, 0, 7), (1, 1, 7), (2, 0, 7), "set", (2, 1, 7), (3, 0, 7), (3, 1, 7), (4, 0, 7)],
+    [(0, 1, 7), (0, 1, 7), (0, 0, 7), (1, 1, 7), (1, 0, 7), (2, 1, 7), (2, 0, 7), (3, 1, 7)],
+])
+def test_history_rule_survives_any_launch_sequence(hip, seq):
+    """rule (H) -- skip a neighbour whose plane did not change in its last half-sweep -- is only
+    valid inside a strictly alternating sequence of full half-sweeps; the session must notice
+    repeated colours, partial stages and rewritten states by itself.  Each sequence is replayed on
+    the oracle launch by launch."""
+    gs, _ = synth.build_problem(synth.tiny_config(cols=128, rows=96, n_src=4, blocksize=15, iterations=5,
+                                                  n_best=3))
+    o = OracleState(gs)
+    o.init_planes()
+    with Session(gs) as s:
+        s.init_planes()
+        for step in seq:
+            if step == "set":
+                n4, c = s.get_state()
+                s.set_state(n4, c)
+                continue
+            it, colour, stages = step
+            s.sweep(it, colour, stages)
+            o.sweep(it, colour, stages)
+        n4, c = s.get_state()
+    assert_same(n4, o.norm4, "sequence norm4")
+    assert_same(c, o.cost, "sequence cost")
 
 
 def test_packed_plane_beyond_the_float_offset_range(hip):
