@@ -1031,7 +1031,7 @@ __device__ __forceinline__ TileXY tile_of(int b, int gx, int gy, unsigned tune)
         o.x = t % gx;
         o.y = t / gx;
     } else {
-        const int bo = (int)((tune >> 8) & 0xffffu);         // experiment override of the band height
+        const int bo = (int)((tune >> 8) & 0x7fffu);         // experiment override of the band height
         const int bh = bo ? min(bo, gy) : (gy + 7) >> 3;  // band height in tile rows
         const int band = t / (bh * gx);
         const int h = min(bh, gy - band * bh);   // the last band may be shorter

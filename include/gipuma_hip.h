@@ -157,8 +157,10 @@ int gipuma_hip_set_state(gipuma_hip_session *s, const float *norm4_host, const f
 /* device pointers of the state planes (for callers that keep results in HBM).  A caller that
  * WRITES the planes through these pointers must afterwards call
  * gipuma_hip_set_state(s, NULL, NULL): like any set_state it tells the session that the stored
- * costs are no longer known to be the costs of the stored planes (the sweep kernel skips
- * candidates equal to a pixel's own plane only while that is known). */
+ * costs are no longer known to be the costs of the stored planes and that its record of which
+ * planes changed in the last half-sweeps is void (the sweep kernels skip candidates equal to a
+ * pixel's own plane, and neighbours that did not change since the pixel last met them, only
+ * while both are known). */
 int gipuma_hip_state_device_ptrs(gipuma_hip_session *s, float **norm4_dev, float **cost_dev);
 /* init + iterations x (black, red) + finalize on the session, timed with HIP events.
  * Does not synchronise the host unless `timing` is non-NULL. */
