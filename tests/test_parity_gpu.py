@@ -268,6 +268,28 @@ def test_history_rule_survives_any_launch_sequence(hip, seq):
     assert_same(c, o.cost, "sequence cost")
 
 
+@pytest.mark.parametrize("cfg,colour", [
+    (dict(cols=96, rows=80, n_src=3, blocksize=11, iterations=8, n_best=2), False),   # box 11, long run
+    (dict(cols=72, rows=56, n_src=3, blocksize=7, iterations=6, n_best=2), False),    # runtime-sized window
+    (dict(cols=80, rows=64, n_src=3, blocksize=11, iterations=5, n_best=2), True),    # colour kernels
+])
+def test_history_rule_on_other_kernels(hip, cfg, colour):
+    """rule (H) lives in the setup shared by every sweep instantiation: long runs on the box-11,
+    runtime-window and colour kernels with and without it, and against the oracle"""
+    gs, _ = synth.build_problem(synth.tiny_config(**cfg), colour=colour)
+    a = runcuda(gs)
+    os.environ["GIPUMA_HIP_TUNE"] = str(1 << 23)
+    try:
+        b = runcuda(gs)
+    finally:
+        del os.environ["GIPUMA_HIP_TUNE"]
+    assert_same(a[0], b[0], "history on/off norm4")
+    assert_same(a[1], b[1], "history on/off cost")
+    o = OracleState(gs).run()
+    assert_same(a[0], o[0], "vs oracle norm4")
+    assert_same(a[1], o[1], "vs oracle cost")
+
+
 def test_packed_plane_beyond_the_float_offset_range(hip):
     """a packed plane of more than 2^21 entries cannot use float-encoded offsets: the session must
     fall back to integer addressing by itself.  1800x1200 is too large for the oracle to run whole,
