@@ -68,6 +68,10 @@ struct gipuma_hip_session {
     int cols_launches = 4;   // leading half-sweeps (2*iteration + colour) evaluated column-per-lane
     size_t lds_sweep = 0, lds_dense = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // experiment aid (GIPUMA_HIP_LAUNCH_TIMES=1): one event per half-sweep launch of gipuma_hip_solve,
+    // durations printed to stderr
+    bool launch_times = false;
+    std::vector<hipEvent_t> lev;
 };
 
 namespace {
@@ -274,8 +278,12 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     s->n_sel = d->n_selected;
     s->iterations = d->params.iterations;
     s->unfused = (d->flags & GIPUMA_HIP_FLAG_UNFUSED) != 0;
-    if (const char *t = getenv("GIPUMA_HIP_TUNE")) s->tune = (unsigned)strtoul(t, nullptr, 0);
+    if (const char *t = getenv("GIPUMA_HIP_TUNE")) {
+        s->tune = (unsigned)strtoul(t, nullptr, 0);
+        s->tune &= ~(Tune::kHistorySkip | Tune::kUntrustedCosts);  // host-internal bits, never from the environment
+    }
     if (const char *t = getenv("GIPUMA_HIP_COLS_LAUNCHES")) s->cols_launches = atoi(t);  // experiment
+    if (const char *t = getenv("GIPUMA_HIP_LAUNCH_TIMES")) s->launch_times = atoi(t) != 0;
     if (d->stream) {
         s->stream = (hipStream_t)d->stream;
     } else {
@@ -384,8 +392,6 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     CREATE_OK(hipMalloc(&s->changed, np));
     CREATE_OK(hipMemsetAsync(s->changed, 1, np, s->stream));
     hp.changed = s->changed;
-    CREATE_OK(hipMalloc(&s->dp, sizeof(pm::Problem)));
-    CREATE_OK(hipMemcpyAsync(s->dp, &hp, sizeof(pm::Problem), hipMemcpyHostToDevice, s->stream));
 
     // state planes, zero-filled like LineState::resize (linestate.h:16-24)
     CREATE_OK(hipMalloc(&s->norm4, np * sizeof(float4)));
@@ -404,6 +410,29 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         s->box = 0;  // the no-interior A/B arm only exists for these two variants
         s->combine_reg = false;
     }
+    // early termination of refinement evaluations (pm::multiview_cost): only where every view cost is
+    // provably finite and below MAXCOST for every plane, so that numValid == n_sel always
+    // (gipuma.cu:771-775): weights exp(-k/gamma) <= 1 from the table, dis <= (1-alpha)*tau_c + alpha*tau_g
+    {
+        const gipuma_hip_params &p = d->params;
+        const double samples = (double)((hp.box_h + 1) / 2) * (double)((hp.box_v + 1) / 2);
+        const bool sane = p.gamma > 0.0f && p.alpha >= 0.0f && p.alpha <= 1.0f && p.tau_color >= 0.0f &&
+                          p.tau_gradient >= 0.0f && std::isfinite(p.tau_color) && std::isfinite(p.tau_gradient) &&
+                          samples * ((1.0 - p.alpha) * p.tau_color + (double)p.alpha * p.tau_gradient) * 1.01 <
+                              (double)GIPUMA_HIP_MAXCOST;
+        hp.et_enable = sane && s->u8 && s->ch == 1 && hp.magic_addr && s->box > 0 && s->combine_reg;
+        hp.et_theta[0] = 1.0f;
+        hp.et_theta[1] = 1.0f;
+        hp.et_theta[2] = 1.5f;
+        if (const char *t = getenv("GIPUMA_HIP_ET_THETA")) {  // experiment: "t0,t1,t2" (any value is exact)
+            float a, b, c;
+            if (sscanf(t, "%f,%f,%f", &a, &b, &c) == 3) {
+                hp.et_theta[0] = a;
+                hp.et_theta[1] = b;
+                hp.et_theta[2] = c;
+            }
+        }
+    }
     s->lds_sweep = lds_bytes(s, pm::kSweepTileH, !s->combine_reg, true);
     s->lds_dense = lds_bytes(s, pm::kDenseTileH, true, false);
     if (s->lds_sweep > 160u * 1024u || s->lds_dense > 160u * 1024u) {  // 160 KiB of LDS per CU on gfx950
@@ -413,6 +442,8 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         g_err = keep;
         return GIPUMA_HIP_ERR_UNSUPPORTED;
     }
+    CREATE_OK(hipMalloc(&s->dp, sizeof(pm::Problem)));
+    CREATE_OK(hipMemcpyAsync(s->dp, &hp, sizeof(pm::Problem), hipMemcpyHostToDevice, s->stream));
     CREATE_OK(hipStreamSynchronize(s->stream));  // host image buffers may be released by the caller
 #undef CREATE_OK
     *out = s;
@@ -433,6 +464,7 @@ int gipuma_hip_destroy(gipuma_hip_session *s)
     if (s->cost) (void)hipFree(s->cost);
     for (auto &e : s->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto &e : s->lev) (void)hipEventDestroy(e);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return 0;
@@ -546,9 +578,18 @@ int gipuma_hip_solve(gipuma_hip_session *s, gipuma_hip_timing *timing)
     HIP_OK(hipEventRecord(s->ev[0], s->stream));
     if ((rc = gipuma_hip_init_planes(s))) return rc;
     HIP_OK(hipEventRecord(s->ev[1], s->stream));
+    const size_t n_lev = s->launch_times ? (size_t)(2 * s->iterations + 1) : 0;
+    while (s->lev.size() < n_lev) {
+        hipEvent_t e;
+        HIP_OK(hipEventCreate(&e));
+        s->lev.push_back(e);
+    }
+    if (n_lev) HIP_OK(hipEventRecord(s->lev[0], s->stream));
     for (int it = 0; it < s->iterations; it++) {  // gipuma.cu:1911-1941
         if ((rc = gipuma_hip_sweep(s, it, GIPUMA_BLACK, GIPUMA_STAGE_ALL))) return rc;
+        if (n_lev) HIP_OK(hipEventRecord(s->lev[2 * it + 1], s->stream));
         if ((rc = gipuma_hip_sweep(s, it, GIPUMA_RED, GIPUMA_STAGE_ALL))) return rc;
+        if (n_lev) HIP_OK(hipEventRecord(s->lev[2 * it + 2], s->stream));
         launches += s->unfused ? 6 : 2;
     }
     HIP_OK(hipEventRecord(s->ev[2], s->stream));
@@ -562,6 +603,16 @@ int gipuma_hip_solve(gipuma_hip_session *s, gipuma_hip_timing *timing)
         HIP_OK(hipEventElapsedTime(&timing->ms_total, s->ev[0], s->ev[3]));
         timing->n_sweep_launches = launches;
         timing->ms_sweep_avg = launches ? timing->ms_sweeps / (float)launches : 0.0f;
+    }
+    if (n_lev) {
+        HIP_OK(hipEventSynchronize(s->ev[3]));
+        fprintf(stderr, "gipuma_hip launch_ms:");
+        for (size_t i = 1; i < n_lev; i++) {
+            float ms = 0.0f;
+            HIP_OK(hipEventElapsedTime(&ms, s->lev[i - 1], s->lev[i]));
+            fprintf(stderr, " %.3f", ms);
+        }
+        fprintf(stderr, "\n");
     }
     return 0;
 }

@@ -44,6 +44,10 @@ struct Problem {  // lives in device memory, read through scalar loads (wave-uni
     int magic_addr;    // gray packed planes small enough (< 2^21 words) for float-encoded offsets
     int pad_;
     unsigned char *changed;  // per pixel: did its plane change in its colour's last half-sweep (history rule)
+    // early termination of refinement evaluations (see multiview_cost): enabled by the host when every
+    // view cost is provably finite and below MAXCOST; theta of refinement step 0, 1, 2+
+    int et_enable;
+    float et_theta[3];
     RefCam rc;
     ViewCam view[kMaxViews];
 };
@@ -251,6 +255,7 @@ struct Tune {  // experiment switches (GIPUMA_HIP_TUNE), all default off
                               kSourceMajorTasks = 1u << 28,  // always source-major (default: by iteration)
                               kNoColsKernel = 1u << 27,      // never the column-per-lane kernel
                               kColsAlways = 1u << 26,        // ... or in every iteration (default: 0 and 1)
+                              kNoEarlyExit = 1u << 25,       // no early termination of view costs
                               kHistorySkip = 1u << 24,       // set by the host when the history rule is valid
                               kNoHistory = 1u << 23;         // never use it
 };
@@ -577,10 +582,10 @@ struct WinReq {
     float a, b;
     u32x4_a4 w;
 };
-template <int BOX, bool FAST>
+template <int BOX, bool FAST, bool ET>
 __device__ __forceinline__ float view_cost_pipe(const Problem *__restrict__ P, const ViewCam &vc,
                                                 const float *__restrict__ H, const float *__restrict__ tp0,
-                                                int tw, const float *__restrict__ lut, int px, int py)
+                                                int tw, const float *__restrict__ lut, int px, int py, float tau)
 {
     static_assert(BOX > 0, "compile-time window only");
     constexpr int R = (BOX - 1) / 2, N = R + 1;  // offsets -R, -R+2, ..., R
@@ -655,15 +660,19 @@ __device__ __forceinline__ float view_cost_pipe(const Problem *__restrict__ P, c
         X0 = X0n;
         Y0 = Y0n;
         Z0 = Z0n;
+        // early termination (ET): the partial sum only grows (w, dis >= 0, fmaf rounds monotonically),
+        // so once every lane of the wavefront has reached its bound the rest of the view cannot
+        // matter (see multiview_cost); the two windows already requested are dropped
+        if (ET && __all(cost >= tau)) break;
     }
     return cost;
 }
 
-template <int BOX, bool U8, bool INTERIOR>
+template <int BOX, bool U8, bool INTERIOR, bool ET = false>
 __device__ __forceinline__ float view_cost(const Problem *__restrict__ P, const ViewCam &vc,
                                            const float *__restrict__ tp0, int tw,
                                            const float *__restrict__ lut, int px, int py, float4 pl,
-                                           const Win<BOX> &win)
+                                           const Win<BOX> &win, float tau = 0.0f)
 {
     float H[9];
     homography(P->rc.K_inv, vc, pl, H);
@@ -672,8 +681,8 @@ __device__ __forceinline__ float view_cost(const Problem *__restrict__ P, const 
     if constexpr (U8) {
         if (P->magic_addr) {
             if constexpr (BOX > 0) {
-                if (__all(safe)) return view_cost_pipe<BOX, true>(P, vc, H, tp0, tw, lut, px, py);
-                return view_cost_pipe<BOX, false>(P, vc, H, tp0, tw, lut, px, py);
+                if (__all(safe)) return view_cost_pipe<BOX, true, ET>(P, vc, H, tp0, tw, lut, px, py, tau);
+                return view_cost_pipe<BOX, false, ET>(P, vc, H, tp0, tw, lut, px, py, tau);
             } else {
                 if (__all(safe))
                     return view_cost_loop<BOX, U8, INTERIOR, true, true>(P, vc, H, tp0, tw, lut, px, py, win);
@@ -820,6 +829,15 @@ struct ViewCombiner {
             cv[j * kThreads] = c;
         }
     }
+    // m-th smallest value so far (m = 1..4; COMBINE_REG only): b0 <= b1 <= b2 <= b3, so it is the
+    // largest of the first m; spelled with min/max so that the registers are not spilled to an array
+    __device__ __forceinline__ float kth(int m) const
+    {
+        const float inf = __builtin_inff();
+        const float s1 = m >= 2 ? inf : -inf, s2 = m >= 3 ? inf : -inf, s3 = m >= 4 ? inf : -inf;
+        return __builtin_fmaxf(__builtin_fmaxf(b0, __builtin_fminf(b1, s1)),
+                               __builtin_fmaxf(__builtin_fminf(b2, s2), __builtin_fminf(b3, s3)));
+    }
     __device__ __forceinline__ float finish(const Problem *__restrict__ P, int n, const float *cv) const
     {
         float cost = 0.0f;
@@ -851,21 +869,48 @@ struct ViewCombiner {
 };
 
 // pmCostMultiview_cu, gipuma.cu:720-806
-template <int BOX, bool U8, bool INTERIOR, bool COMBINE_REG, int CH>
+//
+// Early termination (ET; best-N with n_best <= 4 on packed gray planes, enabled by the host through
+// Problem::et_enable only when the parameters make every view cost finite and < MAXCOST, so that
+// numValid == n_sel for every plane).  Work reduction that cannot change a result:
+//   A view cost is a sum of terms w*dis >= 0 accumulated by fmaf, so its partial sums never
+//   decrease: a view stopped early leaves a LOWER BOUND l_v <= c_v.  Let m = min(n_sel, n_best),
+//   b[0..m-1] the m smallest values seen so far (exact costs and lower bounds alike) and
+//   tau = min(b[m-1], thr).  A view is abandoned -- by the whole wavefront, after a window column --
+//   once every lane's partial sum has reached its own tau.  At the end F' = mean of b[0..m-1] is a
+//   lower bound of the exact result F (the m smallest of elementwise smaller values, summed in the
+//   same order; rounding is monotone), and
+//     * if b[m-1] < thr, no abandoned view is among the m smallest: one abandoned against b[m-1] had
+//       m values at or below it already, one abandoned against thr is >= thr > b[m-1].  The m smallest
+//       are exact and every other view is >= b[m-1]: F' == F bit for bit;
+//     * else if F' >= bound (the cost the candidate must beat): F >= F', the candidate is rejected
+//       either way and its cost is never stored;
+//     * else the caller re-evaluates with thr = infinity (first case).
+//   thr = infinity leaves only the value-exact rule; Problem::et_theta scales thr = theta * bound.
+template <int BOX, bool U8, bool INTERIOR, bool COMBINE_REG, int CH, bool ET = false>
 __device__ __forceinline__ float multiview_cost(const Problem *__restrict__ P, const float *__restrict__ tp0,
                                                 int tw, const float *__restrict__ lut, float *cv, int px,
-                                                int py, float4 pl, const Win<BOX> &win)
+                                                int py, float4 pl, const Win<BOX> &win, bool et_on = false,
+                                                float thr = 0.0f, float *kth_out = nullptr)
 {
+    static_assert(!ET || (COMBINE_REG && CH == 1 && U8 && BOX > 0), "ET: register combiner on packed gray planes");
     const int n = P->n_sel;
+    const int m = min(n, P->n_best);
     ViewCombiner<COMBINE_REG> comb;
     for (int v = 0; v < n; v++) {
         float c;
-        if (CH == 4)
+        if constexpr (CH == 4) {
             c = view_cost_c4<BOX, U8>(P, P->view[v], tp0, tw, lut, px, py, pl, win);
-        else
+        } else if constexpr (ET) {
+            const float tau = et_on ? __builtin_fminf(comb.kth(m), thr) : __builtin_inff();
+            c = view_cost<BOX, U8, INTERIOR, true>(P, P->view[v], tp0, tw, lut, px, py, pl, win, tau);
+        } else {
             c = view_cost<BOX, U8, INTERIOR>(P, P->view[v], tp0, tw, lut, px, py, pl, win);
+        }
         comb.add(c, v, cv);
     }
+    if constexpr (ET)
+        if (kth_out) *kth_out = comb.kth(m);
     return comb.finish(P, n, cv);
 }
 
@@ -1548,6 +1593,8 @@ __global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kerne
     const int prop_rounds = (L.n_tasks + kThreads - 1) / kThreads;
     RefineDraws R;
     refine_init(R, P, stages);
+    constexpr bool ET = U8 && COMBINE_REG && CH == 1 && BOX > 0 && INTERIOR;
+    const bool et_on = ET && P->et_enable && !(tune & Tune::kNoEarlyExit);
 
     // One loop, one call site of the cost function: rounds [0, prop_rounds) evaluate compacted
     // propagation tasks (possibly of another lane's pixel), then the owner replays its accepts,
@@ -1586,8 +1633,32 @@ __global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kerne
         }
         if (do_eval) {
             const float *etp0 = L.tile + (((epy - L.y0) + L.hh) * L.tw + ((epx - L.x0) + L.hw)) * 4;
-            const float c =
-                multiview_cost<BOX, U8, INTERIOR, COMBINE_REG, CH>(P, etp0, L.tw, lds, L.cv, epx, epy, cand, win);
+            float c = 0.0f;
+            if constexpr (ET) {
+                // refinement candidates only have to beat L.cst: bound the evaluation by theta * L.cst
+                // and redo the (rare) lanes whose outcome the bound leaves open (see multiview_cost).
+                // Propagation tasks keep only the value-exact rule (their costs are stored).
+                float thr = __builtin_inff();
+                if (et_on && r >= prop_rounds) thr = P->et_theta[min(r - prop_rounds, 2)] * L.cst;
+                bool need = true;
+                for (int pass = 0; pass < 2; pass++) {
+                    if (need) {
+                        float kth;
+                        const float cc = multiview_cost<BOX, U8, INTERIOR, COMBINE_REG, CH, true>(
+                            P, etp0, L.tw, lds, L.cv, epx, epy, cand, win, et_on, thr, &kth);
+                        const bool open = kth >= thr && cc < L.cst;
+                        if (open) {
+                            thr = __builtin_inff();
+                        } else {
+                            c = cc;
+                            need = false;
+                        }
+                    }
+                    if (!__any(need)) break;
+                }
+            } else {
+                c = multiview_cost<BOX, U8, INTERIOR, COMBINE_REG, CH>(P, etp0, L.tw, lds, L.cv, epx, epy, cand, win);
+            }
             if (r < prop_rounds) {
                 L.bres[slot * kThreads + owner] = c;
             } else if (c < L.cst) {  // refinement has no depth-range test, :986

@@ -1,0 +1,479 @@
+/*
+ * et_stats.c -- EXPERIMENT (CPU, test infrastructure): how much patch-cost work could be removed
+ * exactly on a config-C-like workload?  Includes the oracle restatement and replays the red-black
+ * schedule on a window of the frame with the kernels' skip rules (A)/(D)/(H), recording for every
+ * evaluated (pixel, candidate):
+ *   - per-view column-prefix costs -> simulated early-termination policies (lane and wave level)
+ *   - the (source pixel, orientation) groups of propagation candidates -> dis-sharing potential
+ * Built and driven by scripts/exp/et_stats.py.  Nothing here is linked into the product.
+ */
+#include "../../oracle/gipuma_oracle.c"
+
+#include <stdio.h>
+
+#define MAXC 16
+#ifndef THETA1
+#define THETA1 1.0f
+#define THETA2 1.5f
+#define THETA3 2.0f
+#endif /* window columns (box <= 31) */
+
+/* per-view prefix: pre[c] = cost after window column c, reference order (go_view_cost) */
+static int view_prefix(const gipuma_hip_desc *d, int view, int px, int py, const float pl[4], float *pre)
+{
+    const gipuma_hip_params *ap = &d->params;
+    const int rows = d->rows, cols = d->cols, pitch = d->pitch;
+    const float *ref = d->images[0];
+    const float *src = d->images[view];
+    const int hRad = (ap->box_hsize - 1) / 2;
+    const int vRad = (ap->box_vsize - 1) / 2;
+    const float alpha = ap->alpha, tau_color = ap->tau_color, tau_gradient = ap->tau_gradient;
+    const float gamma = ap->gamma;
+    const float oma = 1.f - alpha;
+    float H[9];
+    go_homography(&d->cameras[0], &d->cameras[view], pl, pl[3], H);
+    const float centre = go_texel(ref, rows, cols, pitch, px, py);
+    float cost = 0.0f;
+    int nc = 0;
+    for (int i = -hRad; i < hRad + 1; i += GO_WIN_INCREMENT) {
+        const float qx = (float)(px + i);
+        const float X0 = fmaf(H[0], qx, H[2]);
+        const float Y0 = fmaf(H[3], qx, H[5]);
+        const float Z0 = fmaf(H[6], qx, H[8]);
+        for (int j = -vRad; j < vRad + 1; j += GO_WIN_INCREMENT) {
+            const int ix = px + i, iy = py + j;
+            const float qy = (float)iy;
+            const float leftValue = go_texel(ref, rows, cols, pitch, ix, iy);
+            const float colorDis = fabsf(leftValue - centre);
+            const float w = go_exp(-colorDis / gamma);
+            const float X = fmaf(H[1], qy, X0);
+            const float Y = fmaf(H[4], qy, Y0);
+            const float Z = fmaf(H[7], qy, Z0);
+            const float rz = 1.0f / Z;
+            const float sx = X * rz, sy = Y * rz;
+            float s[5];
+            go_sample5(src, rows, cols, pitch, sx, sy, s);
+            const float gx2 = s[1] - s[2];
+            const float gy2 = s[3] - s[4];
+            const float colDiff = fabsf(leftValue - s[0]);
+            const float up = go_texel(ref, rows, cols, pitch, ix, iy - 1);
+            const float down = go_texel(ref, rows, cols, pitch, ix, iy + 1);
+            const float left = go_texel(ref, rows, cols, pitch, ix - 1, iy);
+            const float right = go_texel(ref, rows, cols, pitch, ix + 1, iy);
+            const float gradX = (right - left) - gx2;
+            const float gradY = (down - up) - gy2;
+            const float gradDis = fminf((fabsf(gradX) + fabsf(gradY)) * 0.0625f, tau_gradient);
+            const float colDis = fminf(colDiff, tau_color);
+            const float dis = fmaf(alpha, gradDis, oma * colDis);
+            cost = fmaf(w, dis, cost);
+        }
+        pre[nc++] = cost;
+    }
+    return nc;
+}
+
+/* one evaluated task: prefixes of all views; returns the exact aggregated cost */
+typedef struct {
+    float pre[GIPUMA_HIP_MAX_VIEWS][MAXC];
+    int nv, nc;
+    float F; /* exact multi-view cost */
+} task_eval;
+
+static void eval_task(const gipuma_hip_desc *d, int x, int y, const float pl[4], task_eval *t)
+{
+    float cv[GIPUMA_HIP_MAX_VIEWS];
+    t->nv = d->n_selected;
+    for (int i = 0; i < t->nv; i++) {
+        t->nc = view_prefix(d, d->selected[i], x, y, pl, t->pre[i]);
+        cv[i] = t->pre[i][t->nc - 1];
+    }
+    t->F = go_aggregate(cv, t->nv, d->params.cost_comb, d->params.n_best, d->params.good_factor);
+}
+
+/* Early-termination policy, sequential over views in `order`; a view stops after the first
+ * column c with prefix >= min(b_{m-1}, kappa*m*B) (b: m smallest lower bounds so far).
+ * stop[k] = columns evaluated for the k-th processed view.  Returns decision (1 = accept)
+ * and checks it against the exact one. */
+static int policy_run(const task_eval *t, const int *order, int m, float B, float kappa, unsigned char *stop,
+                      int *ambiguous)
+{
+    float b[8];
+    int trunc_in[8];
+    for (int i = 0; i < m; i++) {
+        b[i] = INFINITY;
+        trunc_in[i] = 0;
+    }
+    const float thr = kappa * (float)m * B * 1.000001f;
+    for (int k = 0; k < t->nv; k++) {
+        const int v = order[k];
+        const float tau = fminf(b[m - 1], thr);
+        int c = 0;
+        float p = 0.f;
+        int truncated = 0;
+        for (; c < t->nc; c++) {
+            p = t->pre[v][c];
+            if (p >= tau && c < t->nc - 1) {
+                truncated = 1;
+                c++;
+                break;
+            }
+        }
+        stop[k] = (unsigned char)c;
+        /* insert p */
+        int tr = truncated;
+        for (int i = 0; i < m; i++) {
+            if (p < b[i]) {
+                const float tf = b[i];
+                const int tt = trunc_in[i];
+                b[i] = p;
+                trunc_in[i] = tr;
+                p = tf;
+                tr = tt;
+            }
+        }
+    }
+    float sum = 0.f;
+    int anytr = 0;
+    for (int i = 0; i < m; i++) {
+        sum = sum + b[i];
+        anytr |= trunc_in[i];
+    }
+    const float Fp = sum / (float)m;
+    *ambiguous = (Fp < B) && anytr;
+    return Fp < B;
+}
+
+typedef struct {
+    /* per launch */
+    double prop_tasks, ref_tasks[4];
+    double cols_full_prop, cols_full_ref[4];
+    /* lane-level evaluated columns by policy p (0: fixed order k=1, 1: best-first per lane k=1,
+     * 2: fixed order kappa = 1/m i.e. thr = B (ambiguity counted), 3: wave-adaptive order) */
+    double cols_lane_prop[4], cols_lane_ref[4][4];
+    double cols_wave_ref[4][4]; /* wave-level (max over the 64 lanes per processed view) */
+    double cols_wave_prop[4];
+    double ambiguous_prop[4], ambiguous_ref[4][4];
+    double wrong[4];
+    /* sharing */
+    double jobs, job_union_cols, job_target_cols, job_hist[5];
+    double accepted_prop, accepted_ref[4];
+    double ratio_hist_ref[4][8]; /* F/B histogram per refine step: <1, <1.2, <1.5, <2, <3, <5, <10, >= */
+    double ratio_hist_prop[8];
+} launch_stats;
+
+static int ratio_bin(float F, float B)
+{
+    const float r = F / B;
+    if (r < 1.f) return 0;
+    if (r < 1.2f) return 1;
+    if (r < 1.5f) return 2;
+    if (r < 2.f) return 3;
+    if (r < 3.f) return 4;
+    if (r < 5.f) return 5;
+    if (r < 10.f) return 6;
+    return 7;
+}
+
+static int nb_of(int k, int x, int y, int rows, int cols, int *nx, int *ny)
+{
+    const int dist = k < 4 ? 1 : 5;
+    *nx = x;
+    *ny = y;
+    switch (k & 3) {
+    case 0: *ny = y - dist; return y > dist - 1;
+    case 1: *ny = y + dist; return y < rows - dist;
+    case 2: *nx = x - dist; return x > dist - 1;
+    default: *nx = x + dist; return x < cols - dist;
+    }
+}
+
+/* window [x0,x1) x [y0,y1) of the frame is swept (tile aligned); statistics over all of it.
+ * n_launch half-sweeps; out: n_launch records. */
+int et_stats_run(const gipuma_hip_desc *d, int x0, int y0, int x1, int y1, int n_launch, launch_stats *out,
+                 int verbose)
+{
+    const int rows = d->rows, cols = d->cols;
+    const size_t np = (size_t)rows * cols;
+    float *norm4 = (float *)calloc(np * 4, sizeof(float));
+    float *cost = (float *)calloc(np, sizeof(float));
+    unsigned char *changed = (unsigned char *)malloc(np);
+    memset(changed, 1, np);
+    const int m = d->params.n_best < d->n_selected ? d->params.n_best : d->n_selected;
+    const int nv = d->n_selected;
+    /* init on the window + reach */
+    const int ya = y0 - 5 < 0 ? 0 : y0 - 5, yb = y1 + 5 > rows ? rows : y1 + 5;
+    const int xa = x0 - 5 < 0 ? 0 : x0 - 5, xb = x1 + 5 > cols ? cols : x1 + 5;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int y = ya; y < yb; y++)
+        for (int x = xa; x < xb; x++) go_init_pixel(d, x, y, norm4, cost);
+    memset(out, 0, sizeof(launch_stats) * (size_t)n_launch);
+    const int tw = 32, th = 16;
+    const int ntx = (x1 - x0) / tw, nty = (y1 - y0) / th;
+    for (int L = 0; L < n_launch; L++) {
+        const int it = L / 2, colour = L & 1;
+        const uint32_t phase = go_phase(it, colour);
+        const int history = L >= 2;
+        launch_stats *S = &out[L];
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+        for (int ty = 0; ty < nty; ty++)
+            for (int tx = 0; tx < ntx; tx++) {
+                launch_stats loc;
+                memset(&loc, 0, sizeof loc);
+                /* per tile: 256 pixels of the colour, lane id = (ly << 4) | (lx >> 1) */
+                static __thread unsigned char stopbuf[4][3][256][GIPUMA_HIP_MAX_VIEWS];
+                static __thread unsigned char refvalid[256];
+                static __thread unsigned char ambbuf[4][3][256];
+                static __thread unsigned char pstop[4][2048][GIPUMA_HIP_MAX_VIEWS];
+                int nprop = 0;
+                /* sharing: target masks per (source pixel in extended tile, orientation) */
+                static __thread unsigned char jobmask[2][(16 + 10) * (32 + 10)];
+                memset(jobmask, 0, sizeof jobmask);
+                memset(refvalid, 0, sizeof refvalid);
+                double viewcost_sum[GIPUMA_HIP_MAX_VIEWS];
+                for (int v = 0; v < nv; v++) viewcost_sum[v] = 0;
+                int wave_order[GIPUMA_HIP_MAX_VIEWS];
+                static __thread float curcv[256][GIPUMA_HIP_MAX_VIEWS];
+                /* pre-pass: view costs of every pixel's current plane (order heuristics) */
+                for (int ly = 0; ly < th; ly++)
+                    for (int lxh = 0; lxh < 16; lxh++) {
+                        const int lx = 2 * lxh + ((ly + colour) & 1);
+                        const int x = x0 + tx * tw + lx, y = y0 + ty * th + ly;
+                        const int lane = (ly << 4) | lxh;
+                        task_eval cur;
+                        eval_task(d, x, y, norm4 + 4 * ((size_t)y * cols + x), &cur);
+                        for (int v = 0; v < nv; v++) {
+                            curcv[lane][v] = cur.pre[v][cur.nc - 1];
+                            viewcost_sum[v] += curcv[lane][v];
+                        }
+                    }
+                for (int v = 0; v < nv; v++) wave_order[v] = v;
+                for (int a = 1; a < nv; a++) {
+                    const int ov = wave_order[a];
+                    int bpos = a;
+                    for (; bpos >= 1 && viewcost_sum[ov] < viewcost_sum[wave_order[bpos - 1]]; bpos--)
+                        wave_order[bpos] = wave_order[bpos - 1];
+                    wave_order[bpos] = ov;
+                }
+                for (int ly = 0; ly < th; ly++)
+                    for (int lxh = 0; lxh < 16; lxh++) {
+                        const int lx = 2 * lxh + ((ly + colour) & 1);
+                        const int x = x0 + tx * tw + lx, y = y0 + ty * th + ly;
+                        const int lane = (ly << 4) | lxh;
+                        const size_t center = (size_t)y * cols + x;
+                        go_pixel_state st;
+                        memcpy(st.pl, norm4 + 4 * center, sizeof st.pl);
+                        st.cost = cost[center];
+                        st.depth = go_depth_from_plane(&d->cameras[0], st.pl, x, y);
+                        const float B0 = st.cost;
+                        int chg = 0;
+                        /* candidates + skip rules */
+                        float cands[8][4];
+                        int valid[8], need[8];
+                        for (int k = 0; k < 8; k++) {
+                            int nx, ny;
+                            valid[k] = nb_of(k, x, y, rows, cols, &nx, &ny);
+                            need[k] = 0;
+                            if (!valid[k]) continue;
+                            const size_t nb = (size_t)ny * cols + nx;
+                            memcpy(cands[k], norm4 + 4 * nb, 16);
+                            int fresh = 1;
+                            if (!memcmp(cands[k], st.pl, 16)) fresh = 0;
+                            if (fresh && history && !changed[nb]) fresh = 0;
+                            for (int j = 0; j < k && fresh; j++)
+                                if (valid[j] && !memcmp(cands[k], cands[j], 16)) fresh = 0;
+                            need[k] = fresh;
+                        }
+                        /* best-first order of this lane: by the view costs of its current plane */
+                        int order_fixed[GIPUMA_HIP_MAX_VIEWS], order_best[GIPUMA_HIP_MAX_VIEWS];
+                        {
+                            const float *cv = curcv[lane];
+                            for (int v = 0; v < nv; v++) {
+                                order_fixed[v] = v;
+                                order_best[v] = v;
+                            }
+                            for (int a = 1; a < nv; a++) {
+                                const int ov = order_best[a];
+                                int bpos = a;
+                                for (; bpos >= 1 && cv[ov] < cv[order_best[bpos - 1]]; bpos--)
+                                    order_best[bpos] = order_best[bpos - 1];
+                                order_best[bpos] = ov;
+                            }
+                        }
+                        for (int k = 0; k < 8; k++) {
+                            if (!need[k]) continue;
+                            task_eval te;
+                            eval_task(d, x, y, cands[k], &te);
+                            loc.prop_tasks += 1;
+                            loc.cols_full_prop += (double)te.nv * te.nc;
+                            loc.ratio_hist_prop[ratio_bin(te.F, B0)] += 1;
+                            unsigned char stop[GIPUMA_HIP_MAX_VIEWS];
+                            int amb;
+                            const int *orders[4] = {order_fixed, order_fixed, order_fixed, order_fixed};
+                            const float kap[4] = {1.f, THETA1 / (float)m, THETA2 / (float)m, THETA3 / (float)m};
+                            for (int p = 0; p < 4; p++) {
+                                const int dec = policy_run(&te, orders[p], m, B0, kap[p], stop, &amb);
+                                int s = 0;
+                                for (int v = 0; v < nv; v++) s += stop[v];
+                                loc.cols_lane_prop[p] += s;
+                                loc.ambiguous_prop[p] += amb;
+                                if (!amb && dec != (te.F < B0)) loc.wrong[p] += 1;
+                                if (nprop < 2048) memcpy(pstop[p][nprop], stop, (size_t)nv);
+                            }
+                            if (nprop < 2048) nprop++;
+                            /* sharing bookkeeping */
+                            {
+                                const int dist = k < 4 ? 1 : 5;
+                                const int sx = lx + ((k & 3) == 2 ? -dist : (k & 3) == 3 ? dist : 0) + 5;
+                                const int sy = ly + ((k & 3) == 0 ? -dist : (k & 3) == 1 ? dist : 0) + 5;
+                                const int orient = (k & 3) >= 2 ? 0 : 1; /* 0: horizontal targets */
+                                /* target index 0..3: offsets -5,-1,+1,+5 of the target from the source */
+                                const int off = (k & 3) == 2 || (k & 3) == 0 ? dist : -dist; /* target - source */
+                                const int ti = off == -5 ? 0 : off == -1 ? 1 : off == 1 ? 2 : 3;
+                                jobmask[orient][sy * 42 + sx] |= (unsigned char)(1u << ti);
+                            }
+                            /* accept replay */
+                            const float dnew = go_depth_from_plane(&d->cameras[0], cands[k], x, y);
+                            if (dnew >= d->cameras[0].depth_min && dnew <= d->cameras[0].depth_max && te.F < st.cost) {
+                                st.depth = dnew;
+                                memcpy(st.pl, cands[k], 16);
+                                st.cost = te.F;
+                                chg = 1;
+                                loc.accepted_prop += 1;
+                            }
+                        }
+                        /* refinement */
+                        st.depth = go_depth_from_plane(&d->cameras[0], st.pl, x, y);
+                        {
+                            const gipuma_hip_camera *cam = &d->cameras[0];
+                            const gipuma_hip_params *ap = &d->params;
+                            float view[3];
+                            go_view_vector(cam, x, y, view);
+                            float deltaN = 1.0f;
+                            uint32_t draw = 0;
+                            int step = 0;
+                            for (float deltaZ = ap->max_disparity / 2.0f; deltaZ >= 0.01f; deltaZ = deltaZ / 10.0f, step++) {
+                                const float disp = go_disp_depth(cam->f, cam->baseline, st.depth);
+                                const float minDelta = -fminf(deltaZ, ap->min_disparity + disp);
+                                const float maxDelta = fminf(deltaZ, ap->max_disparity - disp);
+                                const float u0 = go_uniform(d->seed, phase, (uint32_t)x, (uint32_t)y, draw++);
+                                const float u1 = go_uniform(d->seed, phase, (uint32_t)x, (uint32_t)y, draw++);
+                                const float u2 = go_uniform(d->seed, phase, (uint32_t)x, (uint32_t)y, draw++);
+                                const float u3 = go_uniform(d->seed, phase, (uint32_t)x, (uint32_t)y, draw++);
+                                const float dz = go_between(u0, minDelta, maxDelta);
+                                float dispOut = fminf(fmaxf(disp + dz, ap->min_disparity), ap->max_disparity);
+                                const float depthOut = go_disp_depth(cam->f, cam->baseline, dispOut);
+                                float cand[4];
+                                cand[0] = st.pl[0] + go_between(u1, -deltaN, deltaN);
+                                cand[1] = st.pl[1] + go_between(u2, -deltaN, deltaN);
+                                cand[2] = st.pl[2] + go_between(u3, -deltaN, deltaN);
+                                go_normalize(cand);
+                                go_on_hemisphere(cand, view);
+                                cand[3] = go_plane_d(cam, cand, x, y, depthOut);
+                                task_eval te;
+                                eval_task(d, x, y, cand, &te);
+                                const int sidx = step < 3 ? step : 3;
+                                loc.ref_tasks[sidx] += 1;
+                                loc.cols_full_ref[sidx] += (double)te.nv * te.nc;
+                                loc.ratio_hist_ref[sidx][ratio_bin(te.F, st.cost)] += 1;
+                                unsigned char stop[GIPUMA_HIP_MAX_VIEWS];
+                                int amb;
+                                const int *orders[4] = {order_fixed, order_fixed, order_fixed, order_fixed};
+                                const float kap[4] = {1.f, THETA1 / (float)m, THETA2 / (float)m, THETA3 / (float)m};
+                                for (int p = 0; p < 4; p++) {
+                                    const int dec = policy_run(&te, orders[p], m, st.cost, kap[p], stop, &amb);
+                                    int s = 0;
+                                    for (int v = 0; v < nv; v++) s += stop[v];
+                                    loc.cols_lane_ref[p][sidx] += s;
+                                    loc.ambiguous_ref[p][sidx] += amb;
+                                    if (!amb && dec != (te.F < st.cost)) loc.wrong[p] += 1;
+                                    if (step < 3) { memcpy(stopbuf[p][step][lane], stop, (size_t)nv); ambbuf[p][step][lane] = (unsigned char)amb; }
+                                }
+                                refvalid[lane] = 1;
+                                if (te.F < st.cost) {
+                                    st.cost = te.F;
+                                    st.depth = depthOut;
+                                    memcpy(st.pl, cand, 16);
+                                    chg = 1;
+                                    loc.accepted_ref[sidx] += 1;
+                                }
+                                deltaN = deltaN / 4.0f;
+                            }
+                        }
+                        cost[center] = st.cost;
+                        memcpy(norm4 + 4 * center, st.pl, 16);
+                        changed[center] = (unsigned char)chg;
+                    }
+                /* wave level: refinement, wave = 64 consecutive lanes; a wave with an ambiguous lane
+                 * re-runs the step under policy 0 (3B) */
+                for (int p = 0; p < 4; p++)
+                    for (int step = 0; step < 3; step++)
+                        for (int w = 0; w < 4; w++) {
+                            int anyamb = 0;
+                            for (int l = 0; l < 64; l++)
+                                if (refvalid[w * 64 + l] && ambbuf[p][step][w * 64 + l]) anyamb = 1;
+                            for (int k = 0; k < nv; k++) {
+                                int mx = 0, mx0 = 0;
+                                for (int l = 0; l < 64; l++)
+                                    if (refvalid[w * 64 + l]) {
+                                        if (stopbuf[p][step][w * 64 + l][k] > mx) mx = stopbuf[p][step][w * 64 + l][k];
+                                        if (stopbuf[0][step][w * 64 + l][k] > mx0) mx0 = stopbuf[0][step][w * 64 + l][k];
+                                    }
+                                loc.cols_wave_ref[p][step] += 64.0 * mx + (anyamb ? 64.0 * mx0 : 0.0);
+                            }
+                        }
+                /* propagation: groups of 64 tasks in owner order */
+                for (int p = 0; p < 4; p++)
+                    for (int g = 0; g < nprop; g += 64)
+                        for (int k = 0; k < nv; k++) {
+                            int mx = 0;
+                            const int e = g + 64 < nprop ? g + 64 : nprop;
+                            for (int l = g; l < e; l++)
+                                if (pstop[p][l][k] > mx) mx = pstop[p][l][k];
+                            loc.cols_wave_prop[p] += 64.0 * mx;
+                        }
+                /* sharing */
+                for (int o = 0; o < 2; o++)
+                    for (int c = 0; c < 26 * 42; c++) {
+                        const unsigned mk = jobmask[o][c];
+                        if (!mk) continue;
+                        loc.jobs += 1;
+                        /* union columns: target ti covers union columns start[ti]..start[ti]+7 */
+                        static const int start[4] = {0, 2, 3, 5};
+                        int lo = 99, hi = -1, nt = 0;
+                        for (int ti = 0; ti < 4; ti++)
+                            if (mk & (1u << ti)) {
+                                /* target offset order: mask bit = target-source offset -5,-1,+1,+5 */
+                                if (start[ti] < lo) lo = start[ti];
+                                if (start[ti] + 8 > hi) hi = start[ti] + 8;
+                                nt++;
+                            }
+                        /* exact union (columns covered by at least one target) */
+                        int covered = 0;
+                        for (int cc = 0; cc < 13; cc++) {
+                            int in = 0;
+                            for (int ti = 0; ti < 4; ti++)
+                                if ((mk & (1u << ti)) && cc >= start[ti] && cc < start[ti] + 8) in = 1;
+                            covered += in;
+                        }
+                        loc.job_union_cols += covered;
+                        loc.job_target_cols += 8.0 * nt;
+                        loc.job_hist[nt] += 1;
+                    }
+#pragma omp critical
+                {
+                    double *a = (double *)S;
+                    const double *b = (const double *)&loc;
+                    for (size_t i = 0; i < sizeof(launch_stats) / sizeof(double); i++) a[i] += b[i];
+                }
+            }
+        if (verbose) {
+            fprintf(stderr, "launch %d done: prop %.0f tasks\n", L, S->prop_tasks);
+        }
+    }
+    free(norm4);
+    free(cost);
+    free(changed);
+    return 0;
+}
+
+int et_stats_sizeof(void) { return (int)sizeof(launch_stats); }

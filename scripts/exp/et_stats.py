@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""EXPERIMENT driver for et_stats.c (CPU only): early-termination and dis-sharing potential on a
+window of a config-C frame.  usage: et_stats.py [cfg] [x0 y0 x1 y1] [n_launch]"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from gipuma_amd import abi, synth  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = "/tmp/libet_stats.so"
+subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-fPIC", "-fopenmp", "-ffp-contract=off", "-mavx2", "-mfma",
+                       "-fno-math-errno", "-shared", "-o", SO, os.path.join(HERE, "et_stats.c"), "-lm"])
+L = C.CDLL(SO)
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C"
+win = [int(v) for v in sys.argv[2:6]] if len(sys.argv) > 5 else [640, 480, 896, 608]
+nl = int(sys.argv[6]) if len(sys.argv) > 6 else 16
+scene = sys.argv[7] if len(sys.argv) > 7 else None
+kw = {}
+if scene:
+    kw["scene"] = scene
+gs, info = synth.build_problem(cfg, **kw)
+nd = L.et_stats_sizeof() // 8
+out = np.zeros((nl, nd), np.float64)
+L.et_stats_run.argtypes = [C.POINTER(abi.Desc), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+L.et_stats_run(C.byref(gs.desc), win[0], win[1], win[2], win[3], nl, out.ctypes.data, 1)
+
+# field offsets (doubles), in declaration order
+names = [("prop_tasks", 1), ("ref_tasks", 4), ("cols_full_prop", 1), ("cols_full_ref", 4),
+         ("cols_lane_prop", 4), ("cols_lane_ref", 16), ("cols_wave_ref", 16), ("cols_wave_prop", 4),
+         ("ambiguous_prop", 4), ("ambiguous_ref", 16), ("wrong", 4),
+         ("jobs", 1), ("job_union_cols", 1), ("job_target_cols", 1), ("job_hist", 5),
+         ("accepted_prop", 1), ("accepted_ref", 4), ("ratio_hist_ref", 32), ("ratio_hist_prop", 8)]
+off = {}
+o = 0
+for n, k in names:
+    off[n] = (o, k)
+    o += k
+assert o == nd, (o, nd)
+
+
+def f(row, n):
+    a, k = off[n]
+    return row[a:a + k]
+
+
+npx = (win[2] - win[0]) * (win[3] - win[1]) / 2
+print("window %s, %d px per colour" % (win, npx))
+pol = ["3B", "th1.0", "th1.5", "th2.0"]
+for li in range(nl):
+    r = out[li]
+    pt = f(r, "prop_tasks")[0]
+    rt = f(r, "ref_tasks")
+    cfp = f(r, "cols_full_prop")[0]
+    cfr = f(r, "cols_full_ref")
+    print("launch %2d: prop %.2f/px (acc %.3f)  refine acc %s" %
+          (li, pt / npx, f(r, "accepted_prop")[0] / max(pt, 1), np.round(f(r, "accepted_ref")[:3] / np.maximum(rt[:3], 1), 3)))
+    print("    F/B hist prop  %s" % np.round(f(r, "ratio_hist_prop") / max(pt, 1), 3))
+    rh = f(r, "ratio_hist_ref").reshape(4, 8)
+    for s in range(3):
+        print("    F/B hist ref%d  %s" % (s, np.round(rh[s] / max(rt[s], 1), 3)))
+    clp = f(r, "cols_lane_prop")
+    cwp = f(r, "cols_wave_prop")
+    clr = f(r, "cols_lane_ref").reshape(4, 4)
+    cwr = f(r, "cols_wave_ref").reshape(4, 4)
+    amb_r = f(r, "ambiguous_ref").reshape(4, 4)
+    for p in range(4):
+        print("    %-13s prop lane %.3f wave %.3f (amb %.4f) | ref lane %s wave %s amb %s wrong %d" %
+              (pol[p], clp[p] / max(cfp, 1), cwp[p] / max(cfp, 1), f(r, "ambiguous_prop")[p] / max(pt, 1),
+               np.round(clr[p][:3] / np.maximum(cfr[:3], 1), 3), np.round(cwr[p][:3] / np.maximum(cfr[:3], 1), 3),
+               np.round(amb_r[p][:3] / np.maximum(rt[:3], 1), 4), f(r, "wrong")[p]))
+    jobs = f(r, "jobs")[0]
+    print("    sharing: jobs %.2f/px, targets/job hist %s, union cols / target cols = %.3f" %
+          (jobs / npx, np.round(f(r, "job_hist") / max(jobs, 1), 3),
+           f(r, "job_union_cols")[0] / max(f(r, "job_target_cols")[0], 1)))

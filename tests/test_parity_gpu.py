@@ -212,13 +212,13 @@ def test_device_resident_images_with_pitch(hip):
 
 
 @pytest.mark.parametrize("tune", [1 << 30, 1 << 29, 1 << 28, (1 << 30) | (1 << 28), 1 << 27, 1 << 26,
-                                  (1 << 26) | (1 << 29), 1 << 23])
+                                  (1 << 26) | (1 << 29), 1 << 23, 1 << 25, (1 << 25) | (1 << 27)])
 def test_kernel_variants_are_bit_identical(hip, tune):
     """the performance-only choices of the sweep kernels -- float-encoded window offsets + the
     hand-pipelined loop (off: bit 30), task order owner-major (bit 29) / source-major (bit 28) in
     every iteration instead of switching after iteration 1, the column-per-lane kernel never (bit
     27) / in every half-sweep (bit 26) instead of the first four, the history skip rule off (bit
-    23) -- must not change a single bit.
+    23), early termination of view costs off (bit 25) -- must not change a single bit.
     Box 15 (the pipelined and column-per-lane instantiations), 4 iterations so that the default run
     uses both kernels and both task orders."""
     gs, _ = synth.build_problem(synth.tiny_config(cols=160, rows=112, n_src=4, blocksize=15, iterations=4,
@@ -235,6 +235,29 @@ def test_kernel_variants_are_bit_identical(hip, tune):
         o = OracleState(gs).run()
         assert_same(a[0], o[0], "default vs oracle norm4")
         assert_same(a[1], o[1], "default vs oracle cost")
+
+
+@pytest.mark.parametrize("theta", ["0.01,0.01,0.01", "0.5,0.7,0.9", "1,1,1", "1.2,2,3", "1e9,1e9,1e9"])
+@pytest.mark.parametrize("cfg", [dict(cols=160, rows=112, n_src=4, blocksize=15, iterations=4, n_best=3),
+                                 dict(cols=96, rows=80, n_src=5, blocksize=11, iterations=3, n_best=1),
+                                 dict(cols=96, rows=80, n_src=2, blocksize=15, iterations=3, n_best=4)])
+def test_early_termination_is_exact_for_any_bound(hip, theta, cfg):
+    """refinement evaluations are cut off once every view's partial cost has reached
+    theta * (cost to beat) and redone when that leaves the outcome open (pm::multiview_cost):
+    exact for ANY theta.  Tiny theta forces the redo path on almost every wavefront, huge theta
+    leaves only the value-exact rule; the column-per-lane kernel is switched off (bit 27) so that
+    every half-sweep runs the pixel-per-lane kernel that has the cut-off."""
+    gs, _ = synth.build_problem(synth.tiny_config(**cfg))
+    o = OracleState(gs).run()
+    os.environ["GIPUMA_HIP_ET_THETA"] = theta
+    os.environ["GIPUMA_HIP_TUNE"] = str(1 << 27)
+    try:
+        a = runcuda(gs)
+    finally:
+        del os.environ["GIPUMA_HIP_ET_THETA"]
+        del os.environ["GIPUMA_HIP_TUNE"]
+    assert_same(a[0], o[0], "theta %s norm4" % theta)
+    assert_same(a[1], o[1], "theta %s cost" % theta)
 
 
 @pytest.mark.parametrize("seq", [
