@@ -11,6 +11,7 @@
 //   * no per-pixel RNG state array (48 B/pixel, gipuma.cu:1840): the RNG is counter based.
 #include "../../include/gipuma_hip.h"
 #include "pm_device.h"
+#include "pm_prop_shared.h"
 
 #include <cmath>
 #include <cstdio>
@@ -70,6 +71,7 @@ struct gipuma_hip_session {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // experiment aid (GIPUMA_HIP_LAUNCH_TIMES=1): one event per half-sweep launch of gipuma_hip_solve,
     // durations printed to stderr
+    bool prop_attr_set = false;
     bool launch_times = false;
     std::vector<hipEvent_t> lev;
 };
@@ -192,6 +194,27 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
     if (cols_ok && (2 * iteration + colour < s->cols_launches || (tune & Tune::kColsAlways))) {
         k = s->combine_reg ? pm::sweep_cols_kernel<15, true> : pm::sweep_cols_kernel<15, false>;
     }
+    // propagation with shared patch samples (pm_prop_shared.h) where that instantiation exists; the
+    // refinement stage follows as its own launch of the kernel chosen above
+    const bool shared_ok = s->u8 && s->ch == 1 && s->hp.magic_addr && (s->box == 15 || s->box == 11) &&
+                           s->combine_reg && (stages & 3u) && (tune & Tune::kSharedProp) &&
+                           !(tune & (Tune::kNoSkip | Tune::kNoInterior));
+    if (shared_ok) {
+        typedef void (*prop_fn)(const pm::Problem *, float4 *, float *, int, unsigned, unsigned);
+        const prop_fn pk = s->box == 15 ? pm::prop_shared_kernel<15> : pm::prop_shared_kernel<11>;
+        const size_t plds = sizeof(float) * (size_t)(s->box == 15 ? pm::PsLayout<15>::total : pm::PsLayout<11>::total);
+        if (!s->prop_attr_set) {
+            HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(pk), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)plds));
+            s->prop_attr_set = true;
+        }
+        hipLaunchKernelGGL(pk, dim3(gx * gy), dim3(pm::kThreads), plds, s->stream, s->dp, s->norm4, s->cost, colour,
+                           stages & 3u, tune);
+        HIP_OK(hipGetLastError());
+        if (!(stages & 4u)) return 0;
+        stages = 4u;
+        tune |= Tune::kAccumChanged;
+    }
     hipLaunchKernelGGL(k, dim3(gx * gy), dim3(pm::kThreads), s->lds_sweep, s->stream, s->dp, s->norm4,
                        s->cost, colour, phase, stages, tune);
     HIP_OK(hipGetLastError());
@@ -280,7 +303,7 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     s->unfused = (d->flags & GIPUMA_HIP_FLAG_UNFUSED) != 0;
     if (const char *t = getenv("GIPUMA_HIP_TUNE")) {
         s->tune = (unsigned)strtoul(t, nullptr, 0);
-        s->tune &= ~(Tune::kHistorySkip | Tune::kUntrustedCosts);  // host-internal bits, never from the environment
+        s->tune &= ~(Tune::kHistorySkip | Tune::kUntrustedCosts | Tune::kAccumChanged);  // host-internal bits
     }
     if (const char *t = getenv("GIPUMA_HIP_COLS_LAUNCHES")) s->cols_launches = atoi(t);  // experiment
     if (const char *t = getenv("GIPUMA_HIP_LAUNCH_TIMES")) s->launch_times = atoi(t) != 0;
@@ -442,6 +465,10 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         g_err = keep;
         return GIPUMA_HIP_ERR_UNSUPPORTED;
     }
+#ifdef PM_PS_PROFILE
+    CREATE_OK(hipMalloc(&hp.prof, 16 * sizeof(unsigned long long)));
+    CREATE_OK(hipMemsetAsync(hp.prof, 0, 16 * sizeof(unsigned long long), s->stream));
+#endif
     CREATE_OK(hipMalloc(&s->dp, sizeof(pm::Problem)));
     CREATE_OK(hipMemcpyAsync(s->dp, &hp, sizeof(pm::Problem), hipMemcpyHostToDevice, s->stream));
     CREATE_OK(hipStreamSynchronize(s->stream));  // host image buffers may be released by the caller
@@ -455,6 +482,17 @@ int gipuma_hip_destroy(gipuma_hip_session *s)
     if (!s) return 0;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+#ifdef PM_PS_PROFILE
+    if (s->hp.prof) {
+        unsigned long long h[16];
+        if (hipMemcpy(h, s->hp.prof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "prop_shared profile (100 MHz ticks along wavefront 0, summed over workgroups):");
+            for (int i = 0; i < 12; i++) fprintf(stderr, " %llu", h[i]);
+            fprintf(stderr, "\n");
+        }
+        (void)hipFree(s->hp.prof);
+    }
+#endif
     for (float *p : s->owned) (void)hipFree(p);
     for (uint32_t *p : s->packed) (void)hipFree(p);
     if (s->flag) (void)hipFree(s->flag);

@@ -48,6 +48,9 @@ struct Problem {  // lives in device memory, read through scalar loads (wave-uni
     // view cost is provably finite and below MAXCOST; theta of refinement step 0, 1, 2+
     int et_enable;
     float et_theta[3];
+#ifdef PM_PS_PROFILE
+    unsigned long long *prof;  // experiment builds only
+#endif
     RefCam rc;
     ViewCam view[kMaxViews];
 };
@@ -250,11 +253,13 @@ struct Tune {  // experiment switches (GIPUMA_HIP_TUNE), all default off
     static constexpr unsigned kNoLut = 1, kNoInterior = 2, kNoXcdRemap = 4, kGenericBox = 8,
                               kGenericCombine = 16, kRowMajorTiles = 32, kNoSkip = 64,
                               kUntrustedCosts = 128,  // set by the host after gipuma_hip_set_state
-                              kNoMagicAddr = 1u << 30,  // integer window addressing (bits 8..23: band height)
+                              kSharedProp = 1u << 20,    // propagation by the shared-sample kernel (pm_prop_shared.h); opt-in while it is slower
+                              kNoMagicAddr = 1u << 30,  // integer window addressing (bits 8..19: band height)
                               kOwnerMajorTasks = 1u << 29,   // always owner-major task lists
                               kSourceMajorTasks = 1u << 28,  // always source-major (default: by iteration)
                               kNoColsKernel = 1u << 27,      // never the column-per-lane kernel
                               kColsAlways = 1u << 26,        // ... or in every iteration (default: 0 and 1)
+                              kAccumChanged = 1u << 31,      // host-internal: OR into Problem::changed (second launch of a split half-sweep)
                               kNoEarlyExit = 1u << 25,       // no early termination of view costs
                               kHistorySkip = 1u << 24,       // set by the host when the history rule is valid
                               kNoHistory = 1u << 23;         // never use it
@@ -1076,7 +1081,7 @@ __device__ __forceinline__ TileXY tile_of(int b, int gx, int gy, unsigned tune)
         o.x = t % gx;
         o.y = t / gx;
     } else {
-        const int bo = (int)((tune >> 8) & 0x7fffu);         // experiment override of the band height
+        const int bo = (int)((tune >> 8) & 0xfffu);          // experiment override of the band height (bits 8..19)
         const int bh = bo ? min(bo, gy) : (gy + 7) >> 3;  // band height in tile rows
         const int band = t / (bh * gx);
         const int h = min(bh, gy - band * bh);   // the last band may be shorter
@@ -1317,12 +1322,12 @@ struct SweepLane {
     int n_tasks;                      // surviving (pixel, candidate) pairs of the workgroup
 };
 
-// tile staging, lane -> pixel mapping, state read (gipuma.cu:1527-1530), exact skipping rules and
-// the workgroup task list
+// tile staging, lane -> pixel mapping, state read (gipuma.cu:1527-1530) and the exact skipping rules:
+// leaves L.needmask = the candidate slots of this lane's pixel that must be evaluated
 template <int BOX, int CH>
-__device__ __forceinline__ void sweep_setup(SweepLane &L, const Problem *__restrict__ P, float *lds,
-                                            const float4 *__restrict__ norm4, const float *__restrict__ cost,
-                                            int colour, unsigned stages, unsigned tune, bool want_lut)
+__device__ __forceinline__ void sweep_read_state(SweepLane &L, const Problem *__restrict__ P, float *lds,
+                                                 const float4 *__restrict__ norm4, const float *__restrict__ cost,
+                                                 int colour, unsigned stages, unsigned tune, bool want_lut)
 {
     const Win<BOX> win(P);
     const RefCam &rc = P->rc;
@@ -1360,6 +1365,7 @@ __device__ __forceinline__ void sweep_setup(SweepLane &L, const Problem *__restr
     L.depth = 0.f;
     L.needmask = 0;
     L.chg = 0;
+    L.n_tasks = 0;
     const bool history = (tune & Tune::kHistorySkip) != 0;
     if (L.active) {
         const float4 pl = norm4[L.center];
@@ -1397,6 +1403,15 @@ __device__ __forceinline__ void sweep_setup(SweepLane &L, const Problem *__restr
         }
         L.needmask = needmask;
     }
+}
+
+// sweep_read_state + the workgroup task list
+template <int BOX, int CH>
+__device__ __forceinline__ void sweep_setup(SweepLane &L, const Problem *__restrict__ P, float *lds,
+                                            const float4 *__restrict__ norm4, const float *__restrict__ cost,
+                                            int colour, unsigned stages, unsigned tune, bool want_lut)
+{
+    sweep_read_state<BOX, CH>(L, P, lds, norm4, cost, colour, stages, tune, want_lut);
     // Workgroup task list.  Two orders, same set of tasks (the order cannot change a result: a task
     // is a pure function of (pixel, plane) and its cost lands in bres[slot][owner]):
     //  * source-major (default): tasks that evaluate the SAME plane -- the plane of other-colour
@@ -1674,7 +1689,7 @@ __global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kerne
     if (L.active) {
         cost[L.center] = L.cst;
         norm4[L.center] = L.pl;
-        P->changed[L.center] = (unsigned char)L.chg;
+        P->changed[L.center] = (unsigned char)(L.chg | ((tune & Tune::kAccumChanged) ? P->changed[L.center] : 0u));
     }
 }
 
@@ -1757,7 +1772,7 @@ __global__ __launch_bounds__(kThreads) void sweep_cols_kernel(const Problem *__r
     if (L.active) {
         cost[L.center] = L.cst;
         norm4[L.center] = L.pl;
-        P->changed[L.center] = (unsigned char)L.chg;
+        P->changed[L.center] = (unsigned char)(L.chg | ((tune & Tune::kAccumChanged) ? P->changed[L.center] : 0u));
     }
 }
 

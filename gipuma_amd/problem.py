@@ -166,6 +166,10 @@ class Session:
     def finalize(self):
         abi.check(self.lib, self.lib.gipuma_hip_finalize(self.h), "gipuma_hip_finalize")
 
+    def sync(self):
+        """wait for the session's stream (gipuma_hip_get_state with no destination copies nothing)"""
+        abi.check(self.lib, self.lib.gipuma_hip_get_state(self.h, None, None), "gipuma_hip_get_state")
+
     def solve(self, timing=True):
         t = abi.Timing()
         abi.check(self.lib, self.lib.gipuma_hip_solve(self.h, C.byref(t) if timing else None),

@@ -159,6 +159,7 @@ typedef struct {
     double accepted_prop, accepted_ref[4];
     double ratio_hist_ref[4][8]; /* F/B histogram per refine step: <1, <1.2, <1.5, <2, <3, <5, <10, >= */
     double ratio_hist_prop[8];
+    double plane_groups, plane_union_samples, plane_task_samples, plane_bbox_samples, plane_maxgroup;
 } launch_stats;
 
 static int ratio_bin(float F, float B)
@@ -225,6 +226,8 @@ int et_stats_run(const gipuma_hip_desc *d, int x0, int y0, int x1, int y1, int n
                 static __thread unsigned char ambbuf[4][3][256];
                 static __thread unsigned char pstop[4][2048][GIPUMA_HIP_MAX_VIEWS];
                 int nprop = 0;
+                static __thread struct { int lx, ly; uint32_t pl[4]; } ptask[2048];
+                int nptask = 0;
                 /* sharing: target masks per (source pixel in extended tile, orientation) */
                 static __thread unsigned char jobmask[2][(16 + 10) * (32 + 10)];
                 memset(jobmask, 0, sizeof jobmask);
@@ -304,6 +307,7 @@ int et_stats_run(const gipuma_hip_desc *d, int x0, int y0, int x1, int y1, int n
                             task_eval te;
                             eval_task(d, x, y, cands[k], &te);
                             loc.prop_tasks += 1;
+                            if (nptask < 2048) { ptask[nptask].lx = lx; ptask[nptask].ly = ly; memcpy(ptask[nptask].pl, cands[k], 16); nptask++; }
                             loc.cols_full_prop += (double)te.nv * te.nc;
                             loc.ratio_hist_prop[ratio_bin(te.F, B0)] += 1;
                             unsigned char stop[GIPUMA_HIP_MAX_VIEWS];
@@ -431,6 +435,43 @@ int et_stats_run(const gipuma_hip_desc *d, int x0, int y0, int x1, int y1, int n
                                 if (pstop[p][l][k] > mx) mx = pstop[p][l][k];
                             loc.cols_wave_prop[p] += 64.0 * mx;
                         }
+                /* plane-keyed sharing: group tasks by (plane bits, parity class), union of sample points */
+                {
+                    static __thread unsigned char used[2048];
+                    static __thread unsigned char bitmap[(16 + 16) * (32 + 16)];
+                    memset(used, 0, (size_t)nptask);
+                    for (int a = 0; a < nptask; a++) {
+                        if (used[a]) continue;
+                        memset(bitmap, 0, sizeof bitmap);
+                        int cnt = 0;
+                        for (int b = a; b < nptask; b++) {
+                            if (used[b] || memcmp(ptask[a].pl, ptask[b].pl, 16)) continue;
+                            if (((ptask[a].lx ^ ptask[b].lx) & 1) || ((ptask[a].ly ^ ptask[b].ly) & 1)) continue;
+                            used[b] = 1;
+                            cnt++;
+                            for (int i = -7; i <= 7; i += 2)
+                                for (int j = -7; j <= 7; j += 2)
+                                    bitmap[(ptask[b].ly + j + 8) * 48 + ptask[b].lx + i + 8] = 1;
+                        }
+                        int un = 0;
+                        int bx0 = 999, bx1 = -999, by0 = 999, by1 = -999;
+                        for (size_t c = 0; c < sizeof bitmap; c++) {
+                            un += bitmap[c];
+                            if (bitmap[c]) {
+                                const int by = (int)(c / 48), bx = (int)(c % 48);
+                                if (bx < bx0) bx0 = bx;
+                                if (bx > bx1) bx1 = bx;
+                                if (by < by0) by0 = by;
+                                if (by > by1) by1 = by;
+                            }
+                        }
+                        loc.plane_bbox_samples += ((bx1 - bx0) / 2 + 1) * ((by1 - by0) / 2 + 1);
+                        if (cnt > loc.plane_maxgroup) loc.plane_maxgroup = cnt;
+                        loc.plane_groups += 1;
+                        loc.plane_union_samples += un;
+                        loc.plane_task_samples += 64.0 * cnt;
+                    }
+                }
                 /* sharing */
                 for (int o = 0; o < 2; o++)
                     for (int c = 0; c < 26 * 42; c++) {

@@ -35,7 +35,7 @@ names = [("prop_tasks", 1), ("ref_tasks", 4), ("cols_full_prop", 1), ("cols_full
          ("cols_lane_prop", 4), ("cols_lane_ref", 16), ("cols_wave_ref", 16), ("cols_wave_prop", 4),
          ("ambiguous_prop", 4), ("ambiguous_ref", 16), ("wrong", 4),
          ("jobs", 1), ("job_union_cols", 1), ("job_target_cols", 1), ("job_hist", 5),
-         ("accepted_prop", 1), ("accepted_ref", 4), ("ratio_hist_ref", 32), ("ratio_hist_prop", 8)]
+         ("accepted_prop", 1), ("accepted_ref", 4), ("ratio_hist_ref", 32), ("ratio_hist_prop", 8), ("plane_groups", 1), ("plane_union_samples", 1), ("plane_task_samples", 1), ("plane_bbox_samples", 1), ("plane_maxgroup", 1)]
 off = {}
 o = 0
 for n, k in names:
@@ -78,3 +78,6 @@ for li in range(nl):
     print("    sharing: jobs %.2f/px, targets/job hist %s, union cols / target cols = %.3f" %
           (jobs / npx, np.round(f(r, "job_hist") / max(jobs, 1), 3),
            f(r, "job_union_cols")[0] / max(f(r, "job_target_cols")[0], 1)))
+    print("    plane-keyed: groups %.2f/px, union samples / task samples = %.3f, bbox / task samples = %.3f" %
+          (f(r, "plane_groups")[0] / npx, f(r, "plane_union_samples")[0] / max(f(r, "plane_task_samples")[0], 1),
+           f(r, "plane_bbox_samples")[0] / max(f(r, "plane_task_samples")[0], 1)))
