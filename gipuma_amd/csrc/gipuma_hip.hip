@@ -12,6 +12,7 @@
 #include "../../include/gipuma_hip.h"
 #include "pm_device.h"
 #include "pm_prop_shared.h"
+#include "pm_refine_rows.h"
 
 #include <cmath>
 #include <cstdio>
@@ -53,6 +54,11 @@ struct gipuma_hip_session {
     bool own_stream = false;
     bool u8 = false;         // every image integer valued in [0,255] -> weight table + packed windows
     std::vector<uint32_t *> packed;  // window-packed copies of the selected views (U8 mode)
+    std::vector<uint32_t *> packed_t;  // ... and their column-major variants (row-per-lane refinement)
+    bool rows_kernel = false;  // pm::sweep_rows_kernel usable
+    int rows_from = 0;         // first half-sweep (2*iteration + colour) that uses it
+    int shared_from = 0;       // first half-sweep that uses the shared-sample propagation kernel (when enabled)
+    size_t lds_rows = 0;
     int *flag = nullptr;
     bool combine_reg = false;
     bool unfused = false;
@@ -191,13 +197,19 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
     // slower than one lane per pixel on config B: 18.0 vs 19.8 Mpix/s)
     const bool cols_ok = s->u8 && s->ch == 1 && s->hp.magic_addr && s->box == 15 &&
                          !(tune & (Tune::kNoColsKernel | Tune::kNoInterior));
+    size_t lds = s->lds_sweep;
     if (cols_ok && (2 * iteration + colour < s->cols_launches || (tune & Tune::kColsAlways))) {
         k = s->combine_reg ? pm::sweep_cols_kernel<15, true> : pm::sweep_cols_kernel<15, false>;
+    } else if (s->rows_kernel && 2 * iteration + colour >= s->rows_from) {
+        // refinement by groups of 8 lanes (row per lane, column-major packed views, group-level early exit)
+        k = pm::sweep_rows_kernel<15>;
+        lds = s->lds_rows;
     }
     // propagation with shared patch samples (pm_prop_shared.h) where that instantiation exists; the
     // refinement stage follows as its own launch of the kernel chosen above
     const bool shared_ok = s->u8 && s->ch == 1 && s->hp.magic_addr && (s->box == 15 || s->box == 11) &&
                            s->combine_reg && (stages & 3u) && (tune & Tune::kSharedProp) &&
+                           2 * iteration + colour >= s->shared_from &&
                            !(tune & (Tune::kNoSkip | Tune::kNoInterior));
     if (shared_ok) {
         typedef void (*prop_fn)(const pm::Problem *, float4 *, float *, int, unsigned, unsigned);
@@ -215,7 +227,7 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
         stages = 4u;
         tune |= Tune::kAccumChanged;
     }
-    hipLaunchKernelGGL(k, dim3(gx * gy), dim3(pm::kThreads), s->lds_sweep, s->stream, s->dp, s->norm4,
+    hipLaunchKernelGGL(k, dim3(gx * gy), dim3(pm::kThreads), lds, s->stream, s->dp, s->norm4,
                        s->cost, colour, phase, stages, tune);
     HIP_OK(hipGetLastError());
     return 0;
@@ -433,6 +445,31 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         s->box = 0;  // the no-interior A/B arm only exists for these two variants
         s->combine_reg = false;
     }
+    // row-per-lane refinement (pm_refine_rows.h): box 15, register combiner, packed gray planes whose
+    // column-major copy also fits float-encoded offsets
+    hp.ph = d->rows + 8;
+    s->rows_kernel = s->u8 && s->ch == 1 && hp.magic_addr && s->box == 15 && s->combine_reg &&
+                     (s->tune & Tune::kRowsKernel) && !(s->tune & Tune::kNoInterior) &&
+                     (size_t)(d->cols + 3) * (size_t)hp.ph <= (size_t)pm::kMagicMaxWords;
+    if (const char *t = getenv("GIPUMA_HIP_ROWS_FROM")) s->rows_from = atoi(t);  // experiment
+    if (const char *t = getenv("GIPUMA_HIP_SHARED_FROM")) s->shared_from = atoi(t);  // experiment
+    if (s->rows_kernel) {
+        const size_t words = (size_t)(d->cols + 3) * (size_t)hp.ph;
+        const dim3 pgid((hp.ph + pm::kThreads - 1) / pm::kThreads, d->cols + 3);
+        for (int i = 0; i < d->n_selected; i++) {
+            uint32_t *pk = nullptr;
+            CREATE_OK(hipMalloc(&pk, words * sizeof(uint32_t)));
+            s->packed_t.push_back(pk);
+            hp.view[i].packed_t = pk;
+            hipLaunchKernelGGL(pm::pack_t_kernel, pgid, dim3(pm::kThreads), 0, s->stream, hp.view[i].img, hp.rows,
+                               hp.cols, hp.pitch, hp.ph, pk);
+        }
+        CREATE_OK(hipGetLastError());
+        const int hw = (hp.box_h + 1) / 2;
+        const int texels = (pm::kTileW + 2 * hw + pm::kRowsTilePad) * (pm::kSweepTileH + 2 * hw);
+        s->lds_rows = sizeof(float) * ((size_t)pm::lut_size<1>() + (size_t)4 * texels +
+                                       (size_t)pm::work_floats<1>(texels, true));
+    }
     // early termination of refinement evaluations (pm::multiview_cost): only where every view cost is
     // provably finite and below MAXCOST for every plane, so that numValid == n_sel always
     // (gipuma.cu:771-775): weights exp(-k/gamma) <= 1 from the table, dis <= (1-alpha)*tau_c + alpha*tau_g
@@ -495,6 +532,7 @@ int gipuma_hip_destroy(gipuma_hip_session *s)
 #endif
     for (float *p : s->owned) (void)hipFree(p);
     for (uint32_t *p : s->packed) (void)hipFree(p);
+    for (uint32_t *p : s->packed_t) (void)hipFree(p);
     if (s->flag) (void)hipFree(s->flag);
     if (s->dp) (void)hipFree(s->dp);
     if (s->changed) (void)hipFree(s->changed);

@@ -32,6 +32,7 @@ struct ViewCam {  // Camera_cu of a selected source view + its image plane
     int pad;
     const float *img;        // float plane (row-major, Problem::pitch)
     const uint32_t *packed;  // window-packed u8 copy (see pack_kernel), or nullptr
+    const uint32_t *packed_t;  // column-major variant (see pack_t_kernel), or nullptr
 };
 struct Problem {  // lives in device memory, read through scalar loads (wave-uniform)
     int rows, cols, pitch, n_sel;
@@ -42,7 +43,7 @@ struct Problem {  // lives in device memory, read through scalar loads (wave-uni
     const float *ref;
     int pw, channels;  // packed layout: texels per row of V (cols + 8); 1 = gray, 4 = colour
     int magic_addr;    // gray packed planes small enough (< 2^21 words) for float-encoded offsets
-    int pad_;
+    int ph;            // column-major packed layout: words per column of VT (rows + 8)
     unsigned char *changed;  // per pixel: did its plane change in its colour's last half-sweep (history rule)
     // early termination of refinement evaluations (see multiview_cost): enabled by the host when every
     // view cost is provably finite and below MAXCOST; theta of refinement step 0, 1, 2+
@@ -253,6 +254,7 @@ struct Tune {  // experiment switches (GIPUMA_HIP_TUNE), all default off
     static constexpr unsigned kNoLut = 1, kNoInterior = 2, kNoXcdRemap = 4, kGenericBox = 8,
                               kGenericCombine = 16, kRowMajorTiles = 32, kNoSkip = 64,
                               kUntrustedCosts = 128,  // set by the host after gipuma_hip_set_state
+                              kRowsKernel = 1u << 21,    // refinement by the row-per-lane kernel (pm_refine_rows.h); opt-in: not faster when fused
                               kSharedProp = 1u << 20,    // propagation by the shared-sample kernel (pm_prop_shared.h); opt-in while it is slower
                               kNoMagicAddr = 1u << 30,  // integer window addressing (bits 8..19: band height)
                               kOwnerMajorTasks = 1u << 29,   // always owner-major task lists
@@ -378,13 +380,14 @@ __global__ __launch_bounds__(kThreads) void rcp_selftest_kernel(unsigned long lo
 __device__ __forceinline__ float min_nc(float x, float tau)
 {
     float r;
-    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(tau));
+    // tau is wave-uniform (a kernel parameter): taken as a scalar operand, no v_mov per use
+    asm("v_min_f32_e64 %0, %1, %2" : "=v"(r) : "v"(x), "s"(tau));
     return r;
 }
 __device__ __forceinline__ float min_abs_nc(float x, float tau)  // fminf(fabsf(x), tau)
 {
     float r;
-    asm("v_min_f32_e64 %0, |%1|, %2" : "=v"(r) : "v"(x), "v"(tau));
+    asm("v_min_f32_e64 %0, |%1|, %2" : "=v"(r) : "v"(x), "s"(tau));
     return r;
 }
 
@@ -1094,24 +1097,26 @@ __device__ __forceinline__ TileXY tile_of(int b, int gx, int gy, unsigned tune)
 
 // stage the reference tile (+halo) and the weight table; the tile holds clamp-to-edge point
 // samples exactly like the reference's (gipuma.cu:1393-1402, 1513-1522)
-template <int BOX, int CH>
+// (PAD: extra texels per tile row, so that lanes two tile rows apart do not share LDS banks)
+template <int BOX, int CH, int PAD = 0>
 __device__ __forceinline__ void stage_tile(const Problem *__restrict__ P, float *lds, int x0, int y0,
                                            int tile_h, const Win<BOX> &win, bool want_lut)
 {
     const int hw = win.halo_w(), hh = win.halo_h();
     const int tw = kTileW + 2 * hw, th = tile_h + 2 * hh;
+    const int tws = tw + PAD;  // row stride of the float4 tile
     const gptr_f32 ref = (gptr_f32)P->ref;
     float *tile = lds + lut_size<CH>();  // float4 per texel
     // gray: the scalar image goes to a scratch plane behind the float4 tile first, so that the
     // central differences can be formed once per tile instead of once per sample
-    float *plane = tile + 4 * tw * th;
+    float *plane = tile + 4 * tws * th;
     for (int k = threadIdx.x; k < tw * th; k += kThreads) {
         const int ty = k / tw, tx = k - ty * tw;
         const int gx = clampi(x0 - hw + tx, 0, P->cols - 1);
         const int gy = clampi(y0 - hh + ty, 0, P->rows - 1);
         if (CH == 4) {
             const gptr_f32 s = ref + (gy * P->pitch + 4 * gx);
-            *reinterpret_cast<float4 *>(tile + 4 * k) = make_float4(s[0], s[1], s[2], 0.0f);
+            *reinterpret_cast<float4 *>(tile + 4 * (ty * tws + tx)) = make_float4(s[0], s[1], s[2], 0.0f);
         } else {
             plane[k] = ref[gy * P->pitch + gx];
         }
@@ -1132,7 +1137,7 @@ __device__ __forceinline__ void stage_tile(const Problem *__restrict__ P, float 
             }
             // .w repeats I so that the per-sample read uses all four dwords: one ds_read_b128 (4 LDS
             // cycles) instead of the ds_read_b96 (8) the compiler picks for three
-            *reinterpret_cast<float4 *>(tile + 4 * k) = make_float4(plane[k], gx1, gy1, plane[k]);
+            *reinterpret_cast<float4 *>(tile + 4 * (ty * tws + tx)) = make_float4(plane[k], gx1, gy1, plane[k]);
         }
         __syncthreads();
     }
@@ -1324,7 +1329,7 @@ struct SweepLane {
 
 // tile staging, lane -> pixel mapping, state read (gipuma.cu:1527-1530) and the exact skipping rules:
 // leaves L.needmask = the candidate slots of this lane's pixel that must be evaluated
-template <int BOX, int CH>
+template <int BOX, int CH, int PAD = 0>
 __device__ __forceinline__ void sweep_read_state(SweepLane &L, const Problem *__restrict__ P, float *lds,
                                                  const float4 *__restrict__ norm4, const float *__restrict__ cost,
                                                  int colour, unsigned stages, unsigned tune, bool want_lut)
@@ -1337,10 +1342,10 @@ __device__ __forceinline__ void sweep_read_state(SweepLane &L, const Problem *__
     const TileXY txy = tile_of(blockIdx.x, gx, gy, tune);
     L.x0 = txy.x * kTileW;
     L.y0 = txy.y * kSweepTileH;
-    stage_tile<BOX, CH>(P, lds, L.x0, L.y0, kSweepTileH, win, want_lut);
+    stage_tile<BOX, CH, PAD>(P, lds, L.x0, L.y0, kSweepTileH, win, want_lut);
     L.hw = win.halo_w();
     L.hh = win.halo_h();
-    L.tw = kTileW + 2 * L.hw;
+    L.tw = kTileW + 2 * L.hw + PAD;  // row stride of the tile
     const int th = kSweepTileH + 2 * L.hh;
     L.tile = lds + lut_size<CH>();
     float *work = lds + lut_size<CH>() + 4 * L.tw * th;
@@ -1406,12 +1411,12 @@ __device__ __forceinline__ void sweep_read_state(SweepLane &L, const Problem *__
 }
 
 // sweep_read_state + the workgroup task list
-template <int BOX, int CH>
+template <int BOX, int CH, int PAD = 0>
 __device__ __forceinline__ void sweep_setup(SweepLane &L, const Problem *__restrict__ P, float *lds,
                                             const float4 *__restrict__ norm4, const float *__restrict__ cost,
                                             int colour, unsigned stages, unsigned tune, bool want_lut)
 {
-    sweep_read_state<BOX, CH>(L, P, lds, norm4, cost, colour, stages, tune, want_lut);
+    sweep_read_state<BOX, CH, PAD>(L, P, lds, norm4, cost, colour, stages, tune, want_lut);
     // Workgroup task list.  Two orders, same set of tasks (the order cannot change a result: a task
     // is a pure function of (pixel, plane) and its cost lands in bres[slot][owner]):
     //  * source-major (default): tasks that evaluate the SAME plane -- the plane of other-colour

@@ -160,6 +160,8 @@ typedef struct {
     double ratio_hist_ref[4][8]; /* F/B histogram per refine step: <1, <1.2, <1.5, <2, <3, <5, <10, >= */
     double ratio_hist_prop[8];
     double plane_groups, plane_union_samples, plane_task_samples, plane_bbox_samples, plane_maxgroup;
+    double cols_w8_ref[4][4]; /* like cols_wave_ref but a 'wave' of 8 tasks (8 lanes per task) */
+    double seen4, seen8, seen32;  /* needed prop tasks whose plane this pixel evaluated before (ring of K) */
 } launch_stats;
 
 static int ratio_bin(float F, float B)
@@ -197,6 +199,9 @@ int et_stats_run(const gipuma_hip_desc *d, int x0, int y0, int x1, int y1, int n
     const size_t np = (size_t)rows * cols;
     float *norm4 = (float *)calloc(np * 4, sizeof(float));
     float *cost = (float *)calloc(np, sizeof(float));
+    float *hist = (float *)calloc(np * 4 * 32, sizeof(float)); /* ring of 32 planes per pixel */
+    unsigned char *hcount = (unsigned char *)calloc(np, 1);
+    unsigned *hpos = (unsigned *)calloc(np, sizeof(unsigned));
     unsigned char *changed = (unsigned char *)malloc(np);
     memset(changed, 1, np);
     const int m = d->params.n_best < d->n_selected ? d->params.n_best : d->n_selected;
@@ -304,6 +309,21 @@ int et_stats_run(const gipuma_hip_desc *d, int x0, int y0, int x1, int y1, int n
                         }
                         for (int k = 0; k < 8; k++) {
                             if (!need[k]) continue;
+                            {
+                                const float *hp = hist + center * 128;
+                                const unsigned n = hpos[center];
+                                for (unsigned a = 0; a < 32 && a < n; a++) {
+                                    const unsigned idx = (n - 1 - a) & 31;
+                                    if (!memcmp(hp + 4 * idx, cands[k], 16)) {
+                                        if (a < 4) loc.seen4 += 1;
+                                        if (a < 8) loc.seen8 += 1;
+                                        loc.seen32 += 1;
+                                        break;
+                                    }
+                                }
+                                memcpy(hist + center * 128 + 4 * (hpos[center] & 31), cands[k], 16);
+                                hpos[center]++;
+                            }
                             task_eval te;
                             eval_task(d, x, y, cands[k], &te);
                             loc.prop_tasks += 1;
@@ -423,6 +443,22 @@ int et_stats_run(const gipuma_hip_desc *d, int x0, int y0, int x1, int y1, int n
                                         if (stopbuf[0][step][w * 64 + l][k] > mx0) mx0 = stopbuf[0][step][w * 64 + l][k];
                                     }
                                 loc.cols_wave_ref[p][step] += 64.0 * mx + (anyamb ? 64.0 * mx0 : 0.0);
+                            }
+                        }
+                for (int p = 0; p < 4; p++)
+                    for (int step = 0; step < 3; step++)
+                        for (int w = 0; w < 32; w++) {
+                            int anyamb = 0;
+                            for (int l = 0; l < 8; l++)
+                                if (refvalid[w * 8 + l] && ambbuf[p][step][w * 8 + l]) anyamb = 1;
+                            for (int k = 0; k < nv; k++) {
+                                int mx = 0, mx0 = 0;
+                                for (int l = 0; l < 8; l++)
+                                    if (refvalid[w * 8 + l]) {
+                                        if (stopbuf[p][step][w * 8 + l][k] > mx) mx = stopbuf[p][step][w * 8 + l][k];
+                                        if (stopbuf[0][step][w * 8 + l][k] > mx0) mx0 = stopbuf[0][step][w * 8 + l][k];
+                                    }
+                                loc.cols_w8_ref[p][step] += 8.0 * mx + (anyamb ? 8.0 * mx0 : 0.0);
                             }
                         }
                 /* propagation: groups of 64 tasks in owner order */

@@ -213,14 +213,17 @@ def test_device_resident_images_with_pitch(hip):
 
 @pytest.mark.parametrize("tune", [1 << 30, 1 << 29, 1 << 28, (1 << 30) | (1 << 28), 1 << 27, 1 << 26,
                                   (1 << 26) | (1 << 29), 1 << 23, 1 << 25, (1 << 25) | (1 << 27), 1 << 20,
-                                  (1 << 20) | (1 << 27), (1 << 20) | (1 << 25) | (1 << 23)])
+                                  (1 << 20) | (1 << 27), (1 << 20) | (1 << 25) | (1 << 23), 1 << 21,
+                                  (1 << 21) | (1 << 20), (1 << 27) | (1 << 25)])
 def test_kernel_variants_are_bit_identical(hip, tune):
     """the performance-only choices of the sweep kernels -- float-encoded window offsets + the
     hand-pipelined loop (off: bit 30), task order owner-major (bit 29) / source-major (bit 28) in
     every iteration instead of switching after iteration 1, the column-per-lane kernel never (bit
     27) / in every half-sweep (bit 26) instead of the first four, the history skip rule off (bit
     23), early termination of view costs off (bit 25), propagation by the shared-sample kernel
-    (bit 20: pm_prop_shared.h, followed by a refinement-only launch) -- must not change a single bit.
+    (bit 20: pm_prop_shared.h, followed by a refinement-only launch), refinement by the row-per-lane
+    kernel (bit 21: pm_refine_rows.h, groups of 8 lanes on column-major packed views) -- must not
+    change a single bit.
     Box 15 (the pipelined and column-per-lane instantiations), 4 iterations so that the default run
     uses both kernels and both task orders."""
     gs, _ = synth.build_problem(synth.tiny_config(cols=160, rows=112, n_src=4, blocksize=15, iterations=4,
@@ -252,14 +255,15 @@ def test_early_termination_is_exact_for_any_bound(hip, theta, cfg):
     gs, _ = synth.build_problem(synth.tiny_config(**cfg))
     o = OracleState(gs).run()
     os.environ["GIPUMA_HIP_ET_THETA"] = theta
-    os.environ["GIPUMA_HIP_TUNE"] = str(1 << 27)
     try:
-        a = runcuda(gs)
+        for tune in (1 << 27, (1 << 27) | (1 << 21)):  # one lane per pixel / row-per-lane refinement kernel
+            os.environ["GIPUMA_HIP_TUNE"] = str(tune)
+            a = runcuda(gs)
+            assert_same(a[0], o[0], "theta %s tune %d norm4" % (theta, tune))
+            assert_same(a[1], o[1], "theta %s tune %d cost" % (theta, tune))
     finally:
         del os.environ["GIPUMA_HIP_ET_THETA"]
-        del os.environ["GIPUMA_HIP_TUNE"]
-    assert_same(a[0], o[0], "theta %s norm4" % theta)
-    assert_same(a[1], o[1], "theta %s cost" % theta)
+        os.environ.pop("GIPUMA_HIP_TUNE", None)
 
 
 @pytest.mark.parametrize("seq", [
