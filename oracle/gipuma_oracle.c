@@ -704,6 +704,24 @@ int gipuma_oracle_sweep(const gipuma_hip_desc *d, float *norm4, float *cost, int
     return 0;
 }
 
+/* one colour kernel restricted to the rows [y0, y1): reads the whole frame's state, writes only
+ * those rows.  A pixel's update depends only on the state BEFORE the launch (its own and the other
+ * colour's), so running this on the state a device had before a launch and comparing the band with
+ * the device's state after it is an exact check of that launch at any frame size. */
+int gipuma_oracle_sweep_band(const gipuma_hip_desc *d, float *norm4, float *cost, int iteration,
+                             int colour, unsigned stages, int y0, int y1)
+{
+    int rc = go_check(d);
+    if (rc) return rc;
+    if (y0 < 0 || y1 > d->rows || y0 > y1) return GIPUMA_HIP_ERR_ARG;
+    const uint32_t phase = go_phase(iteration, colour);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int y = y0; y < y1; y++)
+        for (int x = (y + colour) & 1; x < d->cols; x += 2)
+            go_sweep_pixel(d, x, y, norm4, cost, phase, stages);
+    return 0;
+}
+
 /* gipuma_compute_disp, gipuma.cu:1080-1103 */
 int gipuma_oracle_finalize(const gipuma_hip_desc *d, float *norm4, const float *cost)
 {

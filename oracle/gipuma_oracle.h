@@ -32,6 +32,9 @@ int gipuma_oracle_run(const gipuma_hip_desc *d, float *norm4, float *cost, int u
 int gipuma_oracle_init_planes(const gipuma_hip_desc *d, float *norm4, float *cost);
 int gipuma_oracle_sweep(const gipuma_hip_desc *d, float *norm4, float *cost, int iteration,
                         int colour, unsigned stages, int unfused);
+/* the same colour kernel on the rows [y0, y1) only (teacher-forced checks at full frame size) */
+int gipuma_oracle_sweep_band(const gipuma_hip_desc *d, float *norm4, float *cost, int iteration,
+                             int colour, unsigned stages, int y0, int y1);
 int gipuma_oracle_finalize(const gipuma_hip_desc *d, float *norm4, const float *cost);
 int gipuma_oracle_eval_cost(const gipuma_hip_desc *d, const float *planes, float *cost_out);
 /* run only `n_iter_timed` iterations after init (cpu_baseline leg of bench.py); returns seconds

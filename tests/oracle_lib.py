@@ -30,6 +30,7 @@ def lib():
         L.gipuma_oracle_run.argtypes = [D, _FP, _FP, C.c_int]
         L.gipuma_oracle_init_planes.argtypes = [D, _FP, _FP]
         L.gipuma_oracle_sweep.argtypes = [D, _FP, _FP, C.c_int, C.c_int, C.c_uint, C.c_int]
+        L.gipuma_oracle_sweep_band.argtypes = [D, _FP, _FP, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int]
         L.gipuma_oracle_finalize.argtypes = [D, _FP, _FP]
         L.gipuma_oracle_eval_cost.argtypes = [D, _FP, _FP]
         L.gipuma_oracle_time.argtypes = [D, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -83,6 +84,10 @@ class OracleState:
     def sweep(self, iteration, colour, stages=abi.STAGE_ALL, unfused=False):
         assert lib().gipuma_oracle_sweep(self._d(), fptr(self.norm4), fptr(self.cost), iteration,
                                          colour, stages, int(unfused)) == 0
+
+    def sweep_band(self, iteration, colour, y0, y1, stages=abi.STAGE_ALL):
+        assert lib().gipuma_oracle_sweep_band(self._d(), fptr(self.norm4), fptr(self.cost), iteration,
+                                              colour, stages, y0, y1) == 0
 
     def finalize(self):
         assert lib().gipuma_oracle_finalize(self._d(), fptr(self.norm4), fptr(self.cost)) == 0

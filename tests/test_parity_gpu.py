@@ -383,6 +383,74 @@ def test_properties_at_full_size(hip):
         assert np.float32(want).view(np.uint32) == c[y, x].view(np.uint32), (x, y, want, c[y, x])
 
 
+def _teacher_forced_bands(gs, bands, what):
+    """Every half-sweep launch of a full run at full frame size, checked exactly: the device state
+    before launch k is handed to the oracle, which sweeps the rows of `bands` (a pixel's update
+    depends only on the state before the launch), and those rows must equal the device state after
+    launch k bit for bit.  Also the initial planes on the bands and the final conversion."""
+    o = OracleState(gs)
+    checked = 0
+    with Session(gs) as s:
+        s.init_planes()
+        n4, c = s.get_state()
+        o.norm4[:] = 0
+        o.cost[:] = 0
+        from tests.oracle_lib import lib, fptr
+        for (y0, y1) in bands:  # init: compare the stored cost with the oracle's cost of the stored plane
+            for y in range(y0, y1, 7):
+                for x in range(3, gs.cols, 97):
+                    pl = np.ascontiguousarray(n4[y, x])
+                    want = lib().gipuma_oracle_multiview_cost(C.byref(gs.desc), x, y, fptr(pl))
+                    assert np.float32(want).view(np.uint32) == c[y, x].view(np.uint32), (what, "init", x, y)
+        for it in range(gs.params.iterations):
+            for colour in (abi.BLACK, abi.RED):
+                o.norm4[...] = n4
+                o.cost[...] = c
+                s.sweep(it, colour)
+                n4, c = s.get_state()
+                for (y0, y1) in bands:
+                    o.sweep_band(it, colour, y0, y1)
+                    assert_same(n4[y0:y1], o.norm4[y0:y1], "%s it %d colour %d rows %d..%d norm4" % (what, it, colour, y0, y1))
+                    assert_same(c[y0:y1], o.cost[y0:y1], "%s it %d colour %d rows %d..%d cost" % (what, it, colour, y0, y1))
+                    checked += (y1 - y0) * gs.cols // 2
+        o.norm4[...] = n4
+        o.cost[...] = c
+        s.finalize()
+        f4, _ = s.get_state()
+    o.finalize()
+    assert_same(f4, o.norm4, what + " final conversion")
+    return checked
+
+
+def test_config_b_full_run(hip):
+    """BASELINE config B (640x480, 6 source views, box 11, 8 iterations, best-3) in full against the
+    oracle's own free-running solve (reference loop gipuma.cu:1911-1941 at the sizes of
+    scripts/templeRing.sh), bit for bit."""
+    gs, info = synth.build_problem("B")
+    n4, c = runcuda(gs)
+    o_n4, o_c = OracleState(gs).run()
+    assert_same(n4, o_n4, "config B norm4")
+    assert_same(c, o_c, "config B cost")
+
+
+def test_config_c_every_launch_at_full_size(hip):
+    """BASELINE config C (the headline: 1600x1200, 10 source views, box 15, 8 iterations, best-3):
+    all 16 half-sweep launches of the shipped schedule (column-per-lane kernel, fused kernel with
+    early termination, history rule) checked exactly on three bands of rows -- top border, interior
+    across a tile-band boundary, bottom border (scripts/dtu_fast.sh:9-21)."""
+    gs, info = synth.build_problem("C")
+    n = _teacher_forced_bands(gs, [(0, 12), (592, 612), (1190, 1200)], "config C")
+    print("config C: %d pixel updates compared exactly" % n)
+
+
+def test_config_d_every_launch_at_full_size(hip):
+    """BASELINE config D (1600x1200, 20 source views, box 25, 8 iterations; scripts/dtu_accurate.sh):
+    every launch checked exactly on two bands (the oracle costs 5x config C per pixel here)."""
+    gs, info = synth.build_problem("D")
+    n = _teacher_forced_bands(gs, [(0, 6), (600, 610)], "config D")
+    print("config D: %d pixel updates compared exactly" % n)
+
+
 # ------------------------------------------------------------------------------------------------
 # -color_processing (T = float4, SURVEY.md 8f row N3)
 # ------------------------------------------------------------------------------------------------
