@@ -11,8 +11,10 @@ that are already resident in HBM when the timed region starts.
 
 Multi-GPU: reference views are independent problems (the reference runs one process per view,
 scripts/dtu_fast.sh:30-55), so rank r solves its own reference view on GPU r; there is no
-data-path collective and RCCL is not used.  torch.distributed (gloo) only carries the barrier and
-the max-over-ranks of the wall time.  scaling = "weak": per-GPU work is fixed.
+data-path collective and RCCL is not used.  torch.distributed (gloo) only carries the barrier, the
+max-over-ranks of the wall time and the device identities.  scaling = "weak": per-GPU work is fixed.
+`--gpus N` launches its own N ranks (one process per GPU) when it is not already running under a
+launcher (no WORLD_SIZE in the environment).
 
 Prints ONE JSON line on rank 0.  `value` is the whole-job aggregate (sum over GPUs); at N=1 it is
 the BASELINE.json per-GPU figure.
@@ -21,6 +23,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,30 +42,151 @@ def algorithmic_bytes_per_sweep_launch(n_pixels, n_views):
     return n_pixels * (152 + 24 * (n_views + 1)) / 2.0
 
 
-def cpu_baseline(gs, iterations, target_seconds=12.0):
-    """the oracle ("port") timed on this host's cores on a bounded band of rows of the SAME
-    workload, scaled to the full frame (work per pixel and per iteration is constant)."""
+# ------------------------------------------------------------------------------------------------
+# CPU baselines (reported, never optimised against): bounded samples of the SAME workload
+# ------------------------------------------------------------------------------------------------
+def _ref_worker(problem_file, bx0, bx1, by0, by1):
+    """one process = one core: the reference's OWN device code (oracle/_ref/libgipuma_ref.so =
+    /root/reference/gipuma.cu lines 1..1824 compiled for the CPU, oracle/ref_shim/build_ref.sh)
+    on a window of 32x32-pixel blocks of the frame: its init kernel + one iteration (6 launches)"""
+    from gipuma_amd.problem import load_problem
+    from tests import ref_lib
+    gs = load_problem(problem_file)
+    L = ref_lib.lib()
+    L.ref_time_window.argtypes = [C.POINTER(type(gs.desc)), C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    ti, ts = C.c_double(), C.c_double()
+    print("READY", flush=True)
+    sys.stdin.readline()  # start together with the other workers
+    rc = L.ref_time_window(C.byref(gs.desc), bx0, bx1, by0, by1, C.byref(ti), C.byref(ts))
+    print(json.dumps({"rc": rc, "sec_init": ti.value, "sec_iter": ts.value,
+                      "pixels": (bx1 - bx0) * (by1 - by0) * 1024}), flush=True)
+
+
+def _ref_baseline(problem_file, rows, cols, iterations, n_proc, blocks_each=1):
+    """the reference's own code on `n_proc` cores at once: one single-threaded process per core
+    (its device code keeps block state in globals), each on its own window of interior blocks of
+    the same frame; throughput = pixels of all windows / slowest process, scaled by iterations
+    (work per pixel and per iteration is constant)."""
+    from tests import ref_lib
+    if not ref_lib.available():
+        return None
+    gx, gy = cols // 32, rows // 32  # interior, fully covered blocks only
+    procs = []
+    for i in range(n_proc):
+        b = (i * 7919) % ((gx - 2) * (gy - 2))
+        bx0, by0 = 1 + b % (gx - 2), 1 + b // (gx - 2)
+        code = ("import sys; sys.path.insert(0, %r); import bench; bench._ref_worker(%r, %d, %d, %d, %d)"
+                % (ROOT, problem_file, bx0, min(bx0 + blocks_each, gx - 1), by0, by0 + 1))
+        procs.append(subprocess.Popen([sys.executable, "-c", code], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                      stderr=subprocess.DEVNULL, text=True,
+                                      env=dict(os.environ, OMP_NUM_THREADS="1")))
+    for p in procs:  # every worker has rendered its frames
+        while True:
+            line = p.stdout.readline()
+            if not line or line.startswith("READY"):
+                break
+    t0 = time.perf_counter()
+    for p in procs:
+        p.stdin.write("go\n")
+        p.stdin.flush()
+    res = []
+    for p in procs:
+        out = p.stdout.read()
+        p.wait()
+        lines = [l for l in out.splitlines() if l.startswith("{")]
+        if lines:
+            res.append(json.loads(lines[-1]))
+    wall = time.perf_counter() - t0
+    if not res or any(r["rc"] for r in res):
+        return None
+    px = sum(r["pixels"] for r in res)
+    t_init = max(r["sec_init"] for r in res)
+    t_iter = max(r["sec_iter"] for r in res)
+    full = (t_init + iterations * t_iter) * rows * cols / px
+    return {"value": rows * cols / full / 1e6, "unit": "Mpix/s", "cores": n_proc, "kind": "reference",
+            "sample": "the reference's own kernels (gipuma.cu compiled for the CPU, oracle/_ref), %d single-threaded "
+                      "processes at once, each on %d interior 32x32 block(s) of the same frame: init %.2fs + 1 "
+                      "iteration (6 launches) %.2fs (slowest), scaled by pixels and x%d iterations; sample wall %.1fs"
+                      % (n_proc, blocks_each, t_init, t_iter, iterations, wall),
+            "est_full_frame_seconds": full}
+
+
+def _port_worker(problem_file, seconds):
+    from gipuma_amd.problem import load_problem
     from tests.oracle_lib import lib
+    gs = load_problem(problem_file)
     L = lib()
     ti, ts = C.c_double(), C.c_double()
     rows = gs.rows
-    band = min(rows, 4)
+    band = 2
     y0 = rows // 2
     L.gipuma_oracle_time_band(C.byref(gs.desc), y0, y0 + band, C.byref(ti), C.byref(ts))
     per_row = (ti.value + ts.value) / band
-    band = int(max(band, min(rows - y0, target_seconds / max(per_row, 1e-9))))
+    band = int(max(band, min(rows - y0, seconds / max(per_row, 1e-9))))
     L.gipuma_oracle_time_band(C.byref(gs.desc), y0, y0 + band, C.byref(ti), C.byref(ts))
-    full = (ti.value + iterations * ts.value) * rows / band
-    return {
-        "value": gs.rows * gs.cols / full / 1e6,
-        "unit": "Mpix/s",
-        "cores": L.gipuma_oracle_num_threads(),
-        "kind": "port",
-        "sample": "oracle (oracle/gipuma_oracle.c, gcc -O2 -fopenmp) on rows [%d,%d) of the same "
-                  "frame: init %.2fs + 1 iteration %.2fs, scaled x%d iterations x rows/%d"
-                  % (y0, y0 + band, ti.value, ts.value, iterations, band),
-        "est_full_frame_seconds": full,
+    it = gs.params.iterations
+    full = (ti.value + it * ts.value) * rows / band
+    print(json.dumps({"value": gs.rows * gs.cols / full / 1e6, "unit": "Mpix/s",
+                      "cores": L.gipuma_oracle_num_threads(), "kind": "port",
+                      "sample": "oracle (oracle/gipuma_oracle.c, gcc -O3 -fopenmp) on rows [%d,%d) of the same frame: "
+                                "init %.2fs + 1 iteration %.2fs, scaled x%d iterations x rows/%d"
+                                % (y0, y0 + band, ti.value, ts.value, it, band),
+                      "est_full_frame_seconds": full}), flush=True)
+
+
+def _port_baseline(problem_file, threads, seconds):
+    code = ("import sys; sys.path.insert(0, %r); import bench; bench._port_worker(%r, %f)"
+            % (ROOT, problem_file, seconds))
+    try:
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, OMP_NUM_THREADS=str(threads)))
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        return json.loads(lines[-1]) if lines else None
+    except Exception as e:  # noqa: BLE001
+        return {"error": str(e)}
+
+
+def cpu_baseline(problem_file, rows, cols, iterations):
+    """`cpu_baseline` object of the bench line: the reference's own code on all cores of this host
+    (kind "reference") when oracle/_ref exists, else the oracle port; the other figures (one core,
+    the port) ride along under "all"."""
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    allv = {
+        "reference_all_cores": _ref_baseline(problem_file, rows, cols, iterations, ncpu),
+        "reference_1_core": _ref_baseline(problem_file, rows, cols, iterations, 1),
+        "port_all_cores": _port_baseline(problem_file, ncpu, 5.0),
+        "port_1_core": _port_baseline(problem_file, 1, 5.0),
     }
+    head = allv["reference_all_cores"] or allv["port_all_cores"] or {"value": None, "kind": "port", "cores": ncpu}
+    out = dict(head)
+    out["all"] = allv
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n):
+    """no launcher around us: start one rank per GPU ourselves (the reference's unit of parallelism
+    is one process per reference view, scripts/dtu_fast.sh:30-55, main.cpp:689-690)"""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
 
 
 def main():
@@ -70,22 +195,32 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C", help="workload: A, B, C (default, the metric's config) or D")
+    ap.add_argument("--scene", default="smooth", choices=["smooth", "steps"],
+                    help="synthetic scene: smooth height field (default) or depth steps + occluder + sensor noise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (exhaustive schedule, "
+                    "second scene, host boundary)")
     ap.add_argument("--colour", action="store_true", help="-color_processing variant of the workload (T=float4)")
     ap.add_argument("--cols", type=int, default=0, help="experiments only: override the frame width")
     ap.add_argument("--rows", type=int, default=0, help="experiments only: override the frame height")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise the rank plumbing only (CPU tests)")
+    ap.add_argument("--oversubscribe", action="store_true", help="allow more ranks than GPUs (tests on a 1-GPU box)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
     from gipuma_amd import abi, synth
-    from gipuma_amd.problem import Session
     from gipuma_amd.shard import views_for_rank
 
     if world > 1:
@@ -101,22 +236,54 @@ def main():
             sys.stdout.flush()
             os.dup2(saved, 1)
             os.close(saved)
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    # one rank per GPU; modulo only matters when a launch oversubscribes the node (e.g. a 2-rank
-    # dry run on a 1-GPU box)
-    dev_index = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    dev = "cuda:%d" % dev_index
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def gather(obj):
+        if world == 1:
+            return [obj]
+        out = [None] * world
+        dist.all_gather_object(out, obj)
+        return out
 
     # this rank's shard: one reference view (config E = 8 different views, one per GPU)
     ref_view = views_for_rank(synth.DTU_REF_VIEWS, rank, world)[0]
+
+    if args.dry_run:
+        ident = gather({"rank": rank, "device": "dry:%d" % local_rank, "ref_view": ref_view})
+        barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "dry run", "value": 0.0, "unit": "Mpix/s", "n_gpus": world, "steps": 0,
+                              "warmup": 0, "dry_run": True, "ranks": ident,
+                              "config": {"workload": "none (plumbing test)"}}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    from gipuma_amd.problem import Session
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    n_dev = torch.cuda.device_count()
+    if world > n_dev and not args.oversubscribe:
+        sys.exit("bench.py: %d ranks but only %d GPUs visible (use --oversubscribe for a plumbing test)" % (world, n_dev))
+    dev_index = local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    dev = "cuda:%d" % dev_index
+    props = torch.cuda.get_device_properties(dev_index)
+    ident = gather({"rank": rank, "device_index": dev_index, "name": props.name,
+                    "uuid": str(getattr(props, "uuid", "")), "ref_view": ref_view})
+    if not args.oversubscribe:
+        keys = {(i["device_index"], i["uuid"]) for i in ident}
+        assert len(keys) == world, "ranks do not sit on %d distinct GPUs: %s" % (world, ident)
+
     over = {}
     if args.cols:
         over["cols"] = args.cols
     if args.rows:
         over["rows"] = args.rows
     gs, info = synth.build_problem(args.config, ref_view=ref_view, device=dev, keep_on_device=True,
-                                   colour=args.colour, **over)
+                                   colour=args.colour, scene=args.scene, **over)
     gs.desc.device_id = dev_index
     torch.cuda.synchronize()
     n_pix = gs.rows * gs.cols
@@ -124,11 +291,6 @@ def main():
     iterations = gs.params.iterations
 
     sess = Session(gs)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
     sweep_ms, total_ms, init_ms = [], [], []
     for _ in range(args.warmup):
         sess.solve(timing=True)
@@ -142,37 +304,48 @@ def main():
         init_ms.append(t.ms_init)
     torch.cuda.synchronize()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
+    elapsed = elapsed_local
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0])
+    per_rank = gather({"rank": rank, "ref_view": ref_view, "value": args.steps * n_pix / elapsed_local / 1e6})
+
+    def quality_of(session, inf):
+        n4_, cost_ = session.get_state()
+        gt_ = inf["gt_depth"]
+        valid_ = cost_ != abi.MAXCOST
+        rel_ = np.abs(n4_[..., 3] - gt_) / gt_
+        return {"depth_rel_err_median_vs_gt": float(np.median(rel_[valid_])),
+                "frac_within_1pct_of_gt": float((rel_ < 0.01).mean())}
 
     # quality vs the analytic ground truth (sanity: the solver reconstructs the surface)
-    n4, cost = sess.get_state()
+    quality = quality_of(sess, info)
     sess.close()
-    gt = info["gt_depth"]
-    valid = cost != abi.MAXCOST
-    rel = np.abs(n4[..., 3] - gt) / gt
-    quality = {"depth_rel_err_median_vs_gt": float(np.median(rel[valid])),
-               "frac_within_1pct_of_gt": float((rel < 0.01).mean())}
 
     if rank == 0:
         value = world * args.steps * n_pix / elapsed / 1e6
         ms_launch = float(np.mean(sweep_ms))
         alg = algorithmic_bytes_per_sweep_launch(n_pix, n_views)
         achieved = alg / (ms_launch * 1e-3) / 1e9
-        traffic = None
-        # HBM-side bytes per sweep launch from the PMC passes of the SAME command
-        # (scripts/pmc_passes.sh -> profiles/pmc_latest.json): FETCH_SIZE x2 (gfx950 correction,
-        # MI355X_MICROARCH.md HBM section) + WRITE_SIZE; separate --pmc passes
+        # HBM-side bytes per sweep launch and VALU instruction counts are NOT measured in this run: they
+        # come from the PMC passes of the same command (scripts/pmc_passes.sh -> profiles/pmc_latest.json),
+        # FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, separate --pmc
+        # passes; the object says so
+        pj = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc) and args.config == "C":
+        if os.path.exists(pmc) and args.config == "C" and args.scene == "smooth" and not args.colour:
             try:
                 pj = json.load(open(pmc))
-                traffic = (pj["hbm_read_bytes_per_launch_x2corr"] + pj["hbm_write_bytes_per_launch"]) / 1e9
-            except Exception:
-                traffic = None
+            except Exception:  # noqa: BLE001
+                pj = None
+        traffic = None
+        if pj and "hbm_read_bytes_per_launch_x2corr" in pj:
+            traffic = (pj["hbm_read_bytes_per_launch_x2corr"] + pj["hbm_write_bytes_per_launch"]) / 1e9
+        imported = {"measured_in_this_run": False, "file": "profiles/pmc_latest.json",
+                    "collected_at_kernel_ms": pj.get("_kernel_ms_profiled_mean") if pj else None,
+                    "note": pj.get("_note") if pj else None}
         box = gs.params.box_hsize
         S = ((box - 1) // 2 + 1) ** 2
         r_ref = 0
@@ -181,9 +354,13 @@ def main():
             r_ref += 1
             dz /= 10.0
         samples_per_frame = n_pix * (1 + iterations * (8 + r_ref)) * n_views * S
+        cols_l = int(os.environ.get("GIPUMA_HIP_COLS_LAUNCHES", "4")) if box == 15 and not args.colour else 0
+        n_launch = 2 * iterations
         out = {
-            "metric": "Mpixels/sec/GPU (1600x1200, 10 src views, 8 iters)" if args.config == "C" and not args.colour
-                      else "Mpixels/sec/GPU (config %s%s)" % (args.config, ", colour" if args.colour else ""),
+            "metric": "Mpixels/sec/GPU (1600x1200, 10 src views, 8 iters)"
+                      if args.config == "C" and not args.colour and args.scene == "smooth"
+                      else "Mpixels/sec/GPU (config %s%s%s)" % (args.config, ", colour" if args.colour else "",
+                                                                 ", scene " + args.scene if args.scene != "smooth" else ""),
             "value": value,
             "unit": "Mpix/s",
             "value_per_gpu": value / world,
@@ -197,57 +374,83 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "config %s: %dx%d, %d source views, box %d, %d iterations, best-%d; "
-                                   "analytic textured surface rendered through DTU calibration "
+                                   "analytic textured surface (%s) rendered through DTU calibration "
                                    "(ref view %d); one reference view per GPU"
                                    % (args.config, gs.cols, gs.rows, n_views, box, iterations,
-                                      gs.params.n_best, ref_view),
+                                      gs.params.n_best, args.scene, ref_view),
                        "parallelism": "independent reference views, %d per step" % world,
                        "device_ms_total": float(np.mean(total_ms)),
                        "device_ms_init": float(np.mean(init_ms))},
+            "ranks": [dict(i, value=p["value"]) for i, p in zip(ident, per_rank)],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": "GB per launch (L2<->fabric incl. Infinity Cache hits)",
-                         "kernel": "one half-sweep launch (one colour: close+far+refine fused); mean over the 16 of a "
-                                   "view: pm::sweep_cols_kernel x3 + pm::sweep_kernel x13 on config C",
+                         "traffic_source": imported,
+                         "kernel": "one half-sweep launch (one colour: close+far+refine fused); mean over the %d of a "
+                                   "view: pm::sweep_cols_kernel x%d + pm::sweep_kernel x%d"
+                                   % (n_launch, min(cols_l, n_launch), n_launch - min(cols_l, n_launch)),
                          "kernel_ms": ms_launch,
+                         "kernel_ms_source": "HIP events on the library's stream inside gipuma_hip_solve, this run",
                          "algorithmic_bytes_per_launch": alg,
                          "note": "compute/gather bound by construction (SURVEY F5): "
                                  "%.3g patch samples/s" % (samples_per_frame / (np.mean(total_ms) * 1e-3))},
             "quality": quality,
         }
-        # The roof that actually binds: vector-ALU issue.  PMC
-        # SQ_INSTS_VALU of the same command (profiles/pmc_latest.json) x 64 lanes / launch time,
-        # against 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz for full-rate ops (the mix also holds
-        # half-rate cvt/min/floor, so 100 % is not reachable; DESIGN.md gives the mix bound).
-        if os.path.exists(pmc) and args.config == "C":
-            try:
-                pj = json.load(open(pmc))
-                lane_ops = pj["SQ_INSTS_VALU"] * 64.0
-                peak = 256 * 4 * 32 * 2.4e9
-                out["roofline_valu"] = {
-                    "bound": "valu", "achieved": lane_ops / (ms_launch * 1e-3) / 1e12, "peak": peak / 1e12,
-                    "unit": "T lane-instr/s", "frac": lane_ops / (ms_launch * 1e-3) / peak,
-                    # per NOMINAL patch sample (E*N*S of SURVEY 8, before the exact skipping) ...
-                    "valu_instr_per_nominal_patch_sample": pj["SQ_INSTS_VALU"] * 64.0 / (
-                        samples_per_frame / (1 + iterations * (8 + r_ref)) * (8 + r_ref) / 2.0),
-                    # ... and per patch sample actually evaluated (one window load each)
-                    "valu_instr_per_window_load": pj["SQ_INSTS_VALU"] / max(1.0, pj.get("SQ_INSTS_VMEM_RD", 0.0)),
-                    "source": "profiles/pmc_latest.json (rocprofv3 --pmc SQ_INSTS_VALU, same command)"}
-            except Exception:
-                pass
-        if world == 1 and not args.no_cpu_baseline:
-            # the oracle reads host memory: same frames, copied back from HBM
+        # The roof that actually binds: vector-ALU issue.  SQ_INSTS_VALU comes from
+        # the committed PMC pass (see `source`), only the launch time is this run's.
+        if pj and "SQ_INSTS_VALU" in pj:
+            lane_ops = pj["SQ_INSTS_VALU"] * 64.0
+            peak = 256 * 4 * 32 * 2.4e9
+            out["roofline_valu"] = {
+                "bound": "valu", "achieved": lane_ops / (ms_launch * 1e-3) / 1e12, "peak": peak / 1e12,
+                "unit": "T lane-instr/s", "frac": lane_ops / (ms_launch * 1e-3) / peak,
+                "valu_instr_per_window_load": pj["SQ_INSTS_VALU"] / max(1.0, pj.get("SQ_INSTS_VMEM_RD", 0.0)),
+                "source": dict(imported, counter="rocprofv3 --pmc SQ_INSTS_VALU")}
+        if world == 1 and not args.no_extras:
             from gipuma_amd.problem import GlobalState, runcuda
+            # (a) the same workload with every exact work-reduction switched off (skip rules A/D/H, early
+            #     termination): what a scene that defeats them would cost
+            os.environ["GIPUMA_HIP_TUNE"] = str(64 | (1 << 23) | (1 << 25))
+            try:
+                with Session(gs) as s2:
+                    s2.solve(timing=True)
+                    t2 = s2.solve(timing=True)
+                out["value_exhaustive"] = {"value": n_pix / (t2.ms_total * 1e-3) / 1e6, "unit": "Mpix/s",
+                                           "ms_per_step": float(t2.ms_total),
+                                           "what": "same frames, GIPUMA_HIP_TUNE=64|2^23|2^25: no skip rules, no early "
+                                                   "termination (all 11 hypotheses x 640 samples per pixel and half-sweep)"}
+            finally:
+                del os.environ["GIPUMA_HIP_TUNE"]
+            # (b) a scene with depth discontinuities, an occluder and sensor noise
+            if args.scene == "smooth":
+                gs3, info3 = synth.build_problem(args.config, ref_view=ref_view, device=dev, keep_on_device=True,
+                                                 colour=args.colour, scene="steps", **over)
+                gs3.desc.device_id = dev_index
+                with Session(gs3) as s3:
+                    s3.solve(timing=True)
+                    t3 = s3.solve(timing=True)
+                    q3 = quality_of(s3, info3)
+                out["value_scene_steps"] = {"value": n_pix / (t3.ms_total * 1e-3) / 1e6, "unit": "Mpix/s",
+                                            "ms_per_step": float(t3.ms_total), "quality": q3,
+                                            "what": "same cameras and parameters, scene with +-30 mm depth steps, a raised "
+                                                    "disc (occlusions) and sigma=2 sensor noise"}
+                del gs3, info3
+            # (c) the boundary as the reference's main.cpp uses it: host images in, host planes out
+            #     (upload + window packing + solve + download); reported, never `value`
             gs_host = GlobalState([im.cpu().numpy() for im in gs.images], gs.cameras, gs.selected,
-                                  gs.params, seed=gs.desc.seed)  # (rows, cols[, 4]) arrays
-            # the boundary as the reference's main.cpp uses it: host images in, host planes out
-            # (upload + window packing + solve + download); reported, never `value`
+                                  gs.params, seed=gs.desc.seed)
             t1 = time.perf_counter()
             runcuda(gs_host)
             host_s = time.perf_counter() - t1
             out["host_boundary"] = {"ms_per_view_host_in_host_out": host_s * 1e3,
                                     "value_pcie_inclusive": n_pix / host_s / 1e6, "unit": "Mpix/s"}
-            out["cpu_baseline"] = cpu_baseline(gs_host, iterations)
+        if world == 1 and not args.no_cpu_baseline:
+            import tempfile
+            from gipuma_amd.problem import save_problem
+            with tempfile.TemporaryDirectory() as td:  # the same frames, copied back from HBM
+                pf = os.path.join(td, "problem.npz")
+                save_problem(pf, gs, info["P_matrices"], info["cam_scale"])
+                out["cpu_baseline"] = cpu_baseline(pf, gs.rows, gs.cols, iterations)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

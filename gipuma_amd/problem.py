@@ -116,6 +116,27 @@ class GlobalState:
         return self.rows * self.cols
 
 
+def save_problem(path, gs, P_matrices, cam_scale=1.0):
+    """Snapshot of one reference view's problem (host images, projection matrices, parameters) as an
+    .npz, so that another process can rebuild the identical GlobalState without rendering anything
+    (bench.py's CPU-baseline workers)."""
+    imgs = [np.asarray(im.cpu().numpy() if hasattr(im, "cpu") else im, dtype=np.float32) for im in gs.images]
+    np.savez(path, images=np.stack(imgs), P=np.stack([np.asarray(p, dtype=np.float64) for p in P_matrices]),
+             cam_scale=float(cam_scale), selected=np.asarray(gs.selected, dtype=np.int32),
+             seed=int(gs.desc.seed), params=np.array([repr(sorted(gs.params.__dict__.items()))]))
+
+
+def load_problem(path):
+    from .cameras import get_camera_parameters
+    z = np.load(path, allow_pickle=False)
+    cs = get_camera_parameters([p for p in z["P"]], cam_scale=float(z["cam_scale"]))
+    ap = AlgorithmParameters()
+    for k, v in eval(str(z["params"][0])):  # written by save_problem above
+        setattr(ap, k, v)
+    imgs = [np.ascontiguousarray(im) for im in z["images"]]
+    return GlobalState(imgs, cs, [int(v) for v in z["selected"]], ap, seed=int(z["seed"]))
+
+
 def _fptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 

@@ -69,3 +69,34 @@ def _launcher(code):
         rc = [p.wait() for p in procs]
         sys.exit(max(rc))
     """ % code)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (one process per
+    GPU, the reference's unit: scripts/dtu_fast.sh:30-55); --dry-run exercises exactly that plumbing
+    -- spawn, gloo rendezvous on 127.0.0.1, shard of reference views, gather, ONE JSON line -- on CPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"]
+    assert [r["rank"] for r in d["ranks"]] == [0, 1]
+    assert len({r["ref_view"] for r in d["ranks"]}) == 2      # two different reference views
+    assert len({r["device"] for r in d["ranks"]}) == 2        # bound to two different devices
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
