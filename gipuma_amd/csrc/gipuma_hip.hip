@@ -69,6 +69,9 @@ struct gipuma_hip_session {
     // half-sweeps (-1 otherwise); the rule is valid for colour c iff prev1 == 1-c and prev2 == c
     int prev1 = -1, prev2 = -1;
     unsigned char *changed = nullptr;  // device, one byte per pixel
+    unsigned *et_stat = nullptr;       // device, Problem::et_stat
+    unsigned char *et_hint = nullptr;  // device, 12 bytes per sweep tile (Problem::et_hint)
+    size_t et_hint_bytes = 0;
     int box = 0;             // specialised window size, 0 = runtime
     int ch = 1;              // 1 = gray (T=float), 4 = colour (T=float4)
     unsigned tune = 0;
@@ -424,6 +427,17 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         copy9(hp.view[i].R, c.R);
         copy3(hp.view[i].t, c.t);
     }
+    {
+        const size_t tiles = (size_t)((d->cols + pm::kTileW - 1) / pm::kTileW) *
+                             (size_t)((d->rows + pm::kSweepTileH - 1) / pm::kSweepTileH);
+        s->et_hint_bytes = tiles * 12;
+        CREATE_OK(hipMalloc(&s->et_hint, s->et_hint_bytes));
+        CREATE_OK(hipMemsetAsync(s->et_hint, 0, s->et_hint_bytes, s->stream));
+        hp.et_hint = s->et_hint;
+        CREATE_OK(hipMalloc(&s->et_stat, 18 * sizeof(unsigned)));
+        CREATE_OK(hipMemsetAsync(s->et_stat, 0, 18 * sizeof(unsigned), s->stream));
+        hp.et_stat = s->et_stat;
+    }
     CREATE_OK(hipMalloc(&s->changed, np));
     CREATE_OK(hipMemsetAsync(s->changed, 1, np, s->stream));
     hp.changed = s->changed;
@@ -480,7 +494,13 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
                           p.tau_gradient >= 0.0f && std::isfinite(p.tau_color) && std::isfinite(p.tau_gradient) &&
                           samples * ((1.0 - p.alpha) * p.tau_color + (double)p.alpha * p.tau_gradient) * 1.01 <
                               (double)GIPUMA_HIP_MAXCOST;
-        hp.et_enable = sane && s->u8 && s->ch == 1 && hp.magic_addr && s->box > 0 && s->combine_reg;
+        // ... and only where a half-sweep is many waves of workgroups: on a frame whose tiles all fit the
+        // GPU at once (< 1024 = 256 CUs x 4) the launch lasts as long as its slowest workgroup, and
+        // the occasional redo pass of a bounded evaluation lengthens exactly that (configs A, B: -5..-13 %)
+        const size_t tiles = (size_t)((d->cols + pm::kTileW - 1) / pm::kTileW) *
+                             (size_t)((d->rows + pm::kSweepTileH - 1) / pm::kSweepTileH);
+        const bool big = tiles >= 1024 || getenv("GIPUMA_HIP_ET_FORCE") != nullptr;  // (env: tests on small frames)
+        hp.et_enable = sane && big && s->u8 && s->ch == 1 && hp.magic_addr && s->box > 0 && s->combine_reg;
         hp.et_theta[0] = 1.0f;
         hp.et_theta[1] = 1.0f;
         hp.et_theta[2] = 1.5f;
@@ -536,6 +556,8 @@ int gipuma_hip_destroy(gipuma_hip_session *s)
     if (s->flag) (void)hipFree(s->flag);
     if (s->dp) (void)hipFree(s->dp);
     if (s->changed) (void)hipFree(s->changed);
+    if (s->et_hint) (void)hipFree(s->et_hint);
+    if (s->et_stat) (void)hipFree(s->et_stat);
     if (s->norm4) (void)hipFree(s->norm4);
     if (s->cost) (void)hipFree(s->cost);
     for (auto &e : s->ev)
@@ -550,6 +572,9 @@ int gipuma_hip_init_planes(gipuma_hip_session *s)
 {
     if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
     HIP_OK(hipSetDevice(s->device));
+    // (a fresh solve starts with fresh hints, so that repeated solves of a session do the same work)
+    HIP_OK(hipMemsetAsync(s->et_hint, 0, s->et_hint_bytes, s->stream));
+    HIP_OK(hipMemsetAsync(s->et_stat, 0, 18 * sizeof(unsigned), s->stream));
     const int rc = launch_dense(s, true, s->norm4, s->cost);
     if (!rc) s->costs_trusted = true;
     s->prev1 = s->prev2 = -1;

@@ -49,6 +49,14 @@ struct Problem {  // lives in device memory, read through scalar loads (wave-uni
     // view cost is provably finite and below MAXCOST; theta of refinement step 0, 1, 2+
     int et_enable;
     float et_theta[3];
+    // per (tile, wavefront, refinement step): > 0 while bounding the evaluation recently did not pay
+    // there (a wavefront had to redo lanes); performance only, any content gives the same results
+    unsigned char *et_hint;
+    // [3 rotating slots][3 steps][window columns a full evaluation takes, columns evaluated with the
+    // bound incl. redos]: what the probe workgroups (every 16th) measured; the other workgroups
+    // bound a step only if that paid for the previous half-sweep's probes.  Half-sweep k (= phase)
+    // writes slot k % 3, reads slot (k-1) % 3 and clears slot (k+1) % 3.
+    unsigned *et_stat;
 #ifdef PM_PS_PROFILE
     unsigned long long *prof;  // experiment builds only
 #endif
@@ -593,7 +601,8 @@ struct WinReq {
 template <int BOX, bool FAST, bool ET>
 __device__ __forceinline__ float view_cost_pipe(const Problem *__restrict__ P, const ViewCam &vc,
                                                 const float *__restrict__ H, const float *__restrict__ tp0,
-                                                int tw, const float *__restrict__ lut, int px, int py, float tau)
+                                                int tw, const float *__restrict__ lut, int px, int py, float tau,
+                                                int *cols_done = nullptr)
 {
     static_assert(BOX > 0, "compile-time window only");
     constexpr int R = (BOX - 1) / 2, N = R + 1;  // offsets -R, -R+2, ..., R
@@ -671,8 +680,12 @@ __device__ __forceinline__ float view_cost_pipe(const Problem *__restrict__ P, c
         // early termination (ET): the partial sum only grows (w, dis >= 0, fmaf rounds monotonically),
         // so once every lane of the wavefront has reached its bound the rest of the view cannot
         // matter (see multiview_cost); the two windows already requested are dropped
-        if (ET && __all(cost >= tau)) break;
+        if (ET && __all(cost >= tau)) {
+            if (cols_done) *cols_done -= N - 1 - c;  // (wave-uniform bookkeeping of the probe workgroups)
+            break;
+        }
     }
+    if (ET && cols_done) *cols_done += N + 1;  // (+1: homography and set-up of the view, paid again by a redo)
     return cost;
 }
 
@@ -680,7 +693,7 @@ template <int BOX, bool U8, bool INTERIOR, bool ET = false>
 __device__ __forceinline__ float view_cost(const Problem *__restrict__ P, const ViewCam &vc,
                                            const float *__restrict__ tp0, int tw,
                                            const float *__restrict__ lut, int px, int py, float4 pl,
-                                           const Win<BOX> &win, float tau = 0.0f)
+                                           const Win<BOX> &win, float tau = 0.0f, int *cols_done = nullptr)
 {
     float H[9];
     homography(P->rc.K_inv, vc, pl, H);
@@ -689,8 +702,8 @@ __device__ __forceinline__ float view_cost(const Problem *__restrict__ P, const 
     if constexpr (U8) {
         if (P->magic_addr) {
             if constexpr (BOX > 0) {
-                if (__all(safe)) return view_cost_pipe<BOX, true, ET>(P, vc, H, tp0, tw, lut, px, py, tau);
-                return view_cost_pipe<BOX, false, ET>(P, vc, H, tp0, tw, lut, px, py, tau);
+                if (__all(safe)) return view_cost_pipe<BOX, true, ET>(P, vc, H, tp0, tw, lut, px, py, tau, cols_done);
+                return view_cost_pipe<BOX, false, ET>(P, vc, H, tp0, tw, lut, px, py, tau, cols_done);
             } else {
                 if (__all(safe))
                     return view_cost_loop<BOX, U8, INTERIOR, true, true>(P, vc, H, tp0, tw, lut, px, py, win);
@@ -899,7 +912,7 @@ template <int BOX, bool U8, bool INTERIOR, bool COMBINE_REG, int CH, bool ET = f
 __device__ __forceinline__ float multiview_cost(const Problem *__restrict__ P, const float *__restrict__ tp0,
                                                 int tw, const float *__restrict__ lut, float *cv, int px,
                                                 int py, float4 pl, const Win<BOX> &win, bool et_on = false,
-                                                float thr = 0.0f, float *kth_out = nullptr)
+                                                float thr = 0.0f, float *kth_out = nullptr, int *cols_done = nullptr)
 {
     static_assert(!ET || (COMBINE_REG && CH == 1 && U8 && BOX > 0), "ET: register combiner on packed gray planes");
     const int n = P->n_sel;
@@ -911,7 +924,7 @@ __device__ __forceinline__ float multiview_cost(const Problem *__restrict__ P, c
             c = view_cost_c4<BOX, U8>(P, P->view[v], tp0, tw, lut, px, py, pl, win);
         } else if constexpr (ET) {
             const float tau = et_on ? __builtin_fminf(comb.kth(m), thr) : __builtin_inff();
-            c = view_cost<BOX, U8, INTERIOR, true>(P, P->view[v], tp0, tw, lut, px, py, pl, win, tau);
+            c = view_cost<BOX, U8, INTERIOR, true>(P, P->view[v], tp0, tw, lut, px, py, pl, win, tau, cols_done);
         } else {
             c = view_cost<BOX, U8, INTERIOR>(P, P->view[v], tp0, tw, lut, px, py, pl, win);
         }
@@ -1615,6 +1628,7 @@ __global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kerne
     refine_init(R, P, stages);
     constexpr bool ET = U8 && COMBINE_REG && CH == 1 && BOX > 0 && INTERIOR;
     const bool et_on = ET && P->et_enable && !(tune & Tune::kNoEarlyExit);
+    if (et_on && blockIdx.x == 0 && threadIdx.x < 6) P->et_stat[((phase + 1u) % 3u) * 6u + threadIdx.x] = 0u;
 
     // One loop, one call site of the cost function: rounds [0, prop_rounds) evaluate compacted
     // propagation tasks (possibly of another lane's pixel), then the owner replays its accepts,
@@ -1658,14 +1672,35 @@ __global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kerne
                 // refinement candidates only have to beat L.cst: bound the evaluation by theta * L.cst
                 // and redo the (rare) lanes whose outcome the bound leaves open (see multiview_cost).
                 // Propagation tasks keep only the value-exact rule (their costs are stored).
+                // Where candidates are often accepted (wide disparity ranges, early sweeps) the redo
+                // costs more than the bound saves: a wavefront that had to redo leaves a note and
+                // evaluates that step unbounded in its next few half-sweeps.
                 float thr = __builtin_inff();
-                if (et_on && r >= prop_rounds) thr = P->et_theta[min(r - prop_rounds, 2)] * L.cst;
-                bool need = true;
+                unsigned char *hint = nullptr;
+                int hv = 0, step = -1;
+                const bool probe = (blockIdx.x & 15u) == 0u;
+                // (only the first three refinement steps: later ones -- a wide disparity range has up to
+                //  six -- are perturbations so small that the candidate usually ties with the plane)
+                if (et_on && r >= prop_rounds && r - prop_rounds < 3) {
+                    step = r - prop_rounds;
+                    const unsigned *seen = P->et_stat + ((phase + 2u) % 3u) * 6u + 2 * step;
+                    const bool pays = seen[0] > 0u && (unsigned long long)seen[1] * 100ull <= (unsigned long long)seen[0] * 85ull;
+                    if (probe) {
+                        thr = P->et_theta[step] * L.cst;
+                    } else if (pays) {
+                        hint = P->et_hint + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 3 + step;
+                        hv = __builtin_amdgcn_readfirstlane((int)*hint);  // low nibble: half-sweeps to sit out; high: level
+                        if ((hv & 15) == 0) thr = P->et_theta[step] * L.cst;
+                    }
+                }
+                bool need = true, redone = false;
+                int cols_done = 0;
                 for (int pass = 0; pass < 2; pass++) {
                     if (need) {
                         float kth;
                         const float cc = multiview_cost<BOX, U8, INTERIOR, COMBINE_REG, CH, true>(
-                            P, etp0, L.tw, lds, L.cv, epx, epy, cand, win, et_on, thr, &kth);
+                            P, etp0, L.tw, lds, L.cv, epx, epy, cand, win, et_on, thr, &kth,
+                            probe && step >= 0 ? &cols_done : nullptr);
                         const bool open = kth >= thr && cc < L.cst;
                         if (open) {
                             thr = __builtin_inff();
@@ -1675,6 +1710,27 @@ __global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kerne
                         }
                     }
                     if (!__any(need)) break;
+                    redone = true;
+                }
+                if (probe && step >= 0 && (threadIdx.x & 63u) == 0u) {
+                    unsigned *mine = P->et_stat + (phase % 3u) * 6u + 2 * step;
+                    atomicAdd(&mine[0], (unsigned)(P->n_sel * ((BOX + 1) / 2 + 1)));
+                    atomicAdd(&mine[1], (unsigned)cols_done);
+                }
+                if (hint && (redone || hv > 0)) {
+                    // exponential back-off: a redo raises the level and sits out 2^level - 1 half-sweeps,
+                    // a bounded step that went through lowers it
+                    const int level = hv >> 4;
+                    int nv;
+                    if (redone) {
+                        const int nl = min(level + 1, 4);
+                        nv = (nl << 4) | ((1 << nl) - 1);
+                    } else if (hv & 15) {
+                        nv = hv - 1;
+                    } else {
+                        nv = max(level - 1, 0) << 4;
+                    }
+                    *hint = (unsigned char)nv;
                 }
             } else {
                 c = multiview_cost<BOX, U8, INTERIOR, COMBINE_REG, CH>(P, etp0, L.tw, lds, L.cv, epx, epy, cand, win);

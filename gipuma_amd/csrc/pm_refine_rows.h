@@ -241,7 +241,7 @@ __global__ __launch_bounds__(kThreads, 4) void sweep_rows_kernel(const Problem *
         candbuf[threadIdx.x] = cand;
         cbound[threadIdx.x] = L.active ? L.cst : -1.0f;  // < 0: nothing can be accepted, cut off at once
         __syncthreads();
-        const float theta = P->et_theta[min(step, 2)];
+        const float theta = step < 3 ? P->et_theta[step] : __builtin_inff();  // (as in sweep_kernel)
         for (int r = 0; r < kThreads / kRowTasks; r++) {
             const int owner = r * kRowTasks + grp;
             int olx, oly;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(kThreads, 4) void sweep_rows_kernel(const Problem *
             const float bound = cbound[owner];
             const float *etp0 = L.tile + (((epy - L.y0) + L.hh) * L.tw + ((epx - L.x0) + L.hw)) * 4;
             // bound the evaluation by theta * bound; redo the groups whose outcome that leaves open
-            float thr = et_on ? theta * bound : __builtin_inff();
+            float thr = et_on && step < 3 ? theta * bound : __builtin_inff();
             float c = 0.0f;
             bool need = true;
             for (int pass = 0; pass < 2; pass++) {

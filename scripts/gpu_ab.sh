@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out/ab
 while read -r label envs; do
   [ -z "$label" ] && continue
-  env GIPUMA_HIP_LAUNCH_TIMES=1 $envs python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" \
+  env GIPUMA_HIP_LAUNCH_TIMES=1 $envs python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras "$@" \
       > $R/gpurun_out/ab/$label.json 2> $R/gpurun_out/ab/$label.err
   python - "$label" $R/gpurun_out/ab/$label.json $R/gpurun_out/ab/$label.err <<'PY'
 import json, sys

@@ -6,7 +6,7 @@ NAME=$1; shift
 OUT=$R/gpurun_out/$NAME
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-env "$@" rocprofv3 --kernel-trace --stats -d $OUT -o tr -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench.json 2> $OUT/err.txt
+env "$@" rocprofv3 --kernel-trace --stats -d $OUT -o tr -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/bench.json 2> $OUT/err.txt
 DB=$(ls $OUT/*_results.db 2>/dev/null | head -1)
 python $R/scripts/rocprof_summary.py stats $DB > $OUT/kernel_stats.txt
 python $R/scripts/rocprof_summary.py series $DB "pm::" > $OUT/series_all.txt

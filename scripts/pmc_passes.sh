@@ -11,7 +11,7 @@ i=0
 while read -r group; do
   i=$((i+1))
   timeout 240 rocprofv3 --kernel-trace --kernel-include-regex "pm::" --pmc $group -d $OUT -o pmc$i -- \
-     python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $OUT/pmc$i.bench.json 2> $OUT/pmc$i.err
+     python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras "$@" > $OUT/pmc$i.bench.json 2> $OUT/pmc$i.err
   echo "pass $i ($group): rc=$?"
 done <<LIST
 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM

@@ -228,12 +228,14 @@ def test_kernel_variants_are_bit_identical(hip, tune):
     uses both kernels and both task orders."""
     gs, _ = synth.build_problem(synth.tiny_config(cols=160, rows=112, n_src=4, blocksize=15, iterations=4,
                                                   n_best=3))
-    a = runcuda(gs)
-    os.environ["GIPUMA_HIP_TUNE"] = str(tune)
+    os.environ["GIPUMA_HIP_ET_FORCE"] = "1"  # early termination also on this small frame
     try:
+        a = runcuda(gs)
+        os.environ["GIPUMA_HIP_TUNE"] = str(tune)
         b = runcuda(gs)
     finally:
-        del os.environ["GIPUMA_HIP_TUNE"]
+        os.environ.pop("GIPUMA_HIP_TUNE", None)
+        del os.environ["GIPUMA_HIP_ET_FORCE"]
     assert_same(a[0], b[0], "variant %d norm4" % tune)
     assert_same(a[1], b[1], "variant %d cost" % tune)
     if tune == 1 << 30:
@@ -255,6 +257,7 @@ def test_early_termination_is_exact_for_any_bound(hip, theta, cfg):
     gs, _ = synth.build_problem(synth.tiny_config(**cfg))
     o = OracleState(gs).run()
     os.environ["GIPUMA_HIP_ET_THETA"] = theta
+    os.environ["GIPUMA_HIP_ET_FORCE"] = "1"  # (the library bounds evaluations only on frames of >= 1024 tiles)
     try:
         for tune in (1 << 27, (1 << 27) | (1 << 21)):  # one lane per pixel / row-per-lane refinement kernel
             os.environ["GIPUMA_HIP_TUNE"] = str(tune)
@@ -263,6 +266,7 @@ def test_early_termination_is_exact_for_any_bound(hip, theta, cfg):
             assert_same(a[1], o[1], "theta %s tune %d cost" % (theta, tune))
     finally:
         del os.environ["GIPUMA_HIP_ET_THETA"]
+        del os.environ["GIPUMA_HIP_ET_FORCE"]
         os.environ.pop("GIPUMA_HIP_TUNE", None)
 
 
