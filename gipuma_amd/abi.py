@@ -16,6 +16,7 @@ STAGE_CLOSE, STAGE_FAR, STAGE_REFINE, STAGE_ALL = 1, 2, 4, 7
 BLACK, RED = 0, 1
 FLAG_IMAGES_ON_DEVICE = 1
 FLAG_UNFUSED = 2
+FLAG_CACHE_IMAGES = 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgipuma_hip.so")
@@ -73,6 +74,7 @@ SYMBOLS = [
     ("gipuma_hip_version", C.c_int, []),
     ("gipuma_hip_last_error", C.c_char_p, []),
     ("gipuma_hip_device_count", C.c_int, []),
+    ("gipuma_hip_cache_clear", C.c_int, []),
     ("gipuma_hip_selftest_reciprocal", C.c_int, [C.c_int, C.POINTER(C.c_ulonglong)]),
     ("gipuma_hip_create", C.c_int, [C.POINTER(Desc), C.POINTER(C.c_void_p)]),
     ("gipuma_hip_destroy", C.c_int, [C.c_void_p]),

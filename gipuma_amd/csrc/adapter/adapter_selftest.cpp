@@ -2,7 +2,8 @@
 // main.cpp does, for the gpu-marked drop-in test (tests/test_adapter_gpu.py):
 //   new GlobalState / AlgorithmParameters in managed memory   (main.cpp:829, 1211)
 //   fill cameras, selected views, parameters                   (main.cpp:888-933)
-//   upload float images as "textures"                          (main.cpp:607-656 call sequence)
+//   upload float images as "textures": gray (addImageToTextureFloatGray, main.cpp:607-656) or,
+//   with -color_processing, float4 BGRA texels (addImageToTextureFloatColor, main.cpp:560-605)
 //   runcuda(*gs)                                               (main.cpp:973)
 //   read gs->lines->norm4 / c back on the host                 (main.cpp:976-985)
 // Compiled against the reference's headers; only the resulting .so travels.
@@ -21,6 +22,7 @@ extern "C" int gipuma_adapter_selftest(const gipuma_hip_desc *d, float *norm4_ou
     p.alpha = d->params.alpha; p.tau_color = d->params.tau_color; p.tau_gradient = d->params.tau_gradient;
     p.gamma = d->params.gamma; p.good_factor = d->params.good_factor;
     p.min_disparity = d->params.min_disparity; p.max_disparity = d->params.max_disparity;
+    p.color_processing = d->channels == 4;  // runcuda() picks gipuma<float4>, gipuma.cu:1965-1968
     gs->params = algParams;
     CameraParameters_cu &cp = *gs->cameras;
     cp.cols = d->cols; cp.rows = d->rows; cp.f = d->cameras[0].f;
@@ -44,12 +46,14 @@ extern "C" int gipuma_adapter_selftest(const gipuma_hip_desc *d, float *norm4_ou
     gs->lines->resize(d->rows * d->cols);
     gs->lines->s = d->cols;
     gs->lines->l = d->cols;
-    // addImageToTextureFloatGray, main.cpp:607-656
+    // addImageToTextureFloatGray, main.cpp:607-656 / addImageToTextureFloatColor, main.cpp:560-605
     for (int i = 0; i < d->n_images; i++) {
-        cudaChannelFormatDesc channelDesc = cudaCreateChannelDesc(32, 0, 0, 0, cudaChannelFormatKindFloat);
+        cudaChannelFormatDesc channelDesc = d->channels == 4
+                                                ? cudaCreateChannelDesc<float4>()
+                                                : cudaCreateChannelDesc(32, 0, 0, 0, cudaChannelFormatKindFloat);
         checkCudaErrors(cudaMallocArray(&gs->cuArray[i], &channelDesc, d->cols, d->rows));
         checkCudaErrors(cudaMemcpy2DToArray(gs->cuArray[i], 0, 0, d->images[i], (size_t)d->pitch * sizeof(float),
-                                            d->cols * sizeof(float), d->rows, cudaMemcpyHostToDevice));
+                                            d->cols * sizeof(float) * d->channels, d->rows, cudaMemcpyHostToDevice));
         struct cudaResourceDesc resDesc;
         memset(&resDesc, 0, sizeof(resDesc));
         resDesc.resType = cudaResourceTypeArray;

@@ -18,7 +18,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
+#include <tuple>
 #include <string>
 #include <vector>
 
@@ -33,6 +36,16 @@ int fail(int code, const char *fmt, const char *a = "", const char *b = "")
     g_err = buf;
     return code;
 }
+
+// GIPUMA_HIP_FLAG_CACHE_IMAGES: what has been derived from a resident image plane, per
+// (device, address, rows, cols, pitch, channels)
+struct CachedImage {
+    int not_u8 = -1;              // result of the 8-bit check (-1: not run yet)
+    uint32_t *packed = nullptr;   // window-packed copy (pack_kernel / pack_kernel_c4)
+};
+typedef std::tuple<int, const void *, int, int, int, int> CacheKey;
+std::map<CacheKey, CachedImage> g_cache;
+std::mutex g_cache_mutex;
 
 #define HIP_OK(expr)                                                                                  \
     do {                                                                                              \
@@ -65,6 +78,9 @@ struct gipuma_hip_session {
     // state invariant cost[p] == cost(p, plane[p]): true once init_planes has run, not assumed after
     // gipuma_hip_set_state (the caller may install any pair); the sweep kernel's skip rule (A) needs it
     bool costs_trusted = false;
+    // gipuma_hip_finalize rewrites norm4 in place to (world normal, depth): no sweep may follow until the
+    // planes are re-initialised or re-installed
+    bool finalized = false;
     // history rule bookkeeping: colours of the last two launches that were full-stage, fused, trusted
     // half-sweeps (-1 otherwise); the rule is valid for colour c iff prev1 == 1-c and prev2 == c
     int prev1 = -1, prev2 = -1;
@@ -266,6 +282,19 @@ int gipuma_hip_device_count(void)
     return n;
 }
 
+int gipuma_hip_cache_clear(void)
+{
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    for (auto &kv : g_cache) {
+        if (kv.second.packed) {
+            (void)hipSetDevice(std::get<0>(kv.first));
+            (void)hipFree(kv.second.packed);
+        }
+    }
+    g_cache.clear();
+    return 0;
+}
+
 int gipuma_hip_selftest_reciprocal(int device_id, unsigned long long *mismatches)
 {
     if (!mismatches) return fail(GIPUMA_HIP_ERR_ARG, "null argument");
@@ -373,18 +402,40 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     // U8 mode (weight table + window-packed source views) if every image handed to the path is
     // integer valued in [0,255] -- 8-bit input converted to float, main.cpp:941
     {
-        CREATE_OK(hipMalloc(&s->flag, sizeof(int)));
-        CREATE_OK(hipMemsetAsync(s->flag, 0, sizeof(int), s->stream));
+        const bool cached = on_device && (d->flags & GIPUMA_HIP_FLAG_CACHE_IMAGES) != 0;
+        std::unique_lock<std::mutex> lock(g_cache_mutex, std::defer_lock);
+        if (cached) lock.lock();
+        auto entry = [&](const float *img) -> CachedImage * {
+            return cached ? &g_cache[CacheKey(s->device, img, d->rows, d->cols, hp.pitch, d->channels)] : nullptr;
+        };
+        // one flag per checked plane, planes whose verdict is cached are skipped
+        const int n_planes = 1 + d->n_selected;
+        CREATE_OK(hipMalloc(&s->flag, sizeof(int) * n_planes));
+        CREATE_OK(hipMemsetAsync(s->flag, 0, sizeof(int) * n_planes, s->stream));
         const dim3 cg((d->cols + pm::kThreads - 1) / pm::kThreads, d->rows);
         auto check = s->ch == 4 ? pm::check_u8_kernel_c4 : pm::check_u8_kernel;
-        hipLaunchKernelGGL(check, cg, dim3(pm::kThreads), 0, s->stream, hp.ref, hp.rows, hp.cols, hp.pitch, s->flag);
-        for (int i = 0; i < d->n_selected; i++)
-            hipLaunchKernelGGL(check, cg, dim3(pm::kThreads), 0, s->stream, hp.view[i].img, hp.rows, hp.cols,
-                               hp.pitch, s->flag);
+        std::vector<int> verdict(n_planes, -1);
+        for (int i = 0; i < n_planes; i++) {
+            const float *img = i == 0 ? hp.ref : hp.view[i - 1].img;
+            CachedImage *e = entry(img);
+            if (e && e->not_u8 >= 0)
+                verdict[i] = e->not_u8;
+            else
+                hipLaunchKernelGGL(check, cg, dim3(pm::kThreads), 0, s->stream, img, hp.rows, hp.cols, hp.pitch,
+                                   s->flag + i);
+        }
         CREATE_OK(hipGetLastError());
-        int not_u8 = 1;
-        CREATE_OK(hipMemcpyAsync(&not_u8, s->flag, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        std::vector<int> flags(n_planes, 1);
+        CREATE_OK(hipMemcpyAsync(flags.data(), s->flag, sizeof(int) * n_planes, hipMemcpyDeviceToHost, s->stream));
         CREATE_OK(hipStreamSynchronize(s->stream));
+        int not_u8 = 0;
+        for (int i = 0; i < n_planes; i++) {
+            if (verdict[i] < 0) {
+                verdict[i] = flags[i] != 0;
+                if (CachedImage *e = entry(i == 0 ? hp.ref : hp.view[i - 1].img)) e->not_u8 = verdict[i];
+            }
+            not_u8 |= verdict[i];
+        }
         s->u8 = !not_u8 && !(s->tune & Tune::kNoLut);
         hp.pw = d->cols + 8;
         // float-encoded window offsets need every entry index of a gray packed plane below 2^21
@@ -395,14 +446,23 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
             auto pack = s->ch == 4 ? pm::pack_kernel_c4 : pm::pack_kernel;
             const dim3 pgid((hp.pw + pm::kThreads - 1) / pm::kThreads, d->rows + 3);
             for (int i = 0; i < d->n_selected; i++) {
+                CachedImage *e = entry(hp.view[i].img);
+                if (e && e->packed) {  // packed for an earlier session: shared, owned by the cache
+                    hp.view[i].packed = e->packed;
+                    continue;
+                }
                 uint32_t *pk = nullptr;
                 CREATE_OK(hipMalloc(&pk, words * sizeof(uint32_t)));
-                s->packed.push_back(pk);
+                if (e)
+                    e->packed = pk;
+                else
+                    s->packed.push_back(pk);
                 hp.view[i].packed = pk;
                 hipLaunchKernelGGL(pack, pgid, dim3(pm::kThreads), 0, s->stream, hp.view[i].img,
                                    hp.rows, hp.cols, hp.pitch, hp.pw, pk);
             }
             CREATE_OK(hipGetLastError());
+            if (cached) CREATE_OK(hipStreamSynchronize(s->stream));  // other sessions' streams may read them next
         }
     }
 
@@ -577,6 +637,7 @@ int gipuma_hip_init_planes(gipuma_hip_session *s)
     HIP_OK(hipMemsetAsync(s->et_stat, 0, 18 * sizeof(unsigned), s->stream));
     const int rc = launch_dense(s, true, s->norm4, s->cost);
     if (!rc) s->costs_trusted = true;
+    s->finalized = false;
     s->prev1 = s->prev2 = -1;
     return rc;
 }
@@ -586,6 +647,9 @@ int gipuma_hip_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned 
     if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
     if (iteration < 0 || (colour != GIPUMA_BLACK && colour != GIPUMA_RED) || (stages & ~7u))
         return fail(GIPUMA_HIP_ERR_ARG, "bad iteration/colour/stages");
+    if (s->finalized)
+        return fail(GIPUMA_HIP_ERR_ARG, "the session holds finalized maps (world normal, depth), not planes: call "
+                                        "gipuma_hip_init_planes or gipuma_hip_set_state before sweeping again");
     HIP_OK(hipSetDevice(s->device));
     if (s->unfused) {  // the reference's three launches per colour, gipuma.cu:1915-1923
         for (unsigned st = 1; st <= 4; st <<= 1)
@@ -603,9 +667,13 @@ int gipuma_hip_finalize(gipuma_hip_session *s)
     if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
     HIP_OK(hipSetDevice(s->device));
     const int n = s->rows * s->cols;
+    if (s->finalized) return fail(GIPUMA_HIP_ERR_ARG, "already finalized");
     hipLaunchKernelGGL(pm::finalize_kernel, dim3((n + pm::kThreads - 1) / pm::kThreads), dim3(pm::kThreads), 0,
                        s->stream, s->dp, s->norm4, s->cost);
     HIP_OK(hipGetLastError());
+    s->finalized = true;
+    s->costs_trusted = false;
+    s->prev1 = s->prev2 = -1;
     return 0;
 }
 
@@ -659,6 +727,7 @@ int gipuma_hip_set_state(gipuma_hip_session *s, const float *norm4_host, const f
     HIP_OK(hipStreamSynchronize(s->stream));
     s->costs_trusted = false;
     s->prev1 = s->prev2 = -1;
+    if (norm4_host) s->finalized = false;
     return 0;
 }
 

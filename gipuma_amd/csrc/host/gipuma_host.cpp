@@ -1,8 +1,10 @@
 // gipuma_host.cpp -- see gipuma_host.h
 #include "gipuma_host.h"
 
+#include <dirent.h>
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -18,8 +20,26 @@ namespace gipuma_host {
 // ------------------------------------------------------------------------------------------ CLI
 static bool starts(const char *a, const char *opt) { return strncmp(a, opt, strlen(opt)) == 0; }
 
-int parse_command_line(int argc, char **argv, InputFiles &in, OutputFiles &out, AlgorithmParameters &ap)
+int parse_command_line(int argc, char **argv, InputFiles &in, OutputFiles &out, AlgorithmParameters &ap,
+                       GTcheckParameters *gt)
 {
+    GTcheckParameters gt_local;
+    GTcheckParameters &g = gt ? *gt : gt_local;
+    int camera_idx = 0;
+    // options that take their value from the next argument (main.cpp:364-417): a trailing one is an error
+    auto next = [&](int &i) -> const char * {
+        if (i + 1 >= argc) {
+            printf("Command-line parameter error: option %s needs a value\n", argv[i]);
+            return nullptr;
+        }
+        return argv[++i];
+    };
+#define NEXT_INTO(dst)                 \
+    {                                  \
+        const char *v_ = next(i);      \
+        if (!v_) return -1;            \
+        dst = v_;                      \
+    }
     // main.cpp:164-428: positional = image names (first = reference); --x=value; -flag value
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
@@ -71,25 +91,49 @@ int parse_command_line(int argc, char **argv, InputFiles &in, OutputFiles &out, 
 #undef IOPT
         else if (starts(a, "--max_views=")) sscanf(val("--max_views="), "%u", &ap.max_views);
         else if (starts(a, "--seed=")) sscanf(val("--seed="), "%u", &ap.seed);  // extension
-        else if (starts(a, "--gtDepth_divisionFactor=") || starts(a, "--gtDepth_tolerance") ||
-                 starts(a, "--camera_idx=")) { /* ground-truth evaluation: not on the path */ }
-        else if (starts(a, "--pmvs_folder")) in.pmvs_folder = argv[++i];
+        else if (starts(a, "--gtDepth_divisionFactor=")) sscanf(val("--gtDepth_divisionFactor="), "%f", &g.divFactor);
+        else if (starts(a, "--gtDepth_tolerance2=")) sscanf(val("--gtDepth_tolerance2="), "%f", &g.dispTolGT2);
+        else if (starts(a, "--gtDepth_tolerance=")) sscanf(val("--gtDepth_tolerance="), "%f", &g.dispTolGT);
+        else if (starts(a, "--camera_idx=")) sscanf(val("--camera_idx="), "%d", &camera_idx);  // pmvs mode only
+        else if (starts(a, "--pmvs_folder")) NEXT_INTO(in.pmvs_folder)
         else if (!strcmp(a, "-view_selection")) ap.viewSelection = true;
         else if (!strcmp(a, "-color_processing")) ap.color_processing = true;
-        else if (!strcmp(a, "-o")) out.disparity_filename = argv[++i];
-        else if (!strcmp(a, "-output_folder")) out.parentFolder = argv[++i];
-        else if (!strcmp(a, "-calib_file")) in.calib_filename = argv[++i];
-        else if (!strcmp(a, "-gt")) in.gt_filename = argv[++i];
-        else if (!strcmp(a, "-gt_nocc")) in.gt_nocc_filename = argv[++i];
-        else if (!strcmp(a, "-occl_mask")) in.occ_filename = argv[++i];
-        else if (!strcmp(a, "-gt_normal")) in.gt_normal_filename = argv[++i];
-        else if (!strcmp(a, "-images_folder")) in.images_folder = argv[++i];
-        else if (!strcmp(a, "-p_folder")) in.p_folder = argv[++i];
-        else if (!strcmp(a, "-krt_file")) in.krt_file = argv[++i];
-        else if (!strcmp(a, "-camera_folder")) in.camera_folder = argv[++i];
-        else if (!strcmp(a, "--initial_seed")) in.seed_file = argv[++i];
-        else if (!strcmp(a, "-bounding_folder")) in.bounding_folder = argv[++i];
+        else if (!strcmp(a, "-o")) NEXT_INTO(out.disparity_filename)
+        else if (!strcmp(a, "-output_folder")) NEXT_INTO(out.parentFolder)
+        else if (!strcmp(a, "-calib_file")) NEXT_INTO(in.calib_filename)
+        else if (!strcmp(a, "-gt")) NEXT_INTO(in.gt_filename)
+        else if (!strcmp(a, "-gt_nocc")) NEXT_INTO(in.gt_nocc_filename)
+        else if (!strcmp(a, "-occl_mask")) NEXT_INTO(in.occ_filename)
+        else if (!strcmp(a, "-gt_normal")) NEXT_INTO(in.gt_normal_filename)
+        else if (!strcmp(a, "-images_folder")) NEXT_INTO(in.images_folder)
+        else if (!strcmp(a, "-p_folder")) NEXT_INTO(in.p_folder)
+        else if (!strcmp(a, "-krt_file")) NEXT_INTO(in.krt_file)
+        else if (!strcmp(a, "-camera_folder")) NEXT_INTO(in.camera_folder)
+        else if (!strcmp(a, "--initial_seed")) NEXT_INTO(in.seed_file)
+        else if (!strcmp(a, "-bounding_folder")) NEXT_INTO(in.bounding_folder)
         else printf("Command-line parameter warning: unknown option %s\n", a);  // e.g. -no_display
+    }
+#undef NEXT_INTO
+    // --pmvs_folder: images under <pmvs>/visualize/, projection matrices under <pmvs>/txt/ (main.cpp:409-417)
+    // The reference then takes its depth range from <pmvs>/bundle.rd.out (main.cpp:873-875); here it comes
+    // from --depth_min/--depth_max or from the view geometry like in the other modes.
+    if (!in.pmvs_folder.empty()) {
+        std::cout << "Using pmvs information inside directory " << in.pmvs_folder << std::endl;
+        in.images_folder = in.pmvs_folder + "/visualize/";
+        in.p_folder = in.pmvs_folder + "/txt/";
+        in.img_filenames.clear();
+        if (DIR *dir = opendir(in.images_folder.c_str())) {
+            while (dirent *ent = readdir(dir))
+                if (strcmp(ent->d_name, ".") && strcmp(ent->d_name, "..")) in.img_filenames.push_back(ent->d_name);
+            closedir(dir);
+        }
+        std::sort(in.img_filenames.begin(), in.img_filenames.end());  // (readdir order in the reference)
+        if (camera_idx < 0 || camera_idx >= (int)in.img_filenames.size()) {
+            printf("Command-line parameter error: --camera_idx out of range\n");
+            return -1;
+        }
+        std::cout << "Using image " << in.img_filenames[camera_idx] << " as reference camera" << std::endl;
+        std::swap(in.img_filenames[0], in.img_filenames[camera_idx]);
     }
     std::cout << "Input files are: ";
     for (const auto &s : in.img_filenames) std::cout << s << " ";
@@ -450,8 +494,141 @@ int write_ply_binary(const std::string &path, const float *depth, const float *n
     return w == buf.size() ? 0 : -1;
 }
 
-int run_gipuma(const InputFiles &in, const OutputFiles &out, AlgorithmParameters &ap, std::string *folder)
+// ------------------------------------------------------------------------------------------ ground truth
+static bool read_pnm_raw(const std::string &path, std::vector<float> &img, int &rows, int &cols, int &chans)
+{  // P5 / P6, 8 or 16 bit (big endian), values unchanged: what imread(path, -1) + convertTo(CV_32F) gives
+    std::ifstream f(path.c_str(), std::ios::binary);
+    if (!f) return false;
+    std::string magic;
+    f >> magic;
+    if (magic != "P5" && magic != "P6") return false;
+    chans = magic == "P6" ? 3 : 1;
+    int vals[3], k = 0;
+    while (k < 3) {
+        f >> std::ws;
+        if (f.peek() == '#') {
+            std::string c;
+            std::getline(f, c);
+            continue;
+        }
+        if (!(f >> vals[k])) return false;
+        k++;
+    }
+    f.get();
+    cols = vals[0]; rows = vals[1];
+    const int bytes = vals[2] > 255 ? 2 : 1;
+    std::vector<unsigned char> raw((size_t)rows * cols * chans * bytes);
+    f.read((char *)raw.data(), (std::streamsize)raw.size());
+    if ((size_t)f.gcount() != raw.size()) return false;
+    img.resize((size_t)rows * cols * chans);
+    for (size_t i = 0; i < img.size(); i++)
+        img[i] = bytes == 2 ? (float)((raw[2 * i] << 8) | raw[2 * i + 1]) : (float)raw[i];
+    return true;
+}
+
+bool read_gt_map(const std::string &path, std::vector<float> &img, int &rows, int &cols)
+{  // main.cpp:760-776
+    const std::string ext = path.substr(path.find_last_of('.') + 1);
+    if (ext == "dmb") {
+        int nb;
+        return read_dmb(path, img, rows, cols, nb) && nb == 1;
+    }
+    if (ext == "pfm") {  // readPfm, fileIoUtils.h:370-460: "Pf", width height, scale, rows bottom-up
+        FILE *fp = fopen(path.c_str(), "rb");
+        if (!fp) return false;
+        char magic[8];
+        double scale;
+        if (fscanf(fp, "%7s %d %d %lf", magic, &cols, &rows, &scale) != 4 || magic[0] != 'P') {
+            fclose(fp);
+            return false;
+        }
+        fgetc(fp);
+        const int ch = magic[1] == 'F' ? 3 : 1;
+        img.assign((size_t)rows * cols, 0.0f);
+        std::vector<float> line((size_t)cols * ch);
+        for (int y = rows - 1; y >= 0; y--) {
+            if (fread(line.data(), sizeof(float), line.size(), fp) != line.size()) {
+                fclose(fp);
+                return false;
+            }
+            for (int x = 0; x < cols; x++) img[(size_t)y * cols + x] = line[(size_t)x * ch];
+        }
+        fclose(fp);
+        return true;
+    }
+    int chans;
+    return read_pnm_raw(path, img, rows, cols, chans) && chans == 1;
+}
+
+bool read_gt_normals(const std::string &path, std::vector<float> &n3, int &rows, int &cols)
+{  // main.cpp:799-817: 16-bit RGB, component - 32767, normalised; all-zero vectors carry no ground truth
+    int chans;
+    std::vector<float> raw;
+    if (!read_pnm_raw(path, raw, rows, cols, chans) || chans != 3) return false;
+    n3.assign(raw.size(), 0.0f);
+    for (size_t k = 0; k < raw.size(); k += 3) {
+        const int a = (int)raw[k] - 32767, b = (int)raw[k + 1] - 32767, c = (int)raw[k + 2] - 32767;
+        if (a == 0 && b == 0 && c == 0) continue;
+        const float len = std::sqrt((float)a * a + (float)b * b + (float)c * c);
+        n3[k] = a / len; n3[k + 1] = b / len; n3[k + 2] = c / len;
+    }
+    return true;
+}
+
+void compute_error(const float *gt, const float *gt_nocc, const float *disp, const unsigned char *valid, int rows,
+                   int cols, const GTcheckParameters &g, GtReport &r)
+{  // computeError, groundTruthUtils.h:22-95 (the error images it also paints are not produced here)
+    float error = 0, error2 = 0, errorNocc = 0, errorValid = 0;
+    int numGt = 0, numNocc = 0, numValid = 0;
+    for (size_t k = 0; k < (size_t)rows * cols; k++) {
+        const float d1 = gt[k] / g.divFactor;
+        if (d1 == 0.0f || d1 == -1.0f) continue;  // no ground truth here
+        numGt++;
+        // `occImg` is a Mat_<uint8_t> built from the float map: saturate_cast<uchar>
+        const float o = gt_nocc[k];
+        const int o8 = o != o ? 0 : (int)std::min(255.0f, std::max(0.0f, std::nearbyint(o)));
+        const bool nocc = o8 != 0;
+        if (nocc) numNocc++;
+        const bool validPixel = valid && valid[k] != 0;
+        if (validPixel) numValid++;
+        const float diff = std::fabs(d1 - disp[k]);
+        if (diff >= g.dispTolGT) {
+            error++;
+            if (nocc) errorNocc++;
+            if (validPixel) errorValid++;
+        }
+        if (diff >= g.dispTolGT2) error2++;
+    }
+    r.num_gt = numGt;
+    r.error = error / (float)numGt;
+    r.error2 = error2 / (float)numGt;
+    r.error_nocc = errorNocc / (float)numNocc;
+    r.error_valid_all = (errorValid + (float)(numGt - numValid)) / (float)numGt;
+    r.error_valid = errorValid / (float)numValid;
+    r.valid_ratio = (float)numValid / (float)numGt;
+}
+
+void compute_normal_error(const float *normals3, const float *gt3, int rows, int cols, float tol, float tol2, GtReport &r)
+{  // computeNormalError, groundTruthUtils.h:97-135; getAngle, mathUtils.h:16-24
+    int numGt = 0, e1 = 0, e2 = 0;
+    for (size_t k = 0; k < (size_t)rows * cols; k++) {
+        const float *gn = gt3 + 3 * k, *n = normals3 + 3 * k;
+        if (gn[0] + gn[1] + gn[2] < 0.1f) continue;
+        numGt++;
+        float angle = std::acos(gn[0] * n[0] + gn[1] * n[1] + gn[2] * n[2]);
+        if (angle != angle) angle = 0.0f;
+        if (angle > tol) e1++;
+        if (angle > tol2) e2++;
+    }
+    r.normal_error = (float)e1 / (float)numGt;
+    r.normal_error2 = (float)e2 / (float)numGt;
+    r.has_normals = true;
+}
+
+int run_gipuma(const InputFiles &in, const OutputFiles &out, AlgorithmParameters &ap, std::string *folder,
+               const GTcheckParameters *gt_in)
 {
+    GTcheckParameters gtp = gt_in ? *gt_in : GTcheckParameters();
     if (in.img_filenames.size() < 2) {
         printf("Command-line parameter error: at least 2 images must be specified\n");
         return -1;
@@ -481,15 +658,65 @@ int run_gipuma(const InputFiles &in, const OutputFiles &out, AlgorithmParameters
         }
         rows = r; cols = c;
     }
+    // ground truth (main.cpp:757-817)
+    std::vector<float> gtDisp, gtDispNocc, gtNormals;
+    if (!in.gt_filename.empty()) {
+        gtp.gtCheck = true;
+        printf("Opening GT image %s\n", in.gt_filename.c_str());
+        int r, c;
+        if (!read_gt_map(in.gt_filename, gtDisp, r, c) || r != rows || c != cols) {
+            printf("cannot read ground truth %s (same size as the images, .dmb / .pfm / PGM)\n", in.gt_filename.c_str());
+            return -1;
+        }
+    }
+    if (!in.gt_nocc_filename.empty()) {
+        if (!gtp.gtCheck) {
+            printf("Command-line parameter error: Ground truth image (-gt) must be specified for use of nocc GT\n");
+            return -1;
+        }
+        gtp.noccCheck = true;
+        printf("Opening nocc GT image %s\n", in.gt_nocc_filename.c_str());
+        int r, c;
+        if (!read_gt_map(in.gt_nocc_filename, gtDispNocc, r, c) || r != rows || c != cols) return -1;
+    } else if (!in.occ_filename.empty()) {
+        if (!gtp.gtCheck) {
+            printf("Command-line parameter error: Ground truth image (-gt) must be specified for use of occlusion mask\n");
+            return -1;
+        }
+        printf("Opening Occlusion image %s\n", in.occ_filename.c_str());
+        std::vector<float> occ;
+        int r, c;
+        if (!read_pnm_gray(in.occ_filename, occ, r, c) || r != rows || c != cols) return -1;
+        gtDispNocc = gtDisp;  // getNoccGTimg: the ground truth where the mask is set, 0 elsewhere
+        for (size_t k = 0; k < occ.size(); k++)
+            if (occ[k] == 0.0f) gtDispNocc[k] = 0.0f;
+    } else {
+        gtDispNocc = gtDisp;
+    }
+    if (!in.gt_normal_filename.empty()) {
+        int r, c;
+        if (!read_gt_normals(in.gt_normal_filename, gtNormals, r, c) || r != rows || c != cols) {
+            printf("cannot read ground-truth normals %s (16-bit PPM)\n", in.gt_normal_filename.c_str());
+            return -1;
+        }
+    }
+
     std::vector<double> P(12 * n, 0.0);
     if (!in.krt_file.empty()) {
         if (read_middlebury_par(in.krt_file, in.img_filenames, P) != n) { printf("krt_file incomplete\n"); return -1; }
     } else if (!in.p_folder.empty()) {
-        for (int i = 0; i < n; i++)
-            if (!read_p_file(in.p_folder + in.img_filenames[i] + ".P", &P[12 * i])) {
-                printf("cannot read %s\n", (in.p_folder + in.img_filenames[i] + ".P").c_str());
+        for (int i = 0; i < n; i++) {
+            // <name>.P next to -p_folder, <name without extension>.txt in a pmvs tree (cameraGeometryUtils.h:199-222)
+            std::string pf = in.p_folder + in.img_filenames[i] + ".P";
+            if (!in.pmvs_folder.empty()) {
+                const std::string &nm = in.img_filenames[i];
+                pf = in.p_folder + nm.substr(0, nm.find_last_of('.')) + ".txt";
+            }
+            if (!read_p_file(pf, &P[12 * i])) {
+                printf("cannot read %s\n", pf.c_str());
                 return -1;
             }
+        }
     } else {
         printf("need -p_folder or -krt_file\n");
         return -1;
@@ -557,6 +784,31 @@ int run_gipuma(const InputFiles &in, const OutputFiles &out, AlgorithmParameters
         }
         write_ply_binary(of + "/3d_model0.ply", disp.data(), nrm3.data(), g, stride, rows, cols, world.cams[0]);
     }
+    if (gtp.gtCheck) {  // main.cpp:1086-1163
+        GtReport rep;
+        // the reference hands computeError an all-zero `valid` map (main.cpp:1089): no pixel passes the
+        // occlusion check it stands for, so "valid" errors are 0/0 and "valid all" is 1
+        std::vector<unsigned char> valid((size_t)rows * cols, 0);
+        compute_error(gtDisp.data(), gtDispNocc.data(), disp.data(), valid.data(), rows, cols, gtp, rep);
+        if (!gtNormals.empty()) compute_normal_error(nrm3.data(), gtNormals.data(), rows, cols, 0.2f, 0.3f, rep);
+        std::ofstream rf((of + "/results.txt").c_str(), std::ios::out | std::ios::app);
+        rf << "Valid pixels of GT subset: " << rep.valid_ratio << std::endl << std::endl;
+        rf << "Error1: " << rep.error << std::endl << "Correct1: " << 1 - rep.error << std::endl;
+        rf << "Error2: " << rep.error2 << std::endl << "Correct2: " << 1 - rep.error2 << std::endl;
+        rf << "\n\nError (nocc): " << rep.error_nocc << std::endl;
+        rf << "Error (valid occlusion check): " << rep.error_valid << std::endl;
+        rf << "Error (valid occlusion check, div by #GT points): " << rep.error_valid_all << std::endl;
+        // (the reference's median filter is commented out: its "after median filtering" figures repeat Error1/2)
+        rf << "\nError after median filtering: " << rep.error << ", thresh 2: " << rep.error2 << std::endl;
+        rf << "Correct %: " << 1 - rep.error << " (thresh 2: " << 1 - rep.error2 << ")" << std::endl;
+        rf << "\nNormal error (0.2rad): " << rep.normal_error << std::endl;
+        rf << "\nNormal error2 (0.3rad): " << rep.normal_error2 << std::endl;
+        std::cout << "Error1: " << rep.error << std::endl << "Correct1: " << 1 - rep.error << std::endl;
+        std::cout << "Error2: " << rep.error2 << std::endl << "Correct2: " << 1 - rep.error2 << std::endl;
+        std::cout << "Error (nocc): " << rep.error_nocc << std::endl;
+        std::cout << "Error (valid occlusion check): " << rep.error_valid << std::endl;
+        std::cout << "Error (valid occlusion check, div by #GT points): " << rep.error_valid_all << std::endl;
+    }
     if (folder) *folder = of;
     return 0;
 }
@@ -588,6 +840,27 @@ int gipuma_host_select_views(const double *P_list, int n, float cam_scale, int c
     return (int)s.size();
 }
 
+int gipuma_host_compute_error(const float *gt, const float *gt_nocc, const float *disp, const unsigned char *valid,
+                              int rows, int cols, float div_factor, float tol, float tol2, float *out)
+{
+    gipuma_host::GTcheckParameters g;
+    g.divFactor = div_factor; g.dispTolGT = tol; g.dispTolGT2 = tol2;
+    gipuma_host::GtReport r;
+    gipuma_host::compute_error(gt, gt_nocc ? gt_nocc : gt, disp, valid, rows, cols, g, r);
+    out[0] = r.error; out[1] = r.error2; out[2] = r.error_nocc; out[3] = r.error_valid; out[4] = r.error_valid_all;
+    out[5] = r.valid_ratio; out[6] = (float)r.num_gt;
+    return 0;
+}
+
+int gipuma_host_compute_normal_error(const float *normals3, const float *gt3, int rows, int cols, float tol,
+                                     float tol2, float *out2)
+{
+    gipuma_host::GtReport r;
+    gipuma_host::compute_normal_error(normals3, gt3, rows, cols, tol, tol2, r);
+    out2[0] = r.normal_error; out2[1] = r.normal_error2;
+    return 0;
+}
+
 int gipuma_host_write_ply(const char *path, const float *depth, const float *normals3, const float *gray, int rows,
                           int cols, const gipuma_hip_camera *cam)
 {
@@ -612,9 +885,10 @@ int gipuma_host_main(int argc, char **argv)
     gipuma_host::InputFiles in;
     gipuma_host::OutputFiles out;
     gipuma_host::AlgorithmParameters ap;
-    if (gipuma_host::parse_command_line(argc, argv, in, out, ap) < 0) return 1;
+    gipuma_host::GTcheckParameters gt;
+    if (gipuma_host::parse_command_line(argc, argv, in, out, ap, &gt) < 0) return 1;
     std::string folder;
-    const int rc = gipuma_host::run_gipuma(in, out, ap, &folder);
+    const int rc = gipuma_host::run_gipuma(in, out, ap, &folder, &gt);
     if (!rc) std::cout << "Results written to " << folder << std::endl;
     return rc ? 1 : 0;
 }

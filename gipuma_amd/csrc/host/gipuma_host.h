@@ -48,12 +48,36 @@ struct InputFiles {  // reference main.h:39-54
     std::string images_folder, p_folder, krt_file, calib_filename, camera_folder, bounding_folder, pmvs_folder,
         seed_file, gt_filename, gt_nocc_filename, occ_filename, gt_normal_filename;
 };
+struct GTcheckParameters {  // reference main.h:27-36
+    bool gtCheck = false, noccCheck = false;
+    float scale = 150.0f;
+    float dispTolGT = 0.5f;
+    float dispTolGT2 = 0.5f;  // (uninitialised in the reference unless --gtDepth_tolerance2= is given)
+    float divFactor = 4.0f;   // ground-truth value / divFactor = disparity (Middlebury small: 4, KITTI: 255)
+};
+struct GtReport {  // what computeError / computeNormalError report (groundTruthUtils.h:22-135)
+    int num_gt = 0;
+    float error = 0, error2 = 0, error_nocc = 0, error_valid = 0, error_valid_all = 0, valid_ratio = 0;
+    float normal_error = 0, normal_error2 = 0;
+    bool has_normals = false;
+};
 struct OutputFiles {  // reference main.h:57-61
     std::string parentFolder = "results", disparity_filename;
 };
 
 // returns 0, or -1 like getParametersFromCommandLine
-int parse_command_line(int argc, char **argv, InputFiles &in, OutputFiles &out, AlgorithmParameters &ap);
+int parse_command_line(int argc, char **argv, InputFiles &in, OutputFiles &out, AlgorithmParameters &ap,
+                       GTcheckParameters *gt = nullptr);
+// ground-truth maps: .dmb, .pfm (PF/Pf, bottom-up) or 8/16-bit PGM taken unchanged (imread(-1)), main.cpp:760-776
+bool read_gt_map(const std::string &path, std::vector<float> &img, int &rows, int &cols);
+// 16-bit PPM of (n * 32767 + 32767), RGB: unit normals, zero where all components are 32767 (main.cpp:799-817)
+bool read_gt_normals(const std::string &path, std::vector<float> &n3, int &rows, int &cols);
+// computeError (groundTruthUtils.h:22-95).  gt_nocc: the map handed over as `occImg` (converted to 8 bit like
+// the reference's implicit Mat_<uint8_t> conversion); valid: per-pixel flags or nullptr (the reference passes zeros)
+void compute_error(const float *gt, const float *gt_nocc, const float *disp, const unsigned char *valid, int rows,
+                   int cols, const GTcheckParameters &g, GtReport &r);
+// computeNormalError (groundTruthUtils.h:97-135), tolerances 0.2 / 0.3 rad as at main.cpp:1110
+void compute_normal_error(const float *normals3, const float *gt3, int rows, int cols, float tol, float tol2, GtReport &r);
 
 bool read_p_file(const std::string &path, double P[12]);
 // fills P for the images named in `names`; returns the number found
@@ -82,7 +106,8 @@ int write_ply_binary(const std::string &path, const float *depth, const float *n
                      int gray_stride, int rows, int cols, const gipuma_hip_camera &cam);
 
 // the whole of runGipuma (main.cpp:694-1199) minus visualisation: returns 0 and the folder written
-int run_gipuma(const InputFiles &in, const OutputFiles &out, AlgorithmParameters &ap, std::string *folder);
+int run_gipuma(const InputFiles &in, const OutputFiles &out, AlgorithmParameters &ap, std::string *folder,
+               const GTcheckParameters *gt = nullptr);
 
 }  // namespace gipuma_host
 
@@ -96,4 +121,10 @@ int gipuma_host_write_ply(const char *path, const float *depth, const float *nor
                           int cols, const gipuma_hip_camera *cam);
 int gipuma_host_camera_parameters_world(const double *P_list, int n, float cam_scale, gipuma_hip_camera *out);
 int gipuma_host_main(int argc, char **argv);
+// computeError / computeNormalError on caller data (tests): out = error, error2, error_nocc, error_valid,
+// error_valid_all, valid_ratio, num_gt;  out2 = normal error, normal error2
+int gipuma_host_compute_error(const float *gt, const float *gt_nocc, const float *disp, const unsigned char *valid,
+                              int rows, int cols, float div_factor, float tol, float tol2, float *out);
+int gipuma_host_compute_normal_error(const float *normals3, const float *gt3, int rows, int cols, float tol,
+                                     float tol2, float *out2);
 }

@@ -93,6 +93,12 @@ typedef struct gipuma_hip_params {
 
 #define GIPUMA_HIP_FLAG_IMAGES_ON_DEVICE 1u /* images[] are device pointers (already resident) */
 #define GIPUMA_HIP_FLAG_UNFUSED 2u          /* run close/far/refine as 3 launches like the reference */
+/* With IMAGES_ON_DEVICE: the library may keep what it derives from an image plane (the 8-bit check and the
+ * window-packed copy the kernels sample) in a process-wide cache keyed by the plane's device address and
+ * geometry, and reuse it in later sessions -- a scan's images serve as source view of many reference
+ * views (the reference re-uploads every image for every view, main.cpp:960-968).  The caller promises not
+ * to change or free those planes before gipuma_hip_cache_clear(). */
+#define GIPUMA_HIP_FLAG_CACHE_IMAGES 4u
 
 /* Everything runcuda() reads out of GlobalState (globalstate.h:24-45). */
 typedef struct gipuma_hip_desc {
@@ -128,6 +134,8 @@ typedef struct gipuma_hip_session gipuma_hip_session;
 int gipuma_hip_version(void);                 /* GIPUMA_HIP_ABI_VERSION of the built library */
 const char *gipuma_hip_last_error(void);      /* thread-local text of the last failure */
 int gipuma_hip_device_count(void);            /* usable HIP devices (0 if none) */
+/* frees everything kept for GIPUMA_HIP_FLAG_CACHE_IMAGES (sessions using it must be destroyed first) */
+int gipuma_hip_cache_clear(void);
 
 /* Device self-test of an arithmetic shortcut the kernels rely on: v_rcp_f32 + one Newton step must
  * equal the IEEE-correct 1.0f/z bit for bit for EVERY float with biased exponent 1..252.  Runs the

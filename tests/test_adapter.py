@@ -27,13 +27,16 @@ def test_adapter_exports_the_reference_symbol():
 
 @have
 @pytest.mark.gpu
-def test_runcuda_through_the_reference_structs_matches_the_oracle(hip):
+@pytest.mark.parametrize("colour", [False, True])
+def test_runcuda_through_the_reference_structs_matches_the_oracle(hip, colour):
     """fill the reference's real GlobalState like main.cpp does, upload images through the
-    cudaMallocArray / cudaCreateTextureObject call sequence, call runcuda(), read gs.lines back"""
+    cudaMallocArray / cudaCreateTextureObject call sequence -- gray (main.cpp:607-656) or float4
+    colour texels with color_processing set (main.cpp:560-605 -> gipuma<float4>, gipuma.cu:1965-1968)
+    -- call runcuda(), read gs.lines back"""
     from tests.oracle_lib import OracleState
     lib = C.CDLL(SO, mode=C.RTLD_GLOBAL)
     lib.gipuma_adapter_selftest.argtypes = [C.POINTER(abi.Desc), C.POINTER(C.c_float), C.POINTER(C.c_float)]
-    gs, _ = synth.build_problem(synth.tiny_config(cols=96, rows=64, n_src=3, blocksize=11, n_best=2))
+    gs, _ = synth.build_problem(synth.tiny_config(cols=96, rows=64, n_src=3, blocksize=11, n_best=2), colour=colour)
     n4 = np.zeros((gs.rows, gs.cols, 4), dtype=np.float32)
     c = np.zeros((gs.rows, gs.cols), dtype=np.float32)
     rc = lib.gipuma_adapter_selftest(C.byref(gs.desc), n4.ctypes.data_as(C.POINTER(C.c_float)),

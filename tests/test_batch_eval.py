@@ -82,3 +82,9 @@ def test_batch_runner_matches_single_view_runs(hip, tmp_path):
         folder = out / os.path.splitext(ref)[0]
         assert np.array_equal(dmb.read_dmb(str(folder / "disp.dmb")).view(np.uint32), n4[..., 3].view(np.uint32))
         assert np.array_equal(dmb.read_dmb(str(folder / "cost.dmb")).view(np.uint32), c.view(np.uint32))
+        if ref == refs[1]:   # and one of them against the oracle (the others share its code path)
+            from tests.oracle_lib import OracleState
+            o4, oc = OracleState(g1).run()
+            assert np.array_equal(o4.view(np.uint32), n4.view(np.uint32))
+            assert np.array_equal(oc.view(np.uint32), c.view(np.uint32))
+    assert all("wall_ms" in v and v["wall_ms"] >= v["device_ms"] for v in rep["views"])

@@ -227,3 +227,166 @@ def test_cli_end_to_end_dmb_matches_oracle(hip, tmp_path, colour):
     ok = disp > 0
     assert ok.mean() > 0.9
     assert np.abs(q[..., 0] / q[..., 2] - xx)[ok].max() < 0.05 and np.abs(q[..., 1] / q[..., 2] - yy)[ok].max() < 0.05
+
+
+# ------------------------------------------------------------------------------------------------
+# ground-truth evaluation through the CLI (main.cpp:757-817, 1086-1163)
+# ------------------------------------------------------------------------------------------------
+def _gt_lib():
+    L = host_lib()
+    fp, up = C.POINTER(C.c_float), C.POINTER(C.c_ubyte)
+    L.gipuma_host_compute_error.argtypes = [fp, fp, fp, up, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, fp]
+    L.gipuma_host_compute_normal_error.argtypes = [fp, fp, C.c_int, C.c_int, C.c_float, C.c_float, fp]
+    return L
+
+
+def test_cpp_compute_error_matches_the_python_restatement():
+    """computeError / computeNormalError of the C++ front-end (what the CLI reports with -gt) against
+    gipuma_amd.evaluate on random maps, incl. missing ground truth, an occlusion map and valid flags"""
+    from gipuma_amd import evaluate
+    rng = np.random.default_rng(5)
+    rows, cols = 37, 53
+    gt = rng.uniform(20, 200, (rows, cols)).astype(np.float32)
+    gt[rng.random((rows, cols)) < 0.1] = 0.0
+    gt[rng.random((rows, cols)) < 0.05] = -4.0            # -1 after the division by 4
+    disp = (gt / 4 + rng.normal(0, 0.6, (rows, cols))).astype(np.float32)
+    nocc = np.where(rng.random((rows, cols)) < 0.7, gt, 0).astype(np.float32)
+    valid = (rng.random((rows, cols)) < 0.6).astype(np.uint8)
+    out = np.zeros(7, np.float32)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    _gt_lib().gipuma_host_compute_error(fp(gt), fp(nocc), fp(disp), valid.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                                        rows, cols, 4.0, 0.5, 1.0, fp(out))
+    # occImg != 0 after the reference's float -> uint8 conversion of the nocc map
+    occ8 = np.clip(np.rint(nocc), 0, 255) != 0
+    want = evaluate.compute_error(gt, disp, tol=0.5, tol2=1.0, occ_mask=occ8, valid=valid, div_factor=4.0)
+    assert out[6] == want["num_gt"]
+    for i, k in enumerate(["error", "error2", "error_nocc", "error_valid", "error_valid_all", "valid_ratio"]):
+        assert out[i] == pytest.approx(want[k], rel=1e-6), k
+    # normals
+    g = rng.normal(size=(rows, cols, 3)).astype(np.float32)
+    g /= np.linalg.norm(g, axis=-1, keepdims=True)
+    g[rng.random((rows, cols)) < 0.2] = 0
+    n = g + rng.normal(0, 0.15, g.shape).astype(np.float32)
+    n /= np.maximum(np.linalg.norm(n, axis=-1, keepdims=True), 1e-9)
+    n = n.astype(np.float32)
+    out2 = np.zeros(2, np.float32)
+    _gt_lib().gipuma_host_compute_normal_error(fp(n), fp(g), rows, cols, 0.2, 0.3, fp(out2))
+    e, e2, _ = evaluate.compute_normal_error(n, g, tol=0.2, tol2=0.3)
+    assert out2[0] == pytest.approx(e, rel=1e-6) and out2[1] == pytest.approx(e2, rel=1e-6)
+
+
+def test_cli_option_without_value_is_an_error(tmp_path):
+    """an option that takes its value from the next argument, given last (the reference reads argv[argc])"""
+    r = subprocess.run([EXE, "a.pgm", "b.pgm", "-p_folder"], capture_output=True, text=True)
+    assert r.returncode != 0 and "needs a value" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cli_ground_truth_report(hip, tmp_path):
+    """-gt / -gt_nocc / -gt_normal / --gtDepth_*: the CLI's results.txt equals gipuma_amd.evaluate on the
+    maps it wrote (ground truth = the analytic surface; depth map stored x4 in a .dmb, divFactor 4)"""
+    from gipuma_amd import evaluate
+    cfg = synth.tiny_config(cols=96, rows=64, n_src=3, blocksize=11, iterations=3, n_best=2)
+    gs, info = synth.build_problem(cfg)
+    img_dir, p_dir, names = write_scene(tmp_path, gs, info["view_ids"])
+    gt = info["gt_depth"].astype(np.float32)
+    gt[:4] = 0.0                                            # rows without ground truth
+    gt_path = str(tmp_path / "gt.dmb")
+    dmb.write_dmb(gt_path, gt * 4.0)
+    nocc = np.where(np.arange(cfg["cols"])[None, :] % 3 != 0, 255, 0).astype(np.uint8) * np.ones((cfg["rows"], 1), np.uint8)
+    occ_path = str(tmp_path / "occ.pgm")
+    with open(occ_path, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (cfg["cols"], cfg["rows"]) + nocc.tobytes())
+    # ground-truth normals as 16-bit RGB PPM: (n * 32767 + 32767), world frame like normals.dmb
+    # (computeNormalError only counts ground-truth normals whose components sum to >= 0.1)
+    gn = np.zeros((cfg["rows"], cfg["cols"], 3), np.float32)
+    gn[...] = np.array([0.36, 0.48, 0.8], np.float32)
+    gn[:, :10] = 0.0                                        # no normal ground truth on the left
+    enc = np.where(np.abs(gn).sum(-1, keepdims=True) > 0, np.rint(gn * 32767.0) + 32767.0, 32767.0).astype(">u2")
+    nrm_path = str(tmp_path / "gtn.ppm")
+    with open(nrm_path, "wb") as f:
+        f.write(b"P6\n%d %d\n65535\n" % (cfg["cols"], cfg["rows"]) + enc.tobytes())
+    out_dir = tmp_path / "out"
+    args = cli_args(cfg, img_dir, p_dir, names, out_dir) + ["-gt", gt_path, "-occl_mask", occ_path, "-gt_normal", nrm_path,
+                                                             "--gtDepth_divisionFactor=4", "--gtDepth_tolerance=2.5",
+                                                             "--gtDepth_tolerance2=5"]
+    r = subprocess.run(args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    folder = out_dir / os.listdir(out_dir)[0]
+    disp, normals = dmb.read_dmb(str(folder / "disp.dmb")), dmb.read_dmb(str(folder / "normals.dmb"))
+    want = evaluate.compute_error(gt * 4.0, disp, tol=2.5, tol2=5.0, occ_mask=np.where(nocc != 0, gt * 4.0, 0) >= 0.5,
+                                  valid=np.zeros_like(nocc), div_factor=4.0)
+    rep = {}
+    for line in open(folder / "results.txt"):
+        if ":" in line:
+            k, v = line.split(":", 1)
+            try:
+                rep[k.strip()] = float(v.split(",")[0])
+            except ValueError:
+                pass
+    assert rep["Error1"] == pytest.approx(want["error"], rel=1e-5)
+    assert rep["Error2"] == pytest.approx(want["error2"], rel=1e-5)
+    assert rep["Error (nocc)"] == pytest.approx(want["error_nocc"], rel=1e-5)
+    assert rep["Error (valid occlusion check, div by #GT points)"] == pytest.approx(1.0)   # all-zero valid map
+    gnu = np.where(np.abs(gn).sum(-1, keepdims=True) > 0, (np.rint(gn * 32767.0)), 0.0)
+    gnu = gnu / np.maximum(np.linalg.norm(gnu, axis=-1, keepdims=True), 1e-9)
+    e, e2, _ = evaluate.compute_normal_error(normals, gnu.astype(np.float32), tol=0.2, tol2=0.3)
+    assert rep["Normal error (0.2rad)"] == pytest.approx(e, rel=1e-5)
+    assert rep["Normal error2 (0.3rad)"] == pytest.approx(e2, rel=1e-5)
+    assert "Error1: " in r.stdout and 0.0 <= rep["Error1"] < 0.5    # and the surface is actually reconstructed
+
+
+@pytest.mark.gpu
+def test_cli_middlebury_par_file(hip, tmp_path):
+    """Middlebury layout (scripts/dinoSparseRing.sh:8-24): one `_par.txt` with `name K(9) R(9) t(3)` per
+    image (readKRtFileMiddlebury, fileIoUtils.h:111-162) instead of .P files -- config-A-shaped input.
+    The dumps equal the oracle run on the cameras P = K [R|t] of that file."""
+    from tests.oracle_lib import OracleState
+    cfg = dict(synth.CONFIGS["A"], cols=96, rows=72, iterations=2)
+    gs, info = synth.build_problem(cfg)
+    img_dir = tmp_path / "img"
+    img_dir.mkdir()
+    names = []
+    lines = []
+    f_ = 1520.0 * cfg["cols"] / 640.0
+    ring = synth.ring_projection_matrices(16, f_, cfg["cols"] / 2.0 - 0.5, cfg["rows"] / 2.0 - 0.5, radius=0.38,
+                                          height=0.40, target_dist=0.55)
+    for im, vid in zip(gs.images, info["view_ids"]):
+        name = "dinoSR%04d.pgm" % vid
+        with open(img_dir / name, "wb") as f:
+            f.write(b"P5\n%d %d\n255\n" % (gs.cols, gs.rows) + im.astype(np.uint8).tobytes())
+        names.append(name)
+        P = ring[vid]
+        K = np.array([[f_, 0, cfg["cols"] / 2.0 - 0.5], [0, f_, cfg["rows"] / 2.0 - 0.5], [0, 0, 1.0]])
+        Rt = np.linalg.inv(K) @ P
+        lines.append(name + " " + " ".join("%.9f" % v for v in list(K.reshape(-1)) + list(Rt[:, :3].reshape(-1)) +
+                                            list(Rt[:, 3])))
+    par = tmp_path / "dinoSR_par.txt"
+    par.write_text("%d\n" % len(lines) + "\n".join(lines) + "\n")
+    out_dir = tmp_path / "out"
+    args = [EXE] + names + ["-images_folder", str(img_dir) + "/", "-krt_file", str(par), "-output_folder", str(out_dir),
+                            "-no_display", "--algorithm=pm", "--blocksize=11", "--iterations=2", "--cost_gamma=10",
+                            "--cost_comb=best_n", "--n_best=2", "--depth_min=0.3", "--depth_max=0.8",
+                            "--min_angle=5", "--max_angle=45", "--max_views=3"]
+    r = subprocess.run(args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    folder = out_dir / os.listdir(out_dir)[0]
+    disp, cost = dmb.read_dmb(str(folder / "disp.dmb")), dmb.read_dmb(str(folder / "cost.dmb"))
+    # the same cameras through the C++ front-end: P = K [R|t] as the par reader composes them
+    P_txt = []
+    for ln in lines:
+        v = [float(t) for t in ln.split()[1:]]
+        K, R, t = np.array(v[:9]).reshape(3, 3), np.array(v[9:18]).reshape(3, 3), np.array(v[18:21])
+        P_txt.append(K @ np.concatenate([R, t[:, None]], axis=1))
+    cs = cpp_cameras(P_txt)
+    ap = AlgorithmParameters(iterations=2, n_best=2, depthMin=0.3, depthMax=0.8, min_angle=5.0, max_angle=45.0,
+                             max_views=3)
+    ap.set_blocksize(11)
+    assert "Selected views: 1, 2," in r.stdout
+    gs2 = GlobalState(gs.images, cs, [1, 2], ap, seed=1)
+    f32 = np.float32
+    gs2.desc.params.min_disparity = f32(cs.f) * f32(0.54) / f32(0.8)
+    gs2.desc.params.max_disparity = f32(cs.f) * f32(0.54) / f32(0.3)
+    n4, c = OracleState(gs2).run()
+    assert np.array_equal(disp.view(np.uint32), n4[..., 3].view(np.uint32))
+    assert np.array_equal(cost.view(np.uint32), c.view(np.uint32))
