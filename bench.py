@@ -354,7 +354,7 @@ def main():
             r_ref += 1
             dz /= 10.0
         samples_per_frame = n_pix * (1 + iterations * (8 + r_ref)) * n_views * S
-        cols_l = int(os.environ.get("GIPUMA_HIP_COLS_LAUNCHES", "4")) if box == 15 and not args.colour else 0
+        cols_l = int(os.environ.get("GIPUMA_HIP_COLS_LAUNCHES", {15: "4", 25: "3"}.get(box, "0"))) if not args.colour else 0
         n_launch = 2 * iterations
         out = {
             "metric": "Mpixels/sec/GPU (1600x1200, 10 src views, 8 iters)"

@@ -91,7 +91,7 @@ struct gipuma_hip_session {
     int box = 0;             // specialised window size, 0 = runtime
     int ch = 1;              // 1 = gray (T=float), 4 = colour (T=float4)
     unsigned tune = 0;
-    int cols_launches = 4;   // leading half-sweeps (2*iteration + colour) evaluated column-per-lane
+    int cols_launches = -1;  // leading half-sweeps (2*iteration + colour) evaluated column-per-lane (-1: by box)
     size_t lds_sweep = 0, lds_dense = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // experiment aid (GIPUMA_HIP_LAUNCH_TIMES=1): one event per half-sweep launch of gipuma_hip_solve,
@@ -214,11 +214,17 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
     // (pixel, plane) pair, pm::sweep_cols_kernel) when the problem has that instantiation
     // (box 15 only: its 8 window columns fill the 8 lanes of a group; box 11, 6 of 8 lanes, measured
     // slower than one lane per pixel on config B: 18.0 vs 19.8 Mpix/s)
-    const bool cols_ok = s->u8 && s->ch == 1 && s->hp.magic_addr && s->box == 15 &&
+    const bool cols_ok = s->u8 && s->ch == 1 && s->hp.magic_addr && (s->box == 15 || s->box == 25) &&
                          !(tune & (Tune::kNoColsKernel | Tune::kNoInterior));
     size_t lds = s->lds_sweep;
-    if (cols_ok && (2 * iteration + colour < s->cols_launches || (tune & Tune::kColsAlways))) {
-        k = s->combine_reg ? pm::sweep_cols_kernel<15, true> : pm::sweep_cols_kernel<15, false>;
+    // measured: box 15 (groups of 8 lanes) wins the first four half-sweeps of config C, box 25 (13 of 16
+    // lanes) the first three of config D (128.7 / 90.9 / 73.7 -> 88.3 / 78.7 / 72.0 ms, the fourth loses)
+    const int cols_launches = s->cols_launches >= 0 ? s->cols_launches : (s->box == 25 ? 3 : 4);
+    if (cols_ok && (2 * iteration + colour < cols_launches || (tune & Tune::kColsAlways))) {
+        if (s->box == 15)
+            k = s->combine_reg ? pm::sweep_cols_kernel<15, true> : pm::sweep_cols_kernel<15, false>;
+        else
+            k = s->combine_reg ? pm::sweep_cols_kernel<25, true> : pm::sweep_cols_kernel<25, false>;
     } else if (s->rows_kernel && 2 * iteration + colour >= s->rows_from) {
         // refinement by groups of 8 lanes (row per lane, column-major packed views, group-level early exit)
         k = pm::sweep_rows_kernel<15>;
@@ -258,9 +264,13 @@ int launch_dense(gipuma_hip_session *s, bool generate, float4 *planes, float *co
     const int gy = (s->rows + pm::kDenseTileH - 1) / pm::kDenseTileH;
     init_fn k = generate ? pick_init<true>(s) : pick_init<false>(s);
     // random (or arbitrary caller-supplied) planes: column-per-lane evaluation where it exists
-    if (s->u8 && s->ch == 1 && s->hp.magic_addr && s->box == 15 &&
-        !(s->tune & (Tune::kNoColsKernel | Tune::kNoInterior)))
-        k = generate ? pm::init_cols_kernel<15, true> : pm::init_cols_kernel<15, false>;
+    if (s->u8 && s->ch == 1 && s->hp.magic_addr && (s->box == 15 || s->box == 25) &&
+        !(s->tune & (Tune::kNoColsKernel | Tune::kNoInterior))) {
+        if (s->box == 15)
+            k = generate ? pm::init_cols_kernel<15, true> : pm::init_cols_kernel<15, false>;
+        else
+            k = generate ? pm::init_cols_kernel<25, true> : pm::init_cols_kernel<25, false>;
+    }
     hipLaunchKernelGGL(k, dim3(gx * gy), dim3(pm::kThreads), s->lds_dense, s->stream, s->dp, planes,
                        cost_out, s->tune);
     HIP_OK(hipGetLastError());

@@ -955,8 +955,18 @@ __device__ __forceinline__ float multiview_cost(const Problem *__restrict__ P, c
 #ifndef PM_COLS_PD
 #define PM_COLS_PD 8
 #endif
-constexpr int kColGroup = 8;                        // lanes per (pixel, plane) pair
-constexpr int kColTasks = kThreads / kColGroup;     // pairs evaluated concurrently by a workgroup
+// lanes per (pixel, plane) pair: 8 for windows of up to 8 columns (box <= 15), 16 for up to 16
+// (box 25: 13 columns, three lanes of a group shadow the last one); groups never straddle a DPP row
+template <int BOX>
+__host__ __device__ constexpr int col_group()
+{
+    return (BOX + 1) / 2 <= 8 ? 8 : 16;
+}
+template <int BOX>
+__host__ __device__ constexpr int col_tasks()  // pairs evaluated concurrently by a workgroup
+{
+    return kThreads / col_group<BOX>();
+}
 
 template <int BOX, bool FAST>
 __device__ __forceinline__ float view_cost_cols(const Problem *__restrict__ P, const ViewCam &vc,
@@ -964,7 +974,7 @@ __device__ __forceinline__ float view_cost_cols(const Problem *__restrict__ P, c
                                                 int tw, const float *__restrict__ lut, int px, int py, int col)
 {
     constexpr int R = (BOX - 1) / 2, N = R + 1;
-    static_assert(BOX > 0 && N <= kColGroup, "one lane per window column");
+    static_assert(BOX > 0 && N <= col_group<BOX>(), "one lane per window column");
     const float colsf = (float)P->cols, rowsf = (float)P->rows;
     const float alpha = P->alpha, oma = 1.f - P->alpha;
     const float tau_color = P->tau_color, tau_gradient = P->tau_gradient;
@@ -1002,7 +1012,8 @@ __device__ __forceinline__ float view_cost_cols(const Problem *__restrict__ P, c
     float wgt[N], dis[N];
     // PD window requests in flight (these launches wait on L2 misses, and the kernel has registers
     // to spare below its 3-wavefront budget)
-    constexpr int PD = PM_COLS_PD < N ? PM_COLS_PD : N;
+    constexpr int PDmax = N > 8 ? 4 : PM_COLS_PD;  // (13 samples per column: keep the registers for wgt/dis)
+    constexpr int PD = PDmax < N ? PDmax : N;
     WinReq req[PD];
 #pragma unroll
     for (int p = 0; p < PD; p++) req[p] = request(qy0 + (float)(2 * p));
@@ -1035,7 +1046,7 @@ __device__ __forceinline__ float view_cost_cols(const Problem *__restrict__ P, c
     return out;  // exact in lane N-1 of the group
 }
 
-// pmCostMultiview_cu for one (pixel, plane) pair evaluated by a group of kColGroup lanes; the
+// pmCostMultiview_cu for one (pixel, plane) pair evaluated by a group of col_group<BOX>() lanes; the
 // result is exact in every lane of the group
 template <int BOX, bool COMBINE_REG>
 __device__ __forceinline__ float multiview_cost_cols(const Problem *__restrict__ P, const float *__restrict__ tp0,
@@ -1045,14 +1056,15 @@ __device__ __forceinline__ float multiview_cost_cols(const Problem *__restrict__
     constexpr int R = (BOX - 1) / 2, N = R + 1;
     const int n = P->n_sel;
     ViewCombiner<COMBINE_REG> comb;
-    const int grp_lane0 = (int)(threadIdx.x & 63u & ~(unsigned)(kColGroup - 1));
+    constexpr int G = col_group<BOX>();
+    const int grp_lane0 = (int)(threadIdx.x & 63u & ~(unsigned)(G - 1));
     const int src_lane = grp_lane0 + (N - 1);
-    // the homography of a (plane, view) pair is the same for the 8 lanes of a group: lane c computes
+    // the homography of a (plane, view) pair is the same for the lanes of a group: lane c computes
     // it for view vb + c (the literal arithmetic of homography()), the lanes then pass them round
-    for (int vb = 0; vb < n; vb += kColGroup) {
+    for (int vb = 0; vb < n; vb += G) {
         float Hl[9];
         homography(P->rc.K_inv, P->view[min(vb + col, n - 1)], pl, Hl);
-        const int vend = min(vb + kColGroup, n);
+        const int vend = min(vb + G, n);
         for (int v = vb; v < vend; v++) {
             float H[9];
 #pragma unroll
@@ -1225,7 +1237,7 @@ __global__ __launch_bounds__(kThreads) void init_kernel(const Problem *__restric
 
 // init_kernel with the column-per-lane evaluation (view_cost_cols): every lane draws / reads the
 // plane of its own pixel as above, the 256 planes of the tile go through LDS and are evaluated by
-// groups of kColGroup lanes -- random planes are the worst case for one lane per pixel.
+// groups of col_group<BOX>() lanes -- random planes are the worst case for one lane per pixel.
 template <int BOX, bool GENERATE>
 __global__ __launch_bounds__(kThreads) void init_cols_kernel(const Problem *__restrict__ P,
                                                              float4 *__restrict__ norm4, float *__restrict__ cost,
@@ -1261,6 +1273,7 @@ __global__ __launch_bounds__(kThreads) void init_cols_kernel(const Problem *__re
     }
     candbuf[threadIdx.x] = pl;
     __syncthreads();
+    constexpr int kColGroup = col_group<BOX>(), kColTasks = col_tasks<BOX>();
     const int grp = threadIdx.x / kColGroup, col = threadIdx.x % kColGroup;
     for (int r = 0; r < kThreads / kColTasks; r++) {
         const int owner = r * kColTasks + grp;
@@ -1757,9 +1770,9 @@ __global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kerne
 // The same half-sweep with the column-per-lane evaluation (see view_cost_cols): state, candidate
 // selection, task list, accept replay and refinement candidates are computed per pixel by its owner
 // lane exactly as in sweep_kernel (the shared helpers above); only the cost evaluations are done by
-// groups of kColGroup lanes, kColTasks (pixel, plane) pairs at a time, exchanging planes and costs
-// through LDS.  Gray packed planes with float-encoded offsets and a compile-time box of at most 15
-// only (the host uses it for box 15, whose 8 columns fill a group).
+// groups of col_group<BOX>() lanes, col_tasks<BOX>() (pixel, plane) pairs at a time, exchanging planes and costs
+// through LDS.  Gray packed planes with float-encoded offsets and a compile-time box only (the host
+// uses it for box 15, whose 8 columns fill a group of 8, and for box 25: 13 of 16 lanes).
 template <int BOX, bool COMBINE_REG>
 __global__ __launch_bounds__(kThreads) void sweep_cols_kernel(const Problem *__restrict__ P,
                                                               float4 *__restrict__ norm4, float *__restrict__ cost,
@@ -1775,6 +1788,7 @@ __global__ __launch_bounds__(kThreads) void sweep_cols_kernel(const Problem *__r
     refine_init(R, P, stages);
 
     // propagation: kColTasks tasks per round, one group of lanes each
+    constexpr int kColGroup = col_group<BOX>(), kColTasks = col_tasks<BOX>();
     const int grp = threadIdx.x / kColGroup, col = threadIdx.x % kColGroup;
     const int prop_rounds_c = (L.n_tasks + kColTasks - 1) / kColTasks;
     for (int r = 0; r < prop_rounds_c; r++) {
