@@ -570,7 +570,8 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         const size_t tiles = (size_t)((d->cols + pm::kTileW - 1) / pm::kTileW) *
                              (size_t)((d->rows + pm::kSweepTileH - 1) / pm::kSweepTileH);
         const bool big = tiles >= 1024 || getenv("GIPUMA_HIP_ET_FORCE") != nullptr;  // (env: tests on small frames)
-        hp.et_enable = sane && big && s->u8 && s->ch == 1 && hp.magic_addr && s->box > 0 && s->combine_reg;
+        // (gray: the pipelined loop on float-encoded offsets; colour: its integer-addressed loop)
+        hp.et_enable = sane && big && s->u8 && s->combine_reg && (s->ch == 4 || (hp.magic_addr && s->box > 0));
         hp.et_theta[0] = 1.0f;
         hp.et_theta[1] = 1.0f;
         hp.et_theta[2] = 1.5f;

@@ -725,11 +725,11 @@ __device__ __forceinline__ float l1_3(float x, float y, float z)
     return (__builtin_fabsf(x) + __builtin_fabsf(y) + __builtin_fabsf(z)) * 0.3333333f;
 }
 
-template <int BOX, bool U8, bool FAST>
+template <int BOX, bool U8, bool FAST, bool ET = false>
 __device__ __forceinline__ float view_cost_c4_loop(const Problem *__restrict__ P, const ViewCam &vc,
                                                    const float *__restrict__ H, const float *__restrict__ tp0,
                                                    int tw, const float *__restrict__ lut, int px, int py,
-                                                   const Win<BOX> &win)
+                                                   const Win<BOX> &win, float tau = 0.0f)
 {
     const gptr_f32 img = (gptr_f32)vc.img;
     const uint32_t *__restrict__ packed = vc.packed;
@@ -804,22 +804,23 @@ __device__ __forceinline__ float view_cost_c4_loop(const Problem *__restrict__ P
             const float dis = __builtin_fmaf(alpha, gradDis, oma * colDis);
             cost = __builtin_fmaf(w, dis, cost);
         }
+        if (ET && __all(cost >= tau)) break;  // early termination, see multiview_cost
     }
     return cost;
 }
 
-template <int BOX, bool U8>
+template <int BOX, bool U8, bool ET = false>
 __device__ __forceinline__ float view_cost_c4(const Problem *__restrict__ P, const ViewCam &vc,
                                               const float *__restrict__ tp0, int tw,
                                               const float *__restrict__ lut, int px, int py, float4 pl,
-                                              const Win<BOX> &win)
+                                              const Win<BOX> &win, float tau = 0.0f)
 {
     float H[9];
     homography(P->rc.K_inv, vc, pl, H);
     const int hr = win.hrad(), vr = win.vrad();
     const bool safe = window_z_safe(H, (float)(px - hr), (float)(px + hr), (float)(py - vr), (float)(py + vr));
-    if (__all(safe)) return view_cost_c4_loop<BOX, U8, true>(P, vc, H, tp0, tw, lut, px, py, win);
-    return view_cost_c4_loop<BOX, U8, false>(P, vc, H, tp0, tw, lut, px, py, win);
+    if (__all(safe)) return view_cost_c4_loop<BOX, U8, true, ET>(P, vc, H, tp0, tw, lut, px, py, win, tau);
+    return view_cost_c4_loop<BOX, U8, false, ET>(P, vc, H, tp0, tw, lut, px, py, win, tau);
 }
 
 // Accumulation of the per-view costs of pmCostMultiview_cu (gipuma.cu:771-805), shared by the
@@ -914,13 +915,16 @@ __device__ __forceinline__ float multiview_cost(const Problem *__restrict__ P, c
                                                 int py, float4 pl, const Win<BOX> &win, bool et_on = false,
                                                 float thr = 0.0f, float *kth_out = nullptr, int *cols_done = nullptr)
 {
-    static_assert(!ET || (COMBINE_REG && CH == 1 && U8 && BOX > 0), "ET: register combiner on packed gray planes");
+    static_assert(!ET || (COMBINE_REG && U8 && (CH == 4 || BOX > 0)), "ET: register combiner on packed 8-bit planes");
     const int n = P->n_sel;
     const int m = min(n, P->n_best);
     ViewCombiner<COMBINE_REG> comb;
     for (int v = 0; v < n; v++) {
         float c;
-        if constexpr (CH == 4) {
+        if constexpr (CH == 4 && ET) {
+            const float tau = et_on ? __builtin_fminf(comb.kth(m), thr) : __builtin_inff();
+            c = view_cost_c4<BOX, U8, true>(P, P->view[v], tp0, tw, lut, px, py, pl, win, tau);
+        } else if constexpr (CH == 4) {
             c = view_cost_c4<BOX, U8>(P, P->view[v], tp0, tw, lut, px, py, pl, win);
         } else if constexpr (ET) {
             const float tau = et_on ? __builtin_fminf(comb.kth(m), thr) : __builtin_inff();
@@ -1639,7 +1643,7 @@ __global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kerne
     const int prop_rounds = (L.n_tasks + kThreads - 1) / kThreads;
     RefineDraws R;
     refine_init(R, P, stages);
-    constexpr bool ET = U8 && COMBINE_REG && CH == 1 && BOX > 0 && INTERIOR;
+    constexpr bool ET = U8 && COMBINE_REG && INTERIOR && (CH == 4 || BOX > 0);
     const bool et_on = ET && P->et_enable && !(tune & Tune::kNoEarlyExit);
     if (et_on && blockIdx.x == 0 && threadIdx.x < 6) P->et_stat[((phase + 1u) % 3u) * 6u + threadIdx.x] = 0u;
 

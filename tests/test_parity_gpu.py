@@ -270,6 +270,23 @@ def test_early_termination_is_exact_for_any_bound(hip, theta, cfg):
         os.environ.pop("GIPUMA_HIP_TUNE", None)
 
 
+@pytest.mark.parametrize("theta", ["0.05,0.05,0.05", "1,1,1.5"])
+def test_early_termination_colour(hip, theta):
+    """the same cut-off in the colour kernels (T = float4): exact for any bound"""
+    gs, _ = synth.build_problem(synth.tiny_config(cols=96, rows=80, n_src=4, blocksize=15, iterations=3, n_best=3),
+                                colour=True)
+    o = OracleState(gs).run()
+    os.environ["GIPUMA_HIP_ET_THETA"] = theta
+    os.environ["GIPUMA_HIP_ET_FORCE"] = "1"
+    try:
+        a = runcuda(gs)
+    finally:
+        del os.environ["GIPUMA_HIP_ET_THETA"]
+        del os.environ["GIPUMA_HIP_ET_FORCE"]
+    assert_same(a[0], o[0], "colour theta %s norm4" % theta)
+    assert_same(a[1], o[1], "colour theta %s cost" % theta)
+
+
 @pytest.mark.parametrize("seq", [
     # (iteration, colour, stages) or "set" = write the state back through set_state
     [(0, 0, 7), (0, 1, 7), (1, 0, 7), (1, 0, 7), (1, 1, 7), (1, 1, 7), (2, 0, 7), (2, 1, 7), (3, 0, 7), (3, 1, 7)],
