@@ -121,7 +121,10 @@ def save_problem(path, gs, P_matrices, cam_scale=1.0):
     .npz, so that another process can rebuild the identical GlobalState without rendering anything
     (bench.py's CPU-baseline workers)."""
     imgs = [np.asarray(im.cpu().numpy() if hasattr(im, "cpu") else im, dtype=np.float32) for im in gs.images]
-    np.savez(path, images=np.stack(imgs), P=np.stack([np.asarray(p, dtype=np.float64) for p in P_matrices]),
+    # the image planes go to their own .npy so that readers can map them (many workers, one copy in
+    # the page cache)
+    np.save(path + ".images.npy", np.stack(imgs))
+    np.savez(path, P=np.stack([np.asarray(p, dtype=np.float64) for p in P_matrices]),
              cam_scale=float(cam_scale), selected=np.asarray(gs.selected, dtype=np.int32),
              seed=int(gs.desc.seed), params=np.array([repr(sorted(gs.params.__dict__.items()))]))
 
@@ -133,8 +136,11 @@ def load_problem(path):
     ap = AlgorithmParameters()
     for k, v in eval(str(z["params"][0])):  # written by save_problem above
         setattr(ap, k, v)
-    imgs = [np.ascontiguousarray(im) for im in z["images"]]
-    return GlobalState(imgs, cs, [int(v) for v in z["selected"]], ap, seed=int(z["seed"]))
+    stack = np.load(path + ".images.npy", mmap_mode="r")
+    gs = GlobalState([stack[i] for i in range(stack.shape[0])], cs, [int(v) for v in z["selected"]], ap,
+                     seed=int(z["seed"]))
+    gs._mapped = stack  # keep the mapping alive
+    return gs
 
 
 def _fptr(a):
