@@ -262,6 +262,7 @@ struct Tune {  // experiment switches (GIPUMA_HIP_TUNE), all default off
     static constexpr unsigned kNoLut = 1, kNoInterior = 2, kNoXcdRemap = 4, kGenericBox = 8,
                               kGenericCombine = 16, kRowMajorTiles = 32, kNoSkip = 64,
                               kUntrustedCosts = 128,  // set by the host after gipuma_hip_set_state
+                              kRegroup = 1u << 22,       // opt-in: lanes swap pixels before refinement (see regroup_for_refinement; measured: no gain)
                               kRowsKernel = 1u << 21,    // refinement by the row-per-lane kernel (pm_refine_rows.h); opt-in: not faster when fused
                               kSharedProp = 1u << 20,    // propagation by the shared-sample kernel (pm_prop_shared.h); opt-in while it is slower
                               kNoMagicAddr = 1u << 30,  // integer window addressing (bits 8..19: band height)
@@ -1628,6 +1629,88 @@ __device__ __forceinline__ void owner_pixel(const SweepLane &L, int owner, int c
     olx = 2 * (owner & 15) + ((oly + colour) & 1);
 }
 
+// Regrouping before the refinement rounds (performance only; OPT-IN, Tune::kRegroup: on config C the
+// sort + exchange costs what the tighter wavefronts save, 115.2 vs 114.7 ms same box).  The bounded evaluation of
+// multiview_cost leaves a view when the SLOWEST lane of the wavefront has reached its bound, and how
+// soon a lane gets there is predictable: the first refinement candidates are far-off planes whose
+// dis is close to saturation, so their partial sums grow like the running sum of the pixel's
+// support weights, and the bound is the pixel's own cost.  Lanes are therefore re-dealt: every
+// lane computes the window column at which 0.6 * dis_max * (weights so far) reaches its cost, the
+// 256 pixels of the tile are sorted by that key (counting sort in LDS) and each lane adopts the
+// pixel of its rank -- plane, cost, change flag, position -- for the whole refinement stage and
+// writes that pixel back.  Wavefronts then hold pixels that stop at similar columns
+// (scripts/exp/et_stats.py: 51 / 61 % of the samples of steps 0 / 1 -> 39 / 53 %).  Results cannot
+// depend on which lane refines a pixel: the draws are keyed by the pixel (M4).
+template <int BOX>
+__device__ __forceinline__ void regroup_for_refinement(SweepLane &L, const Problem *__restrict__ P,
+                                                       const float *__restrict__ lut, int colour)
+{
+    constexpr int R = (BOX - 1) / 2, N = R + 1;
+    constexpr int kBins = 4 * N + 1;
+    static_assert(kBins <= 64, "one wavefront scans the histogram");
+    float *xpl = L.bres;                                   // [256] float4
+    float *xcst = L.bres + 4 * kThreads;                   // [256]
+    int *xinfo = reinterpret_cast<int *>(L.bres + 5 * kThreads);  // [256] lx | ly << 8 | chg << 16 | active << 17
+    int *hist = reinterpret_cast<int *>(L.btask);          // [64] + [64] (the task list is dead)
+    // key of this lane's pixel
+    int key = kBins - 1;
+    if (L.active) {
+        const float dis_max = (1.f - P->alpha) * P->tau_color + P->alpha * P->tau_gradient;
+        const float K = 0.6f * dis_max;
+        const float *tp0 = L.tile + ((L.ly + L.hh) * L.tw + (L.lx + L.hw)) * 4;
+        const float centre = tp0[0];
+        const char *lut_magic = (const char *)lut - kMagicBits;
+        float wsum = 0.0f;
+        bool found = false;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                const float colorDis = __builtin_fabsf(tp0[4 * ((2 * j - R) * L.tw + (2 * i - R))] - centre);
+                wsum += *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
+            }
+            const float reach = K * wsum;
+            if (!found && reach >= L.cst) {
+                found = true;
+                const int q = min(3, max(0, (int)(L.cst / reach * 4.0f)));
+                key = 4 * i + q;
+            }
+        }
+    }
+    if (threadIdx.x < 128) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int rank_in_bin = atomicAdd(&hist[key], 1);
+    __syncthreads();
+    if (threadIdx.x < 64) {  // exclusive scan of the bins by the first wavefront
+        const int v = (int)threadIdx.x < kBins ? hist[threadIdx.x] : 0;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if ((int)threadIdx.x >= d) incl += up;
+        }
+        hist[64 + threadIdx.x] = incl - v;
+    }
+    __syncthreads();
+    const int rank = hist[64 + key] + rank_in_bin;
+    *reinterpret_cast<float4 *>(xpl + 4 * rank) = L.pl;
+    xcst[rank] = L.cst;
+    xinfo[rank] = L.lx | (L.ly << 8) | ((int)L.chg << 16) | ((int)L.active << 17);
+    __syncthreads();
+    L.pl = *reinterpret_cast<const float4 *>(xpl + 4 * threadIdx.x);
+    L.cst = xcst[threadIdx.x];
+    const int info = xinfo[threadIdx.x];
+    L.lx = info & 255;
+    L.ly = (info >> 8) & 255;
+    L.chg = (unsigned)(info >> 16) & 1u;
+    L.active = ((info >> 17) & 1) != 0;
+    L.px = L.x0 + L.lx;
+    L.py = L.y0 + L.ly;
+    L.center = L.py * P->cols + L.px;
+    (void)colour;
+    __syncthreads();  // bres / btask may be reused
+}
+
 // (the packed-gray instantiations are held at 128 VGPRs = 4 wavefronts per SIMD)
 template <int BOX, bool U8, bool COMBINE_REG, bool INTERIOR, int CH>
 __global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kernel(const Problem *__restrict__ P,
@@ -1654,6 +1737,8 @@ __global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kerne
         if (r == prop_rounds) {
             __syncthreads();  // every wavefront runs the same number of rounds, so this is uniform
             sweep_replay(L, P, norm4);
+            if constexpr (ET && CH == 1 && BOX > 0)
+                if (et_on && R.nref > 0 && (tune & Tune::kRegroup)) regroup_for_refinement<BOX>(L, P, lds, colour);
             refine_begin(R, L, P, phase);
         }
         if (r == prop_rounds + R.nref) break;

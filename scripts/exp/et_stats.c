@@ -162,6 +162,7 @@ typedef struct {
     double plane_groups, plane_union_samples, plane_task_samples, plane_bbox_samples, plane_maxgroup;
     double cols_w8_ref[4][4]; /* like cols_wave_ref but a 'wave' of 8 tasks (8 lanes per task) */
     double seen4, seen8, seen32;  /* needed prop tasks whose plane this pixel evaluated before (ring of K) */
+    double cols_sorted_ref[4][4]; /* wave-level with lanes regrouped by a predicted stop column */
 } launch_stats;
 
 static int ratio_bin(float F, float B)
@@ -229,6 +230,7 @@ int et_stats_run(const gipuma_hip_desc *d, int x0, int y0, int x1, int y1, int n
                 static __thread unsigned char stopbuf[4][3][256][GIPUMA_HIP_MAX_VIEWS];
                 static __thread unsigned char refvalid[256];
                 static __thread unsigned char ambbuf[4][3][256];
+                static __thread float keybuf[3][256];
                 static __thread unsigned char pstop[4][2048][GIPUMA_HIP_MAX_VIEWS];
                 int nprop = 0;
                 static __thread struct { int lx, ly; uint32_t pl[4]; } ptask[2048];
@@ -396,6 +398,20 @@ int et_stats_run(const gipuma_hip_desc *d, int x0, int y0, int x1, int y1, int n
                                 task_eval te;
                                 eval_task(d, x, y, cand, &te);
                                 const int sidx = step < 3 ? step : 3;
+                                if (step < 3) {
+                                    /* predicted stop: saturated dis times the running sum of support weights */
+                                    const float dismax = (1.f - ap->alpha) * ap->tau_color + ap->alpha * ap->tau_gradient;
+                                    const float centre = go_texel(d->images[0], rows, cols, d->pitch, x, y);
+                                    const int hR = (ap->box_hsize - 1) / 2, vR = (ap->box_vsize - 1) / 2;
+                                    float wsum = 0.f, key = 99.f;
+                                    int cc = 0;
+                                    for (int i = -hR; i <= hR; i += 2, cc++) {
+                                        for (int j = -vR; j <= vR; j += 2)
+                                            wsum += go_exp(-fabsf(go_texel(d->images[0], rows, cols, d->pitch, x + i, y + j) - centre) / ap->gamma);
+                                        if (key > 98.f && dismax * wsum * 0.6f >= st.cost) key = (float)cc + st.cost / (dismax * wsum * 0.6f);
+                                    }
+                                    keybuf[step][lane] = key;
+                                }
                                 loc.ref_tasks[sidx] += 1;
                                 loc.cols_full_ref[sidx] += (double)te.nv * te.nc;
                                 loc.ratio_hist_ref[sidx][ratio_bin(te.F, st.cost)] += 1;
@@ -461,6 +477,33 @@ int et_stats_run(const gipuma_hip_desc *d, int x0, int y0, int x1, int y1, int n
                                 loc.cols_w8_ref[p][step] += 8.0 * mx + (anyamb ? 8.0 * mx0 : 0.0);
                             }
                         }
+                /* lanes regrouped by the predicted key: rank order -> waves of 64 */
+                for (int step = 0; step < 3; step++) {
+                    int idx[256];
+                    for (int l = 0; l < 256; l++) idx[l] = l;
+                    for (int a = 1; a < 256; a++) {
+                        const int v = idx[a];
+                        int b = a;
+                        for (; b >= 1 && keybuf[step][v] < keybuf[step][idx[b - 1]]; b--) idx[b] = idx[b - 1];
+                        idx[b] = v;
+                    }
+                    for (int p = 0; p < 4; p++)
+                        for (int w = 0; w < 4; w++) {
+                            int anyamb = 0;
+                            for (int l = 0; l < 64; l++)
+                                if (refvalid[idx[w * 64 + l]] && ambbuf[p][step][idx[w * 64 + l]]) anyamb = 1;
+                            for (int k = 0; k < nv; k++) {
+                                int mx = 0, mx0 = 0;
+                                for (int l = 0; l < 64; l++) {
+                                    const int ll = idx[w * 64 + l];
+                                    if (!refvalid[ll]) continue;
+                                    if (stopbuf[p][step][ll][k] > mx) mx = stopbuf[p][step][ll][k];
+                                    if (stopbuf[0][step][ll][k] > mx0) mx0 = stopbuf[0][step][ll][k];
+                                }
+                                loc.cols_sorted_ref[p][step] += 64.0 * mx + (anyamb ? 64.0 * mx0 : 0.0);
+                            }
+                        }
+                }
                 /* propagation: groups of 64 tasks in owner order */
                 for (int p = 0; p < 4; p++)
                     for (int g = 0; g < nprop; g += 64)

@@ -35,7 +35,7 @@ names = [("prop_tasks", 1), ("ref_tasks", 4), ("cols_full_prop", 1), ("cols_full
          ("cols_lane_prop", 4), ("cols_lane_ref", 16), ("cols_wave_ref", 16), ("cols_wave_prop", 4),
          ("ambiguous_prop", 4), ("ambiguous_ref", 16), ("wrong", 4),
          ("jobs", 1), ("job_union_cols", 1), ("job_target_cols", 1), ("job_hist", 5),
-         ("accepted_prop", 1), ("accepted_ref", 4), ("ratio_hist_ref", 32), ("ratio_hist_prop", 8), ("plane_groups", 1), ("plane_union_samples", 1), ("plane_task_samples", 1), ("plane_bbox_samples", 1), ("plane_maxgroup", 1), ("cols_w8_ref", 16), ("seen4", 1), ("seen8", 1), ("seen32", 1)]
+         ("accepted_prop", 1), ("accepted_ref", 4), ("ratio_hist_ref", 32), ("ratio_hist_prop", 8), ("plane_groups", 1), ("plane_union_samples", 1), ("plane_task_samples", 1), ("plane_bbox_samples", 1), ("plane_maxgroup", 1), ("cols_w8_ref", 16), ("seen4", 1), ("seen8", 1), ("seen32", 1), ("cols_sorted_ref", 16)]
 off = {}
 o = 0
 for n, k in names:
@@ -77,6 +77,9 @@ for li in range(nl):
     c8 = f(r, "cols_w8_ref").reshape(4, 4)
     for p in range(4):
         print("    %-13s 8-task wavefronts: ref %s" % (pol[p], np.round(c8[p][:3] / np.maximum(cfr[:3], 1), 3)))
+    cs_ = f(r, "cols_sorted_ref").reshape(4, 4)
+    for p in range(4):
+        print("    %-13s waves of lanes sorted by predicted stop: ref %s" % (pol[p], np.round(cs_[p][:3] / np.maximum(cfr[:3], 1), 3)))
     print("    seen-before fraction of needed prop tasks: K=4 %.3f  K=8 %.3f  K=32 %.3f" %
           (f(r, "seen4")[0] / max(pt, 1), f(r, "seen8")[0] / max(pt, 1), f(r, "seen32")[0] / max(pt, 1)))
     jobs = f(r, "jobs")[0]

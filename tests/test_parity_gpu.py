@@ -214,7 +214,7 @@ def test_device_resident_images_with_pitch(hip):
 @pytest.mark.parametrize("tune", [1 << 30, 1 << 29, 1 << 28, (1 << 30) | (1 << 28), 1 << 27, 1 << 26,
                                   (1 << 26) | (1 << 29), 1 << 23, 1 << 25, (1 << 25) | (1 << 27), 1 << 20,
                                   (1 << 20) | (1 << 27), (1 << 20) | (1 << 25) | (1 << 23), 1 << 21,
-                                  (1 << 21) | (1 << 20), (1 << 27) | (1 << 25)])
+                                  (1 << 21) | (1 << 20), (1 << 27) | (1 << 25), 1 << 22, (1 << 22) | (1 << 27)])
 def test_kernel_variants_are_bit_identical(hip, tune):
     """the performance-only choices of the sweep kernels -- float-encoded window offsets + the
     hand-pipelined loop (off: bit 30), task order owner-major (bit 29) / source-major (bit 28) in
@@ -222,7 +222,8 @@ def test_kernel_variants_are_bit_identical(hip, tune):
     27) / in every half-sweep (bit 26) instead of the first four, the history skip rule off (bit
     23), early termination of view costs off (bit 25), propagation by the shared-sample kernel
     (bit 20: pm_prop_shared.h, followed by a refinement-only launch), refinement by the row-per-lane
-    kernel (bit 21: pm_refine_rows.h, groups of 8 lanes on column-major packed views) -- must not
+    kernel (bit 21: pm_refine_rows.h, groups of 8 lanes on column-major packed views), the lanes of
+    a workgroup regrouped by predicted stopping column before refinement (bit 22, opt-in) -- must not
     change a single bit.
     Box 15 (the pipelined and column-per-lane instantiations), 4 iterations so that the default run
     uses both kernels and both task orders."""
