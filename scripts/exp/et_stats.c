@@ -94,6 +94,8 @@ static void eval_task(const gipuma_hip_desc *d, int x, int y, const float pl[4],
  * column c with prefix >= min(b_{m-1}, kappa*m*B) (b: m smallest lower bounds so far).
  * stop[k] = columns evaluated for the k-th processed view.  Returns decision (1 = accept)
  * and checks it against the exact one. */
+static int g_use_kth = 1; /* 0: a view is cut off at thr only (items independent of the other views) */
+#pragma omp threadprivate(g_use_kth)
 static int policy_run(const task_eval *t, const int *order, int m, float B, float kappa, unsigned char *stop,
                       int *ambiguous)
 {
@@ -106,7 +108,7 @@ static int policy_run(const task_eval *t, const int *order, int m, float B, floa
     const float thr = kappa * (float)m * B * 1.000001f;
     for (int k = 0; k < t->nv; k++) {
         const int v = order[k];
-        const float tau = fminf(b[m - 1], thr);
+        const float tau = g_use_kth ? fminf(b[m - 1], thr) : thr;
         int c = 0;
         float p = 0.f;
         int truncated = 0;
@@ -163,6 +165,11 @@ typedef struct {
     double cols_w8_ref[4][4]; /* like cols_wave_ref but a 'wave' of 8 tasks (8 lanes per task) */
     double seen4, seen8, seen32;  /* needed prop tasks whose plane this pixel evaluated before (ring of K) */
     double cols_sorted_ref[4][4]; /* wave-level with lanes regrouped by a predicted stop column */
+    /* workgroup pool: per view, rounds of G columns (G = 1, 2, 4); after a round the lanes that reached
+     * their bound drop out and the survivors are compacted into ceil(alive/64) wavefronts; lanes left
+     * ambiguous are redone in full (compacted too) */
+    double cols_pool_ref[4][4][3];
+    double cols_wave_nr[4][4]; /* wave-level without the redo cost */
 } launch_stats;
 
 static int ratio_bin(float F, float B)
@@ -227,9 +234,9 @@ int et_stats_run(const gipuma_hip_desc *d, int x0, int y0, int x1, int y1, int n
                 launch_stats loc;
                 memset(&loc, 0, sizeof loc);
                 /* per tile: 256 pixels of the colour, lane id = (ly << 4) | (lx >> 1) */
-                static __thread unsigned char stopbuf[4][3][256][GIPUMA_HIP_MAX_VIEWS];
+                static __thread unsigned char stopbuf[4][4][256][GIPUMA_HIP_MAX_VIEWS];
                 static __thread unsigned char refvalid[256];
-                static __thread unsigned char ambbuf[4][3][256];
+                static __thread unsigned char ambbuf[4][4][256];
                 static __thread float keybuf[3][256];
                 static __thread unsigned char pstop[4][2048][GIPUMA_HIP_MAX_VIEWS];
                 int nprop = 0;
@@ -420,13 +427,15 @@ int et_stats_run(const gipuma_hip_desc *d, int x0, int y0, int x1, int y1, int n
                                 const int *orders[4] = {order_fixed, order_fixed, order_fixed, order_fixed};
                                 const float kap[4] = {1.f, THETA1 / (float)m, THETA2 / (float)m, THETA3 / (float)m};
                                 for (int p = 0; p < 4; p++) {
-                                    const int dec = policy_run(&te, orders[p], m, st.cost, kap[p], stop, &amb);
+                                    g_use_kth = p != 3; /* refinement, policy 3: theta 1.0, thr only */
+                                    const int dec = policy_run(&te, orders[p], m, st.cost, p == 3 ? THETA1 / (float)m : kap[p], stop, &amb);
+                                    g_use_kth = 1;
                                     int s = 0;
                                     for (int v = 0; v < nv; v++) s += stop[v];
                                     loc.cols_lane_ref[p][sidx] += s;
                                     loc.ambiguous_ref[p][sidx] += amb;
                                     if (!amb && dec != (te.F < st.cost)) loc.wrong[p] += 1;
-                                    if (step < 3) { memcpy(stopbuf[p][step][lane], stop, (size_t)nv); ambbuf[p][step][lane] = (unsigned char)amb; }
+                                    if (step < 4) { memcpy(stopbuf[p][step][lane], stop, (size_t)nv); ambbuf[p][step][lane] = (unsigned char)amb; }
                                 }
                                 refvalid[lane] = 1;
                                 if (te.F < st.cost) {
@@ -445,6 +454,15 @@ int et_stats_run(const gipuma_hip_desc *d, int x0, int y0, int x1, int y1, int n
                     }
                 /* wave level: refinement, wave = 64 consecutive lanes; a wave with an ambiguous lane
                  * re-runs the step under policy 0 (3B) */
+                for (int p = 0; p < 4; p++)
+                    for (int step = 0; step < 4; step++)
+                        for (int w = 0; w < 4; w++)
+                            for (int k = 0; k < nv; k++) {
+                                int mx = 0;
+                                for (int l = 0; l < 64; l++)
+                                    if (refvalid[w * 64 + l] && stopbuf[p][step][w * 64 + l][k] > mx) mx = stopbuf[p][step][w * 64 + l][k];
+                                loc.cols_wave_nr[p][step] += 64.0 * mx;
+                            }
                 for (int p = 0; p < 4; p++)
                     for (int step = 0; step < 3; step++)
                         for (int w = 0; w < 4; w++) {
@@ -476,6 +494,26 @@ int et_stats_run(const gipuma_hip_desc *d, int x0, int y0, int x1, int y1, int n
                                     }
                                 loc.cols_w8_ref[p][step] += 8.0 * mx + (anyamb ? 8.0 * mx0 : 0.0);
                             }
+                        }
+                for (int p = 0; p < 4; p++)
+                    for (int step = 0; step < 4; step++)
+                        for (int gi = 0; gi < 3; gi++) {
+                            const int G = 1 << gi;
+                            const int nc = (d->params.box_hsize + 1) / 2;
+                            int namb = 0;
+                            for (int l = 0; l < 256; l++)
+                                if (refvalid[l] && ambbuf[p][step][l]) namb++;
+                            double work = 0;
+                            for (int k = 0; k < nv; k++)
+                                for (int c0 = 0; c0 < nc; c0 += G) {
+                                    int alive = 0;
+                                    for (int l = 0; l < 256; l++)
+                                        if (refvalid[l] && stopbuf[p][step][l][k] > c0) alive++;
+                                    const int g = c0 + G <= nc ? G : nc - c0;
+                                    work += (double)((alive + 63) / 64) * 64.0 * g;
+                                }
+                            work += (double)((namb + 63) / 64) * 64.0 * nc * nv;
+                            loc.cols_pool_ref[p][step][gi] += work;
                         }
                 /* lanes regrouped by the predicted key: rank order -> waves of 64 */
                 for (int step = 0; step < 3; step++) {

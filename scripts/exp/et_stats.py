@@ -35,7 +35,7 @@ names = [("prop_tasks", 1), ("ref_tasks", 4), ("cols_full_prop", 1), ("cols_full
          ("cols_lane_prop", 4), ("cols_lane_ref", 16), ("cols_wave_ref", 16), ("cols_wave_prop", 4),
          ("ambiguous_prop", 4), ("ambiguous_ref", 16), ("wrong", 4),
          ("jobs", 1), ("job_union_cols", 1), ("job_target_cols", 1), ("job_hist", 5),
-         ("accepted_prop", 1), ("accepted_ref", 4), ("ratio_hist_ref", 32), ("ratio_hist_prop", 8), ("plane_groups", 1), ("plane_union_samples", 1), ("plane_task_samples", 1), ("plane_bbox_samples", 1), ("plane_maxgroup", 1), ("cols_w8_ref", 16), ("seen4", 1), ("seen8", 1), ("seen32", 1), ("cols_sorted_ref", 16)]
+         ("accepted_prop", 1), ("accepted_ref", 4), ("ratio_hist_ref", 32), ("ratio_hist_prop", 8), ("plane_groups", 1), ("plane_union_samples", 1), ("plane_task_samples", 1), ("plane_bbox_samples", 1), ("plane_maxgroup", 1), ("cols_w8_ref", 16), ("seen4", 1), ("seen8", 1), ("seen32", 1), ("cols_sorted_ref", 16), ("cols_pool_ref", 48), ("cols_wave_nr", 16)]
 off = {}
 o = 0
 for n, k in names:
@@ -51,7 +51,7 @@ def f(row, n):
 
 npx = (win[2] - win[0]) * (win[3] - win[1]) / 2
 print("window %s, %d px per colour" % (win, npx))
-pol = ["3B", "th1.0", "th1.5", "th2.0"]
+pol = ["3B", "th1.0", "th1.5", "th2.0/1.0nk"]  # refinement: the 4th policy is theta 1.0 without the k-th-smallest rule
 for li in range(nl):
     r = out[li]
     pt = f(r, "prop_tasks")[0]
@@ -80,6 +80,12 @@ for li in range(nl):
     cs_ = f(r, "cols_sorted_ref").reshape(4, 4)
     for p in range(4):
         print("    %-13s waves of lanes sorted by predicted stop: ref %s" % (pol[p], np.round(cs_[p][:3] / np.maximum(cfr[:3], 1), 3)))
+    wn_ = f(r, "cols_wave_nr").reshape(4, 4)
+    for p in range(4):
+        print("    %-13s wave-level, redo not counted: ref %s  amb %s lane %s" % (pol[p], np.round(wn_[p][:4] / np.maximum(cfr[:4], 1), 3), np.round(amb_r[p][:4] / np.maximum(rt[:4], 1), 4), np.round(clr[p][:4] / np.maximum(cfr[:4], 1), 3)))
+    cp_ = f(r, "cols_pool_ref").reshape(4, 4, 3)
+    for p in range(4):
+        print("    %-13s workgroup pool, compaction every 1/2/4 columns: ref %s" % (pol[p], " | ".join(str(np.round(cp_[p][:4, g] / np.maximum(cfr[:4], 1), 3)) for g in range(3))))
     print("    seen-before fraction of needed prop tasks: K=4 %.3f  K=8 %.3f  K=32 %.3f" %
           (f(r, "seen4")[0] / max(pt, 1), f(r, "seen8")[0] / max(pt, 1), f(r, "seen32")[0] / max(pt, 1)))
     jobs = f(r, "jobs")[0]
