@@ -574,7 +574,11 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         hp.et_enable = sane && big && s->u8 && s->combine_reg && (s->ch == 4 || (hp.magic_addr && s->box > 0));
         hp.et_theta[0] = 1.0f;
         hp.et_theta[1] = 1.0f;
-        hp.et_theta[2] = 1.5f;
+        // the two-phase refinement (gray, compile-time box) redoes open candidates item by item, which
+        // is cheap; the per-wavefront bound repeats the whole wavefront and wants a looser third bound
+        const bool two_phase = s->ch == 1 && s->box > 0 && !(s->tune & (Tune::kNoTwoPhase | Tune::kRegroup));
+        hp.et_theta[2] = two_phase ? 1.0f : 1.5f;
+        if (const char *g = getenv("GIPUMA_HIP_TP_G0")) hp.tp_g0 = atoi(g);  // experiment: phase-1 columns
         if (const char *t = getenv("GIPUMA_HIP_ET_THETA")) {  // experiment: "t0,t1,t2" (any value is exact)
             float a, b, c;
             if (sscanf(t, "%f,%f,%f", &a, &b, &c) == 3) {

@@ -57,6 +57,7 @@ struct Problem {  // lives in device memory, read through scalar loads (wave-uni
     // bound a step only if that paid for the previous half-sweep's probes.  Half-sweep k (= phase)
     // writes slot k % 3, reads slot (k-1) % 3 and clears slot (k+1) % 3.
     unsigned *et_stat;
+    int tp_g0;  // window columns of phase 1 of refine_two_phase (0: default, 3/8 of the window)
 #ifdef PM_PS_PROFILE
     unsigned long long *prof;  // experiment builds only
 #endif
@@ -226,7 +227,20 @@ __host__ __device__ constexpr int lut_size()
 }
 
 // sweep kernel scratch per workgroup: [8][256] candidate costs, 2048 u16 task slots, counters
-constexpr int kTaskScratchFloats = 8 * kThreads + (8 * kThreads) / 2 + 32;
+constexpr int kTaskScratchFloats = 8 * kThreads + (8 * kThreads) / 2 + 32 + 128;
+// ... reused by the two-phase refinement (refine_two_phase): partial view costs of a group of
+// kTpViews views, the candidates, their bounds, the list of surviving (task, view) items, counters
+constexpr int kTpViews = 5;
+struct TpLayout {  // offsets in floats into the scratch region
+    static constexpr int acc = 0;                             // [kTpViews][256] partial / final view costs
+    static constexpr int plane = acc + kTpViews * kThreads;   // [256] float4 candidate planes
+    static constexpr int tau = plane + 4 * kThreads;          // [256] bounds
+    static constexpr int items = tau + kThreads;              // [kTpViews * 256] u16: view in group << 8 | task
+    static constexpr int cnt = items + kTpViews * kThreads / 2;  // two item counters, used alternately
+    static constexpr int total = cnt + 4;
+};
+static_assert(TpLayout::total <= kTaskScratchFloats, "two-phase refinement scratch");
+static_assert(TpLayout::cnt >= 8 * kThreads + (8 * kThreads) / 2 + 32, "the item counters must not alias the task scratch");
 
 template <int CH>
 __host__ __device__ constexpr int work_floats(int tile_texels, bool sweep)
@@ -262,10 +276,11 @@ struct Tune {  // experiment switches (GIPUMA_HIP_TUNE), all default off
     static constexpr unsigned kNoLut = 1, kNoInterior = 2, kNoXcdRemap = 4, kGenericBox = 8,
                               kGenericCombine = 16, kRowMajorTiles = 32, kNoSkip = 64,
                               kUntrustedCosts = 128,  // set by the host after gipuma_hip_set_state
+                              kNoTwoPhase = 1u << 19,    // refinement bounded per wavefront (v11) instead of two-phase (refine_two_phase)
                               kRegroup = 1u << 22,       // opt-in: lanes swap pixels before refinement (see regroup_for_refinement; measured: no gain)
                               kRowsKernel = 1u << 21,    // refinement by the row-per-lane kernel (pm_refine_rows.h); opt-in: not faster when fused
                               kSharedProp = 1u << 20,    // propagation by the shared-sample kernel (pm_prop_shared.h); opt-in while it is slower
-                              kNoMagicAddr = 1u << 30,  // integer window addressing (bits 8..19: band height)
+                              kNoMagicAddr = 1u << 30,  // integer window addressing (bits 8..17: band height)
                               kOwnerMajorTasks = 1u << 29,   // always owner-major task lists
                               kSourceMajorTasks = 1u << 28,  // always source-major (default: by iteration)
                               kNoColsKernel = 1u << 27,      // never the column-per-lane kernel
@@ -687,6 +702,93 @@ __device__ __forceinline__ float view_cost_pipe(const Problem *__restrict__ P, c
         }
     }
     if (ET && cols_done) *cols_done += N + 1;  // (+1: homography and set-up of the view, paid again by a redo)
+    return cost;
+}
+
+// view_cost_pipe restricted to the window columns [c0, c1), continuing from the partial sum `cost`
+// (the value view_cost_pipe holds after column c0 - 1): the same samples, the same instruction
+// sequence per sample, the same accumulation order.  `magic_base` may differ per lane (the lanes
+// of a wavefront may work on different source views, see refine_two_phase).  The wavefront leaves
+// after the first column at which every lane has reached its `tau`; *cols_run += columns evaluated.
+template <int BOX, bool FAST>
+__device__ __forceinline__ float view_cost_pipe_range(const Problem *__restrict__ P, gptr_bytes magic_base,
+                                                      const float *__restrict__ H, const float *__restrict__ tp0,
+                                                      int tw, const float *__restrict__ lut, int px, int py, int c0,
+                                                      int c1, float cost, float tau, int *cols_run)
+{
+    static_assert(BOX > 0, "compile-time window only");
+    constexpr int R = (BOX - 1) / 2, N = R + 1;
+    const float colsf = (float)P->cols, rowsf = (float)P->rows;
+    const float alpha = P->alpha, oma = 1.f - P->alpha;
+    const float tau_color = P->tau_color, tau_gradient = P->tau_gradient;
+    const float centre = tp0[0];
+    const float pwf = (float)P->pw;
+    const float magic_c = kMagicF + (float)(2 * P->pw + 2);
+    const char *lut_magic = (const char *)lut - kMagicBits;
+    const float H1 = H[1], H4 = H[4], H7 = H[7];
+
+    auto request = [&](float X0, float Y0, float Z0, float qy) -> WinReq {
+        const float X = __builtin_fmaf(H1, qy, X0);
+        const float Y = __builtin_fmaf(H4, qy, Y0);
+        const float Z = __builtin_fmaf(H7, qy, Z0);
+        const float rz = recip<FAST>(Z);
+        const float sx = X * rz, sy = Y * rz;
+        const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
+        WinReq r;
+        r.a = sx - fx0;
+        r.b = sy - fy0;
+        const float Xc = __builtin_amdgcn_fmed3f(fx0, -2.0f, colsf);
+        const float Yc = __builtin_amdgcn_fmed3f(fy0, -2.0f, rowsf);
+        const uint32_t off = __float_as_uint(__builtin_fmaf(Yc, pwf, Xc + magic_c));
+        r.w = *(gptr_u32x4)(magic_base + off);
+        return r;
+    };
+
+    const float qy0 = (float)(py - R);
+    float qx = (float)(px - R + 2 * c0);  // (exact: small integers)
+    float X0 = __builtin_fmaf(H[0], qx, H[2]);
+    float Y0 = __builtin_fmaf(H[3], qx, H[5]);
+    float Z0 = __builtin_fmaf(H[6], qx, H[8]);
+    WinReq r0 = request(X0, Y0, Z0, qy0), r1 = request(X0, Y0, Z0, qy0 + 2.0f);
+    const float *tcol = tp0 + 4 * (-R * tw - R) + 8 * c0;
+    int c = c0;
+    for (; c < c1; c++, tcol += 8) {
+        const float qxn = qx + 2.0f;
+        const float X0n = __builtin_fmaf(H[0], qxn, H[2]);
+        const float Y0n = __builtin_fmaf(H[3], qxn, H[5]);
+        const float Z0n = __builtin_fmaf(H[6], qxn, H[8]);
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const WinReq cur = r0;
+            r0 = r1;
+            if (k + 2 < N)
+                r1 = request(X0, Y0, Z0, qy0 + (float)(2 * (k + 2)));
+            else
+                r1 = request(X0n, Y0n, Z0n, qy0 + (float)(2 * (k + 2 - N)));
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 t4 = *reinterpret_cast<const float4 *>(tcol + 8 * k * tw);
+            const float colorDis = __builtin_fabsf(t4.x - centre);
+            const float w = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
+            const Taps tp5 = taps_u8(cur.a, cur.b, cur.w.x, cur.w.y, cur.w.z, cur.w.w);
+            const float colDiff = t4.w - tp5.sc;
+            const float gradX = t4.y - tp5.gx2;
+            const float gradY = t4.z - tp5.gy2;
+            const float gradDis = min_nc((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
+            const float colDis = min_abs_nc(colDiff, tau_color);
+            const float dis = __builtin_fmaf(alpha, gradDis, oma * colDis);
+            cost = __builtin_fmaf(w, dis, cost);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        qx = qxn;
+        X0 = X0n;
+        Y0 = Y0n;
+        Z0 = Z0n;
+        if (__all(cost >= tau)) {
+            c++;
+            break;
+        }
+    }
+    if (cols_run) *cols_run += c - c0;
     return cost;
 }
 
@@ -1114,7 +1216,7 @@ __device__ __forceinline__ TileXY tile_of(int b, int gx, int gy, unsigned tune)
         o.x = t % gx;
         o.y = t / gx;
     } else {
-        const int bo = (int)((tune >> 8) & 0xfffu);          // experiment override of the band height (bits 8..19)
+        const int bo = (int)((tune >> 8) & 0x3ffu);          // experiment override of the band height (bits 8..17)
         const int bh = bo ? min(bo, gy) : (gy + 7) >> 3;  // band height in tile rows
         const int band = t / (bh * gx);
         const int h = min(bh, gy - band * bh);   // the last band may be shorter
@@ -1711,6 +1813,115 @@ __device__ __forceinline__ void regroup_for_refinement(SweepLane &L, const Probl
     __syncthreads();  // bres / btask may be reused
 }
 
+// Two-phase evaluation of one refinement step of a workgroup (performance only; gray packed planes
+// with float-encoded offsets, compile-time box, register combiner).
+//
+// multiview_cost's bounded evaluation leaves a view when the SLOWEST of 64 lanes has reached its
+// bound; the average lane gets there after a third of the window (scripts/exp/et_stats.py), the
+// slowest of 64 after more than half.  Here the unit of work is the (candidate, view) ITEM:
+//   phase 1  every lane evaluates the first g0 window columns of every view of its own candidate
+//            (the partial sums go to LDS); an item whose partial sum has not reached tau = thr
+//            survives, and the survivors of the workgroup are appended to one list;
+//   phase 2  the list is dealt out 64 items per wavefront: a lane picks up an item of any pixel --
+//            its plane and bound from LDS, the homography recomputed by the literal arithmetic of
+//            homography() -- and continues the sum from column g0, the wavefront leaving when all
+//            of its items have reached their bounds;
+//   combine  every lane collects the values of its candidate's views -- exact costs, or lower
+//            bounds >= thr -- in view order through the same ViewCombiner.
+// Views are handled in groups of kTpViews (LDS space).  The values are those of view_cost_pipe
+// stopped at a column boundary, and the bound is thr alone (not min(b[m-1], thr)), so the three
+// cases of multiview_cost's proof apply unchanged: kth < thr -> exact; else F' >= bound -> rejected;
+// else the caller calls again with thr = inf, g0 = 0 for the lanes left open (every view of theirs
+// becomes an item and is summed in full).  Which lane evaluates an item cannot matter: an item is
+// a pure function of (pixel, plane, view, columns).
+// All lanes of the workgroup must call this (barriers); `seq` counts the groups processed so far
+// in this launch (the two item counters are used alternately: the one not in use is cleared while
+// nobody touches it).
+template <int BOX>
+__device__ __forceinline__ float refine_two_phase(const Problem *__restrict__ P, const SweepLane &L, float *work,
+                                                  const float *__restrict__ lut, int colour, bool valid, float4 cand,
+                                                  float thr, int g0, float *kth_out, int &seq, int *cols_run)
+{
+    constexpr int R = (BOX - 1) / 2, N = R + 1;
+    float *accv = work + TpLayout::acc;
+    float4 *tplane = reinterpret_cast<float4 *>(work + TpLayout::plane);
+    float *ttau = work + TpLayout::tau;
+    unsigned short *items = reinterpret_cast<unsigned short *>(work + TpLayout::items);
+    int *cnt = reinterpret_cast<int *>(work + TpLayout::cnt);
+    const int n = P->n_sel, m = min(n, P->n_best);
+    const int tid = threadIdx.x;
+    const float ninf = -__builtin_inff();
+    const float my_tau = valid ? thr : ninf;  // lanes without a candidate never hold a wavefront back
+    tplane[tid] = cand;
+    ttau[tid] = thr;
+    ViewCombiner<true> comb;
+    for (int vb = 0; vb < n; vb += kTpViews, seq++) {
+        const int ve = min(vb + kTpViews, n);
+        int *ctr = cnt + (seq & 1);
+        // ---- phase 1 ----
+        for (int v = vb; v < ve; v++) {
+            float a = 0.0f;
+            bool alive = valid;
+            if (g0 > 0) {
+                float H[9];
+                homography(P->rc.K_inv, P->view[v], cand, H);
+                const bool safe = window_z_safe(H, (float)(L.px - R), (float)(L.px + R), (float)(L.py - R), (float)(L.py + R));
+                const gptr_bytes base = (gptr_bytes)((uintptr_t)P->view[v].packed - (uintptr_t)kMagicBits);
+                const float *tp0 = L.tile + ((L.ly + L.hh) * L.tw + (L.lx + L.hw)) * 4;
+                if (__all(safe))
+                    a = view_cost_pipe_range<BOX, true>(P, base, H, tp0, L.tw, lut, L.px, L.py, 0, g0, 0.0f, my_tau, cols_run);
+                else
+                    a = view_cost_pipe_range<BOX, false>(P, base, H, tp0, L.tw, lut, L.px, L.py, 0, g0, 0.0f, my_tau, cols_run);
+                if (cols_run) *cols_run += 1;  // (homography and set-up, as in view_cost_pipe's count)
+                alive = valid && !(a >= thr);
+            }
+            accv[(v - vb) * kThreads + tid] = a;
+            const unsigned long long bal = __ballot(alive);
+            if (bal != 0ull) {
+                int first = 0;
+                if ((tid & 63) == 0) first = atomicAdd(ctr, (int)__popcll(bal));
+                first = __builtin_amdgcn_readfirstlane(first);
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                if (alive) items[first + rank] = (unsigned short)(((v - vb) << 8) | tid);
+            }
+        }
+        __syncthreads();
+        const int n_items = *ctr;
+        if (tid == 0) cnt[(seq + 1) & 1] = 0;
+        // ---- phase 2 ----
+        for (int first = 0; first < n_items; first += kThreads) {
+            const int wave_first = first + (tid & ~63);
+            if (wave_first >= n_items) continue;  // (wave-uniform)
+            const int i = first + tid;
+            const bool have = i < n_items;
+            const unsigned it = items[have ? i : wave_first];  // spare lanes shadow the wavefront's first item
+            const int t = (int)(it & 255u), vl = (int)(it >> 8), v = vb + vl;
+            const float4 pl = tplane[t];
+            const float tau_i = have ? ttau[t] : ninf;
+            float a = accv[vl * kThreads + t];
+            int olx, oly;
+            owner_pixel(L, t, colour, olx, oly);
+            const int epx = L.x0 + olx, epy = L.y0 + oly;
+            const float *tp0 = L.tile + ((oly + L.hh) * L.tw + (olx + L.hw)) * 4;
+            float H[9];
+            homography(P->rc.K_inv, P->view[v], pl, H);
+            const bool safe = window_z_safe(H, (float)(epx - R), (float)(epx + R), (float)(epy - R), (float)(epy + R));
+            const gptr_bytes base = (gptr_bytes)((uintptr_t)P->view[v].packed - (uintptr_t)kMagicBits);
+            if (__all(safe))
+                a = view_cost_pipe_range<BOX, true>(P, base, H, tp0, L.tw, lut, epx, epy, g0, N, a, tau_i, cols_run);
+            else
+                a = view_cost_pipe_range<BOX, false>(P, base, H, tp0, L.tw, lut, epx, epy, g0, N, a, tau_i, cols_run);
+            if (cols_run) *cols_run += 1;
+            if (have) accv[vl * kThreads + t] = a;
+        }
+        __syncthreads();
+        // ---- combine (view order, as multiview_cost) ----
+        for (int v = vb; v < ve; v++) comb.add(accv[(v - vb) * kThreads + tid], v, nullptr);
+    }
+    *kth_out = comb.kth(m);
+    return comb.finish(P, n, nullptr);
+}
+
 // (the packed-gray instantiations are held at 128 VGPRs = 4 wavefronts per SIMD)
 template <int BOX, bool U8, bool COMBINE_REG, bool INTERIOR, int CH>
 __global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kernel(const Problem *__restrict__ P,
@@ -1729,6 +1940,9 @@ __global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kerne
     constexpr bool ET = U8 && COMBINE_REG && INTERIOR && (CH == 4 || BOX > 0);
     const bool et_on = ET && P->et_enable && !(tune & Tune::kNoEarlyExit);
     if (et_on && blockIdx.x == 0 && threadIdx.x < 6) P->et_stat[((phase + 1u) % 3u) * 6u + threadIdx.x] = 0u;
+    int tp_seq = 0;  // refine_two_phase: groups of views processed so far
+    if constexpr (ET && CH == 1 && BOX > 0)
+        if (threadIdx.x < 2) reinterpret_cast<int *>(L.bres + TpLayout::cnt)[threadIdx.x] = 0;  // (barriers follow)
 
     // One loop, one call site of the cost function: rounds [0, prop_rounds) evaluate compacted
     // propagation tasks (possibly of another lane's pixel), then the owner replays its accepts,
@@ -1740,6 +1954,8 @@ __global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kerne
             if constexpr (ET && CH == 1 && BOX > 0)
                 if (et_on && R.nref > 0 && (tune & Tune::kRegroup)) regroup_for_refinement<BOX>(L, P, lds, colour);
             refine_begin(R, L, P, phase);
+            if constexpr (ET && CH == 1 && BOX > 0)
+                if (et_on) __syncthreads();  // refine_two_phase reuses the candidate costs the replay has just read
         }
         if (r == prop_rounds + R.nref) break;
 
@@ -1766,6 +1982,47 @@ __global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kerne
             do_eval = L.active;
             if (do_eval) cand = refine_candidate(R, L, P, d_new);
             refine_next_step(R);
+        }
+        if constexpr (ET && CH == 1 && BOX > 0) {
+            // the first three refinement steps by items instead of wavefronts (refine_two_phase), where
+            // the previous half-sweep's probe workgroups found that bounding the step pays
+            if (et_on && r >= prop_rounds && r - prop_rounds < 3 && !(tune & (Tune::kNoTwoPhase | Tune::kRegroup))) {
+                const int step = r - prop_rounds;
+                const bool probe = (blockIdx.x & 15u) == 0u;
+                const unsigned *seen = P->et_stat + ((phase + 2u) % 3u) * 6u + 2 * step;
+                const bool pays = seen[0] > 0u && (unsigned long long)seen[1] * 100ull <= (unsigned long long)seen[0] * 85ull;
+                if (probe || pays) {  // (uniform over the workgroup)
+                    constexpr int Nc = (BOX + 1) / 2;
+                    int g0 = P->tp_g0 > 0 ? min(P->tp_g0, Nc) : (3 * Nc + 4) / 8;
+                    float thr = P->et_theta[step] * L.cst;
+                    bool need = do_eval;
+                    int cols_run = 0;
+                    float c = 0.0f;
+                    for (int pass = 0; pass < 2; pass++) {
+                        float kth;
+                        const float cc = refine_two_phase<BOX>(P, L, L.bres, lds, colour, need, cand, thr, g0, &kth, tp_seq,
+                                                               probe ? &cols_run : nullptr);
+                        const bool open = need && kth >= thr && cc < L.cst;
+                        if (need && !open) c = cc;
+                        need = open;
+                        thr = __builtin_inff();
+                        g0 = 0;
+                        if (!__syncthreads_or(need)) break;
+                    }
+                    if (probe && (threadIdx.x & 63u) == 0u) {
+                        unsigned *mine = P->et_stat + (phase % 3u) * 6u + 2 * step;
+                        atomicAdd(&mine[0], (unsigned)(P->n_sel * (Nc + 1)));
+                        atomicAdd(&mine[1], (unsigned)cols_run);
+                    }
+                    if (do_eval && c < L.cst) {  // refinement has no depth-range test, :986
+                        L.depth = d_new;
+                        L.pl = cand;
+                        L.cst = c;
+                        L.chg = 1;
+                    }
+                    continue;
+                }
+            }
         }
         if (do_eval) {
             const float *etp0 = L.tile + (((epy - L.y0) + L.hh) * L.tw + ((epx - L.x0) + L.hw)) * 4;

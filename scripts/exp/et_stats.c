@@ -170,6 +170,11 @@ typedef struct {
      * ambiguous are redone in full (compacted too) */
     double cols_pool_ref[4][4][3];
     double cols_wave_nr[4][4]; /* wave-level without the redo cost */
+    /* two-phase: every lane does the first G0 = 1, 2, 3, 4 columns of every view of its own task, the
+     * surviving (task, view) items of [half the views | all views] are compacted into wavefronts of 64
+     * that run to their slowest item's stop (theta 1.0, thr only); [step][G0-1][half/all] */
+    double cols_two_phase[4][4][2];
+    double items_alive[4][4]; /* surviving items after G0 columns / all items */
 } launch_stats;
 
 static int ratio_bin(float F, float B)
@@ -514,6 +519,41 @@ int et_stats_run(const gipuma_hip_desc *d, int x0, int y0, int x1, int y1, int n
                                 }
                             work += (double)((namb + 63) / 64) * 64.0 * nc * nv;
                             loc.cols_pool_ref[p][step][gi] += work;
+                        }
+                for (int step = 0; step < 3; step++)
+                    for (int g0 = 1; g0 <= 4; g0++)
+                        for (int mode = 0; mode < 2; mode++) {
+                            const int p = 3;
+                            const int nc = (d->params.box_hsize + 1) / 2;
+                            const int grp = mode == 0 ? (nv + 1) / 2 : nv;
+                            double work = 0;
+                            int nvalid = 0;
+                            for (int l = 0; l < 256; l++) nvalid += refvalid[l];
+                            work += 256.0 * nv * g0;
+                            for (int vb = 0; vb < nv; vb += grp) {
+                                int cnt = 0, mx = 0;
+                                for (int k = vb; k < vb + grp && k < nv; k++)
+                                    for (int l = 0; l < 256; l++) {
+                                        if (!refvalid[l] || stopbuf[p][step][l][k] <= g0) continue;
+                                        if (mode == 0 && g0 == 1) loc.items_alive[step][0] += 0; /* (counted below) */
+                                        if (stopbuf[p][step][l][k] > mx) mx = stopbuf[p][step][l][k];
+                                        if (++cnt == 64) {
+                                            work += 64.0 * (mx - g0);
+                                            cnt = 0;
+                                            mx = 0;
+                                        }
+                                    }
+                                if (cnt) work += 64.0 * (mx - g0);
+                            }
+                            loc.cols_two_phase[step][g0 - 1][mode] += work;
+                            if (mode == 1) {
+                                int alive = 0;
+                                for (int k = 0; k < nv; k++)
+                                    for (int l = 0; l < 256; l++)
+                                        if (refvalid[l] && stopbuf[p][step][l][k] > g0) alive++;
+                                loc.items_alive[step][g0 - 1] += alive;
+                            }
+                            (void)nc;
                         }
                 /* lanes regrouped by the predicted key: rank order -> waves of 64 */
                 for (int step = 0; step < 3; step++) {

@@ -35,7 +35,7 @@ names = [("prop_tasks", 1), ("ref_tasks", 4), ("cols_full_prop", 1), ("cols_full
          ("cols_lane_prop", 4), ("cols_lane_ref", 16), ("cols_wave_ref", 16), ("cols_wave_prop", 4),
          ("ambiguous_prop", 4), ("ambiguous_ref", 16), ("wrong", 4),
          ("jobs", 1), ("job_union_cols", 1), ("job_target_cols", 1), ("job_hist", 5),
-         ("accepted_prop", 1), ("accepted_ref", 4), ("ratio_hist_ref", 32), ("ratio_hist_prop", 8), ("plane_groups", 1), ("plane_union_samples", 1), ("plane_task_samples", 1), ("plane_bbox_samples", 1), ("plane_maxgroup", 1), ("cols_w8_ref", 16), ("seen4", 1), ("seen8", 1), ("seen32", 1), ("cols_sorted_ref", 16), ("cols_pool_ref", 48), ("cols_wave_nr", 16)]
+         ("accepted_prop", 1), ("accepted_ref", 4), ("ratio_hist_ref", 32), ("ratio_hist_prop", 8), ("plane_groups", 1), ("plane_union_samples", 1), ("plane_task_samples", 1), ("plane_bbox_samples", 1), ("plane_maxgroup", 1), ("cols_w8_ref", 16), ("seen4", 1), ("seen8", 1), ("seen32", 1), ("cols_sorted_ref", 16), ("cols_pool_ref", 48), ("cols_wave_nr", 16), ("cols_two_phase", 32), ("items_alive", 16)]
 off = {}
 o = 0
 for n, k in names:
@@ -83,6 +83,10 @@ for li in range(nl):
     wn_ = f(r, "cols_wave_nr").reshape(4, 4)
     for p in range(4):
         print("    %-13s wave-level, redo not counted: ref %s  amb %s lane %s" % (pol[p], np.round(wn_[p][:4] / np.maximum(cfr[:4], 1), 3), np.round(amb_r[p][:4] / np.maximum(rt[:4], 1), 4), np.round(clr[p][:4] / np.maximum(cfr[:4], 1), 3)))
+    tp_ = f(r, "cols_two_phase").reshape(4, 4, 2)
+    ia_ = f(r, "items_alive").reshape(4, 4)
+    for st_ in range(3):
+        print("    two-phase step %d: G0=1..4 half-views %s  all-views %s  alive items %s" % (st_, np.round(tp_[st_, :, 0] / max(cfr[st_], 1), 3), np.round(tp_[st_, :, 1] / max(cfr[st_], 1), 3), np.round(ia_[st_] * 8 / max(cfr[st_], 1), 3)))
     cp_ = f(r, "cols_pool_ref").reshape(4, 4, 3)
     for p in range(4):
         print("    %-13s workgroup pool, compaction every 1/2/4 columns: ref %s" % (pol[p], " | ".join(str(np.round(cp_[p][:4, g] / np.maximum(cfr[:4], 1), 3)) for g in range(3))))
