@@ -572,6 +572,8 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         const bool big = tiles >= 1024 || getenv("GIPUMA_HIP_ET_FORCE") != nullptr;  // (env: tests on small frames)
         // (gray: the pipelined loop on float-encoded offsets; colour: its integer-addressed loop)
         hp.et_enable = sane && big && s->u8 && s->combine_reg && (s->ch == 4 || (hp.magic_addr && s->box > 0));
+        // GIPUMA_HIP_ET_FORCE=2 (tests): every workgroup bounds every step, whatever the probes measured
+        if (hp.et_enable && getenv("GIPUMA_HIP_ET_FORCE") && atoi(getenv("GIPUMA_HIP_ET_FORCE")) >= 2) hp.et_enable = 2;
         hp.et_theta[0] = 1.0f;
         hp.et_theta[1] = 1.0f;
         // the two-phase refinement (gray, compile-time box) redoes open candidates item by item, which

@@ -1990,7 +1990,8 @@ __global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kerne
                 const int step = r - prop_rounds;
                 const bool probe = (blockIdx.x & 15u) == 0u;
                 const unsigned *seen = P->et_stat + ((phase + 2u) % 3u) * 6u + 2 * step;
-                const bool pays = seen[0] > 0u && (unsigned long long)seen[1] * 100ull <= (unsigned long long)seen[0] * 85ull;
+                const bool pays = P->et_enable > 1 ||  // (tests: every workgroup bounds every step)
+                                  (seen[0] > 0u && (unsigned long long)seen[1] * 100ull <= (unsigned long long)seen[0] * 85ull);
                 if (probe || pays) {  // (uniform over the workgroup)
                     constexpr int Nc = (BOX + 1) / 2;
                     int g0 = P->tp_g0 > 0 ? min(P->tp_g0, Nc) : (3 * Nc + 4) / 8;
@@ -2043,7 +2044,8 @@ __global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kerne
                 if (et_on && r >= prop_rounds && r - prop_rounds < 3) {
                     step = r - prop_rounds;
                     const unsigned *seen = P->et_stat + ((phase + 2u) % 3u) * 6u + 2 * step;
-                    const bool pays = seen[0] > 0u && (unsigned long long)seen[1] * 100ull <= (unsigned long long)seen[0] * 85ull;
+                    const bool pays = P->et_enable > 1 ||  // (tests: every workgroup bounds every step)
+                                  (seen[0] > 0u && (unsigned long long)seen[1] * 100ull <= (unsigned long long)seen[0] * 85ull);
                     if (probe) {
                         thr = P->et_theta[step] * L.cst;
                     } else if (pays) {

@@ -214,7 +214,8 @@ def test_device_resident_images_with_pitch(hip):
 @pytest.mark.parametrize("tune", [1 << 30, 1 << 29, 1 << 28, (1 << 30) | (1 << 28), 1 << 27, 1 << 26,
                                   (1 << 26) | (1 << 29), 1 << 23, 1 << 25, (1 << 25) | (1 << 27), 1 << 20,
                                   (1 << 20) | (1 << 27), (1 << 20) | (1 << 25) | (1 << 23), 1 << 21,
-                                  (1 << 21) | (1 << 20), (1 << 27) | (1 << 25), 1 << 22, (1 << 22) | (1 << 27)])
+                                  (1 << 21) | (1 << 20), (1 << 27) | (1 << 25), 1 << 22, (1 << 22) | (1 << 27), 1 << 19,
+                                  (1 << 19) | (1 << 27)])
 def test_kernel_variants_are_bit_identical(hip, tune):
     """the performance-only choices of the sweep kernels -- float-encoded window offsets + the
     hand-pipelined loop (off: bit 30), task order owner-major (bit 29) / source-major (bit 28) in
@@ -223,8 +224,9 @@ def test_kernel_variants_are_bit_identical(hip, tune):
     23), early termination of view costs off (bit 25), propagation by the shared-sample kernel
     (bit 20: pm_prop_shared.h, followed by a refinement-only launch), refinement by the row-per-lane
     kernel (bit 21: pm_refine_rows.h, groups of 8 lanes on column-major packed views), the lanes of
-    a workgroup regrouped by predicted stopping column before refinement (bit 22, opt-in) -- must not
-    change a single bit.
+    a workgroup regrouped by predicted stopping column before refinement (bit 22, opt-in), refinement
+    bounded per wavefront instead of per (candidate, view) item (bit 19: pm::refine_two_phase off) -- must
+    not change a single bit.
     Box 15 (the pipelined and column-per-lane instantiations), 4 iterations so that the default run
     uses both kernels and both task orders."""
     gs, _ = synth.build_problem(synth.tiny_config(cols=160, rows=112, n_src=4, blocksize=15, iterations=4,
@@ -260,7 +262,9 @@ def test_early_termination_is_exact_for_any_bound(hip, theta, cfg):
     os.environ["GIPUMA_HIP_ET_THETA"] = theta
     os.environ["GIPUMA_HIP_ET_FORCE"] = "1"  # (the library bounds evaluations only on frames of >= 1024 tiles)
     try:
-        for tune in (1 << 27, (1 << 27) | (1 << 21)):  # one lane per pixel / row-per-lane refinement kernel
+        # one lane per pixel with the two-phase refinement (default) / bounded per wavefront /
+        # row-per-lane refinement kernel
+        for tune in (1 << 27, (1 << 27) | (1 << 19), (1 << 27) | (1 << 21)):
             os.environ["GIPUMA_HIP_TUNE"] = str(tune)
             a = runcuda(gs)
             assert_same(a[0], o[0], "theta %s tune %d norm4" % (theta, tune))
@@ -269,6 +273,27 @@ def test_early_termination_is_exact_for_any_bound(hip, theta, cfg):
         del os.environ["GIPUMA_HIP_ET_THETA"]
         del os.environ["GIPUMA_HIP_ET_FORCE"]
         os.environ.pop("GIPUMA_HIP_TUNE", None)
+
+
+@pytest.mark.parametrize("g0", [1, 2, 5, 8])
+@pytest.mark.parametrize("theta", ["0.05,0.05,0.05", "1,1,1"])
+def test_two_phase_refinement_is_exact_for_any_split(hip, g0, theta):
+    """pm::refine_two_phase: the first g0 window columns by the pixel's own lane, the rest by
+    whichever lane picks the (candidate, view) item up; open candidates redone item by item (tiny
+    theta: nearly all of them).  Any g0 (8 = the whole window in phase 1), any theta: the oracle's bits."""
+    gs, _ = synth.build_problem(synth.tiny_config(cols=160, rows=112, n_src=7, blocksize=15, iterations=3, n_best=3))
+    o = OracleState(gs).run()
+    os.environ["GIPUMA_HIP_ET_THETA"] = theta
+    os.environ["GIPUMA_HIP_ET_FORCE"] = "2"  # small frame, and every workgroup bounds every step
+    os.environ["GIPUMA_HIP_TP_G0"] = str(g0)
+    os.environ["GIPUMA_HIP_TUNE"] = str(1 << 27)
+    try:
+        a = runcuda(gs)
+    finally:
+        for k in ("GIPUMA_HIP_ET_THETA", "GIPUMA_HIP_ET_FORCE", "GIPUMA_HIP_TP_G0", "GIPUMA_HIP_TUNE"):
+            del os.environ[k]
+    assert_same(a[0], o[0], "g0 %d theta %s norm4" % (g0, theta))
+    assert_same(a[1], o[1], "g0 %d theta %s cost" % (g0, theta))
 
 
 @pytest.mark.parametrize("theta", ["0.05,0.05,0.05", "1,1,1.5"])
