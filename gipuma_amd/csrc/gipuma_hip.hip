@@ -576,9 +576,9 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         if (hp.et_enable && getenv("GIPUMA_HIP_ET_FORCE") && atoi(getenv("GIPUMA_HIP_ET_FORCE")) >= 2) hp.et_enable = 2;
         hp.et_theta[0] = 1.0f;
         hp.et_theta[1] = 1.0f;
-        // the two-phase refinement (gray, compile-time box) redoes open candidates item by item, which
+        // the two-phase refinement (compile-time box) redoes open candidates item by item, which
         // is cheap; the per-wavefront bound repeats the whole wavefront and wants a looser third bound
-        const bool two_phase = s->ch == 1 && s->box > 0 && !(s->tune & (Tune::kNoTwoPhase | Tune::kRegroup));
+        const bool two_phase = s->box > 0 && !(s->tune & (Tune::kNoTwoPhase | Tune::kRegroup));
         hp.et_theta[2] = two_phase ? 1.0f : 1.5f;
         if (const char *g = getenv("GIPUMA_HIP_TP_G0")) hp.tp_g0 = atoi(g);  // experiment: phase-1 columns
         if (const char *t = getenv("GIPUMA_HIP_ET_THETA")) {  // experiment: "t0,t1,t2" (any value is exact)

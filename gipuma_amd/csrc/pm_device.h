@@ -832,8 +832,11 @@ template <int BOX, bool U8, bool FAST, bool ET = false>
 __device__ __forceinline__ float view_cost_c4_loop(const Problem *__restrict__ P, const ViewCam &vc,
                                                    const float *__restrict__ H, const float *__restrict__ tp0,
                                                    int tw, const float *__restrict__ lut, int px, int py,
-                                                   const Win<BOX> &win, float tau = 0.0f)
+                                                   const Win<BOX> &win, float tau = 0.0f, int c0 = 0, int c1 = 1 << 20,
+                                                   float cost0 = 0.0f, int *cols_run = nullptr)
 {
+    // (c0, c1, cost0: window columns [c0, c1) only, continuing from the partial sum cost0 -- see
+    //  view_cost_pipe_range / refine_two_phase)
     const gptr_f32 img = (gptr_f32)vc.img;
     const uint32_t *__restrict__ packed = vc.packed;
     const uint32_t pw = (uint32_t)P->pw;
@@ -844,9 +847,10 @@ __device__ __forceinline__ float view_cost_c4_loop(const Problem *__restrict__ P
     const float tau_color = P->tau_color, tau_gradient = P->tau_gradient, gamma = P->gamma;
     const float4 centre = *reinterpret_cast<const float4 *>(tp0);
     const int hr = win.hrad(), vr = win.vrad();
-    float cost = 0.0f;
-    float qx = (float)(px - hr);
-    for (int i = -hr; i <= hr; i += 2, qx += 2.0f) {
+    float cost = cost0;
+    float qx = (float)(px - hr + 2 * c0);
+    int col = c0;
+    for (int i = -hr + 2 * c0; i <= hr && col < c1; i += 2, qx += 2.0f) {
         const float X0 = __builtin_fmaf(H[0], qx, H[2]);
         const float Y0 = __builtin_fmaf(H[3], qx, H[5]);
         const float Z0 = __builtin_fmaf(H[6], qx, H[8]);
@@ -907,8 +911,10 @@ __device__ __forceinline__ float view_cost_c4_loop(const Problem *__restrict__ P
             const float dis = __builtin_fmaf(alpha, gradDis, oma * colDis);
             cost = __builtin_fmaf(w, dis, cost);
         }
+        col++;
         if (ET && __all(cost >= tau)) break;  // early termination, see multiview_cost
     }
+    if (cols_run) *cols_run += col - c0;
     return cost;
 }
 
@@ -1813,8 +1819,8 @@ __device__ __forceinline__ void regroup_for_refinement(SweepLane &L, const Probl
     __syncthreads();  // bres / btask may be reused
 }
 
-// Two-phase evaluation of one refinement step of a workgroup (performance only; gray packed planes
-// with float-encoded offsets, compile-time box, register combiner).
+// Two-phase evaluation of one refinement step of a workgroup (performance only; packed 8-bit planes
+// -- gray with float-encoded offsets or colour --, compile-time box, register combiner).
 //
 // multiview_cost's bounded evaluation leaves a view when the SLOWEST of 64 lanes has reached its
 // bound; the average lane gets there after a third of the window (scripts/exp/et_stats.py), the
@@ -1837,7 +1843,22 @@ __device__ __forceinline__ void regroup_for_refinement(SweepLane &L, const Probl
 // All lanes of the workgroup must call this (barriers); `seq` counts the groups processed so far
 // in this launch (the two item counters are used alternately: the one not in use is cleared while
 // nobody touches it).
-template <int BOX>
+// (one (candidate, view) item over the window columns [c0, c1); `vc` may differ per lane)
+template <int BOX, int CH, bool FAST>
+__device__ __forceinline__ float tp_item(const Problem *__restrict__ P, const ViewCam &vc, const float *__restrict__ H,
+                                         const float *__restrict__ tp0, int tw, const float *__restrict__ lut, int px,
+                                         int py, int c0, int c1, float a, float tau, int *cols_run)
+{
+    if constexpr (CH == 4) {
+        const Win<BOX> win(P);
+        return view_cost_c4_loop<BOX, true, FAST, true>(P, vc, H, tp0, tw, lut, px, py, win, tau, c0, c1, a, cols_run);
+    } else {
+        const gptr_bytes base = (gptr_bytes)((uintptr_t)vc.packed - (uintptr_t)kMagicBits);
+        return view_cost_pipe_range<BOX, FAST>(P, base, H, tp0, tw, lut, px, py, c0, c1, a, tau, cols_run);
+    }
+}
+
+template <int BOX, int CH>
 __device__ __forceinline__ float refine_two_phase(const Problem *__restrict__ P, const SweepLane &L, float *work,
                                                   const float *__restrict__ lut, int colour, bool valid, float4 cand,
                                                   float thr, int g0, float *kth_out, int &seq, int *cols_run)
@@ -1866,12 +1887,11 @@ __device__ __forceinline__ float refine_two_phase(const Problem *__restrict__ P,
                 float H[9];
                 homography(P->rc.K_inv, P->view[v], cand, H);
                 const bool safe = window_z_safe(H, (float)(L.px - R), (float)(L.px + R), (float)(L.py - R), (float)(L.py + R));
-                const gptr_bytes base = (gptr_bytes)((uintptr_t)P->view[v].packed - (uintptr_t)kMagicBits);
                 const float *tp0 = L.tile + ((L.ly + L.hh) * L.tw + (L.lx + L.hw)) * 4;
                 if (__all(safe))
-                    a = view_cost_pipe_range<BOX, true>(P, base, H, tp0, L.tw, lut, L.px, L.py, 0, g0, 0.0f, my_tau, cols_run);
+                    a = tp_item<BOX, CH, true>(P, P->view[v], H, tp0, L.tw, lut, L.px, L.py, 0, g0, 0.0f, my_tau, cols_run);
                 else
-                    a = view_cost_pipe_range<BOX, false>(P, base, H, tp0, L.tw, lut, L.px, L.py, 0, g0, 0.0f, my_tau, cols_run);
+                    a = tp_item<BOX, CH, false>(P, P->view[v], H, tp0, L.tw, lut, L.px, L.py, 0, g0, 0.0f, my_tau, cols_run);
                 if (cols_run) *cols_run += 1;  // (homography and set-up, as in view_cost_pipe's count)
                 alive = valid && !(a >= thr);
             }
@@ -1906,11 +1926,10 @@ __device__ __forceinline__ float refine_two_phase(const Problem *__restrict__ P,
             float H[9];
             homography(P->rc.K_inv, P->view[v], pl, H);
             const bool safe = window_z_safe(H, (float)(epx - R), (float)(epx + R), (float)(epy - R), (float)(epy + R));
-            const gptr_bytes base = (gptr_bytes)((uintptr_t)P->view[v].packed - (uintptr_t)kMagicBits);
             if (__all(safe))
-                a = view_cost_pipe_range<BOX, true>(P, base, H, tp0, L.tw, lut, epx, epy, g0, N, a, tau_i, cols_run);
+                a = tp_item<BOX, CH, true>(P, P->view[v], H, tp0, L.tw, lut, epx, epy, g0, N, a, tau_i, cols_run);
             else
-                a = view_cost_pipe_range<BOX, false>(P, base, H, tp0, L.tw, lut, epx, epy, g0, N, a, tau_i, cols_run);
+                a = tp_item<BOX, CH, false>(P, P->view[v], H, tp0, L.tw, lut, epx, epy, g0, N, a, tau_i, cols_run);
             if (cols_run) *cols_run += 1;
             if (have) accv[vl * kThreads + t] = a;
         }
@@ -1941,7 +1960,7 @@ __global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kerne
     const bool et_on = ET && P->et_enable && !(tune & Tune::kNoEarlyExit);
     if (et_on && blockIdx.x == 0 && threadIdx.x < 6) P->et_stat[((phase + 1u) % 3u) * 6u + threadIdx.x] = 0u;
     int tp_seq = 0;  // refine_two_phase: groups of views processed so far
-    if constexpr (ET && CH == 1 && BOX > 0)
+    if constexpr (ET && BOX > 0)
         if (threadIdx.x < 2) reinterpret_cast<int *>(L.bres + TpLayout::cnt)[threadIdx.x] = 0;  // (barriers follow)
 
     // One loop, one call site of the cost function: rounds [0, prop_rounds) evaluate compacted
@@ -1954,7 +1973,7 @@ __global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kerne
             if constexpr (ET && CH == 1 && BOX > 0)
                 if (et_on && R.nref > 0 && (tune & Tune::kRegroup)) regroup_for_refinement<BOX>(L, P, lds, colour);
             refine_begin(R, L, P, phase);
-            if constexpr (ET && CH == 1 && BOX > 0)
+            if constexpr (ET && BOX > 0)
                 if (et_on) __syncthreads();  // refine_two_phase reuses the candidate costs the replay has just read
         }
         if (r == prop_rounds + R.nref) break;
@@ -1983,7 +2002,7 @@ __global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kerne
             if (do_eval) cand = refine_candidate(R, L, P, d_new);
             refine_next_step(R);
         }
-        if constexpr (ET && CH == 1 && BOX > 0) {
+        if constexpr (ET && BOX > 0) {
             // the first three refinement steps by items instead of wavefronts (refine_two_phase), where
             // the previous half-sweep's probe workgroups found that bounding the step pays
             if (et_on && r >= prop_rounds && r - prop_rounds < 3 && !(tune & (Tune::kNoTwoPhase | Tune::kRegroup))) {
@@ -2001,7 +2020,7 @@ __global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kerne
                     float c = 0.0f;
                     for (int pass = 0; pass < 2; pass++) {
                         float kth;
-                        const float cc = refine_two_phase<BOX>(P, L, L.bres, lds, colour, need, cand, thr, g0, &kth, tp_seq,
+                        const float cc = refine_two_phase<BOX, CH>(P, L, L.bres, lds, colour, need, cand, thr, g0, &kth, tp_seq,
                                                                probe ? &cols_run : nullptr);
                         const bool open = need && kth >= thr && cc < L.cst;
                         if (need && !open) c = cc;

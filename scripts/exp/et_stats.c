@@ -175,6 +175,10 @@ typedef struct {
      * that run to their slowest item's stop (theta 1.0, thr only); [step][G0-1][half/all] */
     double cols_two_phase[4][4][2];
     double items_alive[4][4]; /* surviving items after G0 columns / all items */
+    /* propagation tasks bounded item-wise against the pixel's cost at the start of the half-sweep:
+     * [0] thr only, open tasks (F' < B0 with a truncated view) completed in full; [1] the same with
+     * min(k-th smallest, thr) (sequential views); [2] fraction of tasks left open under [0]; [3] under [1] */
+    double prop_item[4];
 } launch_stats;
 
 static int ratio_bin(float F, float B)
@@ -358,6 +362,16 @@ int et_stats_run(const gipuma_hip_desc *d, int x0, int y0, int x1, int y1, int n
                                 if (nprop < 2048) memcpy(pstop[p][nprop], stop, (size_t)nv);
                             }
                             if (nprop < 2048) nprop++;
+                            for (int q = 0; q < 2; q++) {
+                                g_use_kth = q;
+                                const int dec = policy_run(&te, order_fixed, m, B0, THETA1 / (float)m, stop, &amb);
+                                g_use_kth = 1;
+                                (void)dec;
+                                int s2 = 0;
+                                for (int v = 0; v < nv; v++) s2 += stop[v];
+                                loc.prop_item[q] += amb ? (double)te.nv * te.nc : (double)s2;
+                                loc.prop_item[2 + q] += amb;
+                            }
                             /* sharing bookkeeping */
                             {
                                 const int dist = k < 4 ? 1 : 5;

@@ -35,7 +35,7 @@ names = [("prop_tasks", 1), ("ref_tasks", 4), ("cols_full_prop", 1), ("cols_full
          ("cols_lane_prop", 4), ("cols_lane_ref", 16), ("cols_wave_ref", 16), ("cols_wave_prop", 4),
          ("ambiguous_prop", 4), ("ambiguous_ref", 16), ("wrong", 4),
          ("jobs", 1), ("job_union_cols", 1), ("job_target_cols", 1), ("job_hist", 5),
-         ("accepted_prop", 1), ("accepted_ref", 4), ("ratio_hist_ref", 32), ("ratio_hist_prop", 8), ("plane_groups", 1), ("plane_union_samples", 1), ("plane_task_samples", 1), ("plane_bbox_samples", 1), ("plane_maxgroup", 1), ("cols_w8_ref", 16), ("seen4", 1), ("seen8", 1), ("seen32", 1), ("cols_sorted_ref", 16), ("cols_pool_ref", 48), ("cols_wave_nr", 16), ("cols_two_phase", 32), ("items_alive", 16)]
+         ("accepted_prop", 1), ("accepted_ref", 4), ("ratio_hist_ref", 32), ("ratio_hist_prop", 8), ("plane_groups", 1), ("plane_union_samples", 1), ("plane_task_samples", 1), ("plane_bbox_samples", 1), ("plane_maxgroup", 1), ("cols_w8_ref", 16), ("seen4", 1), ("seen8", 1), ("seen32", 1), ("cols_sorted_ref", 16), ("cols_pool_ref", 48), ("cols_wave_nr", 16), ("cols_two_phase", 32), ("items_alive", 16), ("prop_item", 4)]
 off = {}
 o = 0
 for n, k in names:
@@ -90,6 +90,8 @@ for li in range(nl):
     cp_ = f(r, "cols_pool_ref").reshape(4, 4, 3)
     for p in range(4):
         print("    %-13s workgroup pool, compaction every 1/2/4 columns: ref %s" % (pol[p], " | ".join(str(np.round(cp_[p][:4, g] / np.maximum(cfr[:4], 1), 3)) for g in range(3))))
+    pi_ = f(r, "prop_item")
+    print("    propagation bounded item-wise vs the cost at the start (open tasks in full): thr only %.3f (open %.3f), with k-th rule %.3f (open %.3f)" % (pi_[0] / max(cfp, 1), pi_[2] / max(pt, 1), pi_[1] / max(cfp, 1), pi_[3] / max(pt, 1)))
     print("    seen-before fraction of needed prop tasks: K=4 %.3f  K=8 %.3f  K=32 %.3f" %
           (f(r, "seen4")[0] / max(pt, 1), f(r, "seen8")[0] / max(pt, 1), f(r, "seen32")[0] / max(pt, 1)))
     jobs = f(r, "jobs")[0]

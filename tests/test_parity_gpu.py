@@ -297,18 +297,22 @@ def test_two_phase_refinement_is_exact_for_any_split(hip, g0, theta):
 
 
 @pytest.mark.parametrize("theta", ["0.05,0.05,0.05", "1,1,1.5"])
-def test_early_termination_colour(hip, theta):
-    """the same cut-off in the colour kernels (T = float4): exact for any bound"""
-    gs, _ = synth.build_problem(synth.tiny_config(cols=96, rows=80, n_src=4, blocksize=15, iterations=3, n_best=3),
+@pytest.mark.parametrize("tune", [0, 1 << 19])
+def test_early_termination_colour(hip, theta, tune):
+    """the same cut-offs in the colour kernels (T = float4) -- two-phase by (candidate, view) items,
+    or per wavefront (bit 19) --: exact for any bound"""
+    gs, _ = synth.build_problem(synth.tiny_config(cols=96, rows=80, n_src=6, blocksize=15, iterations=3, n_best=3),
                                 colour=True)
     o = OracleState(gs).run()
     os.environ["GIPUMA_HIP_ET_THETA"] = theta
-    os.environ["GIPUMA_HIP_ET_FORCE"] = "1"
+    os.environ["GIPUMA_HIP_ET_FORCE"] = "2"
+    os.environ["GIPUMA_HIP_TUNE"] = str(tune)
     try:
         a = runcuda(gs)
     finally:
         del os.environ["GIPUMA_HIP_ET_THETA"]
         del os.environ["GIPUMA_HIP_ET_FORCE"]
+        del os.environ["GIPUMA_HIP_TUNE"]
     assert_same(a[0], o[0], "colour theta %s norm4" % theta)
     assert_same(a[1], o[1], "colour theta %s cost" % theta)
 
