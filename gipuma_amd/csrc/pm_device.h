@@ -1943,7 +1943,7 @@ __device__ __forceinline__ float refine_two_phase(const Problem *__restrict__ P,
 
 // (the packed-gray instantiations are held at 128 VGPRs = 4 wavefronts per SIMD)
 template <int BOX, bool U8, bool COMBINE_REG, bool INTERIOR, int CH>
-__global__ __launch_bounds__(kThreads, (U8 && CH == 1) ? 4 : 1) void sweep_kernel(const Problem *__restrict__ P,
+__global__ __launch_bounds__(kThreads, U8 ? 4 : 1) void sweep_kernel(const Problem *__restrict__ P,
                                                          float4 *__restrict__ norm4, float *__restrict__ cost,
                                                          int colour, uint32_t phase, unsigned stages,
                                                          unsigned tune)
