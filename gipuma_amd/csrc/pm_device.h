@@ -2009,8 +2009,11 @@ __global__ __launch_bounds__(kThreads, U8 ? 4 : 1) void sweep_kernel(const Probl
                 const int step = r - prop_rounds;
                 const bool probe = (blockIdx.x & 15u) == 0u;
                 const unsigned *seen = P->et_stat + ((phase + 2u) % 3u) * 6u + 2 * step;
+                // (no measurement yet -- the previous half-sweep ran the column-per-lane kernel --: assume
+                //  it pays from the fifth half-sweep on)
                 const bool pays = P->et_enable > 1 ||  // (tests: every workgroup bounds every step)
-                                  (seen[0] > 0u && (unsigned long long)seen[1] * 100ull <= (unsigned long long)seen[0] * 85ull);
+                                  (seen[0] > 0u ? (unsigned long long)seen[1] * 100ull <= (unsigned long long)seen[0] * 85ull
+                                                : phase >= 5u);
                 if (probe || pays) {  // (uniform over the workgroup)
                     constexpr int Nc = (BOX + 1) / 2;
                     int g0 = P->tp_g0 > 0 ? min(P->tp_g0, Nc) : (3 * Nc + 4) / 8;
