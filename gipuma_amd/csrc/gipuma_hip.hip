@@ -504,8 +504,8 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         CREATE_OK(hipMalloc(&s->et_hint, s->et_hint_bytes));
         CREATE_OK(hipMemsetAsync(s->et_hint, 0, s->et_hint_bytes, s->stream));
         hp.et_hint = s->et_hint;
-        CREATE_OK(hipMalloc(&s->et_stat, 18 * sizeof(unsigned)));
-        CREATE_OK(hipMemsetAsync(s->et_stat, 0, 18 * sizeof(unsigned), s->stream));
+        CREATE_OK(hipMalloc(&s->et_stat, 3 * pm::kEtSlot * sizeof(unsigned)));
+        CREATE_OK(hipMemsetAsync(s->et_stat, 0, 3 * pm::kEtSlot * sizeof(unsigned), s->stream));
         hp.et_stat = s->et_stat;
     }
     CREATE_OK(hipMalloc(&s->changed, np));
@@ -651,7 +651,7 @@ int gipuma_hip_init_planes(gipuma_hip_session *s)
     HIP_OK(hipSetDevice(s->device));
     // (a fresh solve starts with fresh hints, so that repeated solves of a session do the same work)
     HIP_OK(hipMemsetAsync(s->et_hint, 0, s->et_hint_bytes, s->stream));
-    HIP_OK(hipMemsetAsync(s->et_stat, 0, 18 * sizeof(unsigned), s->stream));
+    HIP_OK(hipMemsetAsync(s->et_stat, 0, 3 * pm::kEtSlot * sizeof(unsigned), s->stream));
     const int rc = launch_dense(s, true, s->norm4, s->cost);
     if (!rc) s->costs_trusted = true;
     s->finalized = false;

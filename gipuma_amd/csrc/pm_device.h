@@ -56,7 +56,7 @@ struct Problem {  // lives in device memory, read through scalar loads (wave-uni
     // bound incl. redos]: what the probe workgroups (every 16th) measured; the other workgroups
     // bound a step only if that paid for the previous half-sweep's probes.  Half-sweep k (= phase)
     // writes slot k % 3, reads slot (k-1) % 3 and clears slot (k+1) % 3.
-    unsigned *et_stat;
+    unsigned *et_stat;  // kEtSlot words per slot, see the kernel
     int tp_g0;  // window columns of phase 1 of refine_two_phase (0: default, 3/8 of the window)
 #ifdef PM_PS_PROFILE
     unsigned long long *prof;  // experiment builds only
@@ -231,6 +231,10 @@ constexpr int kTaskScratchFloats = 8 * kThreads + (8 * kThreads) / 2 + 32 + 128;
 // ... reused by the two-phase refinement (refine_two_phase): partial view costs of a group of
 // kTpViews views, the candidates, their bounds, the list of surviving (task, view) items, counters
 constexpr int kTpViews = 5;
+// Problem::et_stat: per rotating slot, [4 * step + {0: columns of full evaluations, 1: columns evaluated,
+// 2: items left after phase 1, 3: items}] for the three bounded steps, then [12 + step] = the phase-1
+// length the probes used
+constexpr unsigned kEtSlot = 16;
 struct TpLayout {  // offsets in floats into the scratch region
     static constexpr int acc = 0;                             // [kTpViews][256] partial / final view costs
     static constexpr int plane = acc + kTpViews * kThreads;   // [256] float4 candidate planes
@@ -1861,7 +1865,8 @@ __device__ __forceinline__ float tp_item(const Problem *__restrict__ P, const Vi
 template <int BOX, int CH>
 __device__ __forceinline__ float refine_two_phase(const Problem *__restrict__ P, const SweepLane &L, float *work,
                                                   const float *__restrict__ lut, int colour, bool valid, float4 cand,
-                                                  float thr, int g0, float *kth_out, int &seq, int *cols_run)
+                                                  float thr, int g0, float *kth_out, int &seq, int *cols_run,
+                                                  int *items_left = nullptr)
 {
     constexpr int R = (BOX - 1) / 2, N = R + 1;
     float *accv = work + TpLayout::acc;
@@ -1908,6 +1913,7 @@ __device__ __forceinline__ float refine_two_phase(const Problem *__restrict__ P,
         __syncthreads();
         const int n_items = *ctr;
         if (tid == 0) cnt[(seq + 1) & 1] = 0;
+        if (items_left) *items_left += n_items;  // (the same number in every lane)
         // ---- phase 2 ----
         for (int first = 0; first < n_items; first += kThreads) {
             const int wave_first = first + (tid & ~63);
@@ -1958,7 +1964,7 @@ __global__ __launch_bounds__(kThreads, U8 ? 4 : 1) void sweep_kernel(const Probl
     refine_init(R, P, stages);
     constexpr bool ET = U8 && COMBINE_REG && INTERIOR && (CH == 4 || BOX > 0);
     const bool et_on = ET && P->et_enable && !(tune & Tune::kNoEarlyExit);
-    if (et_on && blockIdx.x == 0 && threadIdx.x < 6) P->et_stat[((phase + 1u) % 3u) * 6u + threadIdx.x] = 0u;
+    if (et_on && blockIdx.x == 0 && threadIdx.x < kEtSlot) P->et_stat[((phase + 1u) % 3u) * kEtSlot + threadIdx.x] = 0u;
     int tp_seq = 0;  // refine_two_phase: groups of views processed so far
     if constexpr (ET && BOX > 0)
         if (threadIdx.x < 2) reinterpret_cast<int *>(L.bres + TpLayout::cnt)[threadIdx.x] = 0;  // (barriers follow)
@@ -2008,7 +2014,7 @@ __global__ __launch_bounds__(kThreads, U8 ? 4 : 1) void sweep_kernel(const Probl
             if (et_on && r >= prop_rounds && r - prop_rounds < 3 && !(tune & (Tune::kNoTwoPhase | Tune::kRegroup))) {
                 const int step = r - prop_rounds;
                 const bool probe = (blockIdx.x & 15u) == 0u;
-                const unsigned *seen = P->et_stat + ((phase + 2u) % 3u) * 6u + 2 * step;
+                const unsigned *seen = P->et_stat + ((phase + 2u) % 3u) * kEtSlot + 4 * step;
                 // (no measurement yet -- the previous half-sweep ran the column-per-lane kernel --: assume
                 //  it pays from the fifth half-sweep on)
                 const bool pays = P->et_enable > 1 ||  // (tests: every workgroup bounds every step)
@@ -2016,7 +2022,19 @@ __global__ __launch_bounds__(kThreads, U8 ? 4 : 1) void sweep_kernel(const Probl
                                                 : phase >= 5u);
                 if (probe || pays) {  // (uniform over the workgroup)
                     constexpr int Nc = (BOX + 1) / 2;
-                    int g0 = P->tp_g0 > 0 ? min(P->tp_g0, Nc) : (3 * Nc + 4) / 8;
+                    // phase-1 length: 3/8 of the window, then one column more / less than the previous
+                    // half-sweep's probes used if more than 40 % / fewer than 10 % of their items survived it
+                    int g0 = (3 * Nc + 4) / 8;
+                    if (P->tp_g0 > 0) {
+                        g0 = min(P->tp_g0, Nc);
+                    } else if (seen[3] > 0u) {
+                        g0 = (int)P->et_stat[((phase + 2u) % 3u) * kEtSlot + 12 + step];
+                        if ((unsigned long long)seen[2] * 100ull > (unsigned long long)seen[3] * 40ull) g0++;
+                        if ((unsigned long long)seen[2] * 100ull < (unsigned long long)seen[3] * 10ull) g0--;
+                        g0 = max(2, min(g0, (Nc + 1) / 2 + 1));
+                    }
+                    const int g0_used = g0;
+                    int items_left = 0;
                     float thr = P->et_theta[step] * L.cst;
                     bool need = do_eval;
                     int cols_run = 0;
@@ -2024,7 +2042,7 @@ __global__ __launch_bounds__(kThreads, U8 ? 4 : 1) void sweep_kernel(const Probl
                     for (int pass = 0; pass < 2; pass++) {
                         float kth;
                         const float cc = refine_two_phase<BOX, CH>(P, L, L.bres, lds, colour, need, cand, thr, g0, &kth, tp_seq,
-                                                               probe ? &cols_run : nullptr);
+                                                               probe ? &cols_run : nullptr, pass == 0 ? &items_left : nullptr);
                         const bool open = need && kth >= thr && cc < L.cst;
                         if (need && !open) c = cc;
                         need = open;
@@ -2032,10 +2050,18 @@ __global__ __launch_bounds__(kThreads, U8 ? 4 : 1) void sweep_kernel(const Probl
                         g0 = 0;
                         if (!__syncthreads_or(need)) break;
                     }
-                    if (probe && (threadIdx.x & 63u) == 0u) {
-                        unsigned *mine = P->et_stat + (phase % 3u) * 6u + 2 * step;
-                        atomicAdd(&mine[0], (unsigned)(P->n_sel * (Nc + 1)));
-                        atomicAdd(&mine[1], (unsigned)cols_run);
+                    if (probe) {
+                        const unsigned n_cand = (unsigned)__popcll(__ballot(do_eval));
+                        if ((threadIdx.x & 63u) == 0u) {
+                            unsigned *mine = P->et_stat + (phase % 3u) * kEtSlot + 4 * step;
+                            atomicAdd(&mine[0], (unsigned)(P->n_sel * (Nc + 1)));
+                            atomicAdd(&mine[1], (unsigned)cols_run);
+                            atomicAdd(&mine[3], n_cand * (unsigned)P->n_sel);
+                            if (threadIdx.x == 0) {
+                                atomicAdd(&mine[2], (unsigned)items_left);
+                                P->et_stat[(phase % 3u) * kEtSlot + 12 + step] = (unsigned)g0_used;
+                            }
+                        }
                     }
                     if (do_eval && c < L.cst) {  // refinement has no depth-range test, :986
                         L.depth = d_new;
@@ -2065,7 +2091,7 @@ __global__ __launch_bounds__(kThreads, U8 ? 4 : 1) void sweep_kernel(const Probl
                 //  six -- are perturbations so small that the candidate usually ties with the plane)
                 if (et_on && r >= prop_rounds && r - prop_rounds < 3) {
                     step = r - prop_rounds;
-                    const unsigned *seen = P->et_stat + ((phase + 2u) % 3u) * 6u + 2 * step;
+                    const unsigned *seen = P->et_stat + ((phase + 2u) % 3u) * kEtSlot + 4 * step;
                     const bool pays = P->et_enable > 1 ||  // (tests: every workgroup bounds every step)
                                   (seen[0] > 0u && (unsigned long long)seen[1] * 100ull <= (unsigned long long)seen[0] * 85ull);
                     if (probe) {
@@ -2096,7 +2122,7 @@ __global__ __launch_bounds__(kThreads, U8 ? 4 : 1) void sweep_kernel(const Probl
                     redone = true;
                 }
                 if (probe && step >= 0 && (threadIdx.x & 63u) == 0u) {
-                    unsigned *mine = P->et_stat + (phase % 3u) * 6u + 2 * step;
+                    unsigned *mine = P->et_stat + (phase % 3u) * kEtSlot + 4 * step;
                     atomicAdd(&mine[0], (unsigned)(P->n_sel * ((BOX + 1) / 2 + 1)));
                     atomicAdd(&mine[1], (unsigned)cols_done);
                 }

@@ -275,6 +275,20 @@ def test_early_termination_is_exact_for_any_bound(hip, theta, cfg):
         os.environ.pop("GIPUMA_HIP_TUNE", None)
 
 
+def test_two_phase_refinement_ragged_frame_many_views(hip):
+    """the same on a frame that is not a multiple of the 32x16 tile (border tiles take the unbounded
+    path, interior ones the item lists) with 12 source views (item groups of 5 + 5 + 2) and best-2"""
+    gs, _ = synth.build_problem(synth.tiny_config(cols=150, rows=100, n_src=12, blocksize=15, iterations=2, n_best=2))
+    o = OracleState(gs).run()
+    os.environ["GIPUMA_HIP_ET_FORCE"] = "2"
+    try:
+        a = runcuda(gs)
+    finally:
+        del os.environ["GIPUMA_HIP_ET_FORCE"]
+    assert_same(a[0], o[0], "ragged norm4")
+    assert_same(a[1], o[1], "ragged cost")
+
+
 @pytest.mark.parametrize("g0", [1, 2, 5, 8])
 @pytest.mark.parametrize("theta", ["0.05,0.05,0.05", "1,1,1"])
 def test_two_phase_refinement_is_exact_for_any_split(hip, g0, theta):
