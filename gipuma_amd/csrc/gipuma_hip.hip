@@ -70,6 +70,7 @@ struct gipuma_hip_session {
     std::vector<uint32_t *> packed_t;  // ... and their column-major variants (row-per-lane refinement)
     bool rows_kernel = false;  // pm::sweep_rows_kernel usable
     int rows_from = 0;         // first half-sweep (2*iteration + colour) that uses it
+    bool shared_fused = false;  // ... with the refinement stage in the same launch (experiment)
     int shared_from = 0;       // first half-sweep that uses the shared-sample propagation kernel (when enabled)
     size_t lds_rows = 0;
     int *flag = nullptr;
@@ -237,7 +238,7 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
                            2 * iteration + colour >= s->shared_from &&
                            !(tune & (Tune::kNoSkip | Tune::kNoInterior));
     if (shared_ok) {
-        typedef void (*prop_fn)(const pm::Problem *, float4 *, float *, int, unsigned, unsigned);
+        typedef void (*prop_fn)(const pm::Problem *, float4 *, float *, int, unsigned, unsigned, uint32_t);
         const prop_fn pk = s->box == 15 ? pm::prop_shared_kernel<15> : pm::prop_shared_kernel<11>;
         const size_t plds = sizeof(float) * (size_t)(s->box == 15 ? pm::PsLayout<15>::total : pm::PsLayout<11>::total);
         if (!s->prop_attr_set) {
@@ -245,10 +246,12 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
                                        (int)plds));
             s->prop_attr_set = true;
         }
+        // (GIPUMA_HIP_SHARED_FUSED: the refinement stage in the same launch)
+        const bool fused = s->shared_fused && (stages & 4u);
         hipLaunchKernelGGL(pk, dim3(gx * gy), dim3(pm::kThreads), plds, s->stream, s->dp, s->norm4, s->cost, colour,
-                           stages & 3u, tune);
+                           fused ? stages : (stages & 3u), tune, phase);
         HIP_OK(hipGetLastError());
-        if (!(stages & 4u)) return 0;
+        if (fused || !(stages & 4u)) return 0;
         stages = 4u;
         tune |= Tune::kAccumChanged;
     }
@@ -537,6 +540,7 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
                      (size_t)(d->cols + 3) * (size_t)hp.ph <= (size_t)pm::kMagicMaxWords;
     if (const char *t = getenv("GIPUMA_HIP_ROWS_FROM")) s->rows_from = atoi(t);  // experiment
     if (const char *t = getenv("GIPUMA_HIP_SHARED_FROM")) s->shared_from = atoi(t);  // experiment
+    if (const char *t = getenv("GIPUMA_HIP_SHARED_FUSED")) s->shared_fused = atoi(t) != 0;
     if (s->rows_kernel) {
         const size_t words = (size_t)(d->cols + 3) * (size_t)hp.ph;
         const dim3 pgid((hp.ph + pm::kThreads - 1) / pm::kThreads, d->cols + 3);

@@ -1947,6 +1947,75 @@ __device__ __forceinline__ float refine_two_phase(const Problem *__restrict__ P,
     return comb.finish(P, n, nullptr);
 }
 
+// One of the first three refinement steps of a workgroup by (candidate, view) items
+// (refine_two_phase), where the previous half-sweep's probe workgroups (every 16th) found that
+// bounding the step pays; returns false -- nothing done -- where it does not.  All lanes of the
+// workgroup must call it (the decision is uniform over the workgroup); `cand` / `d_new`: the lane's
+// candidate (refine_candidate) where do_eval.
+template <int BOX, int CH>
+__device__ __forceinline__ bool refine_step_items(const Problem *__restrict__ P, SweepLane &L, const float *lds,
+                                                  int colour, uint32_t phase, int step, bool do_eval, float4 cand,
+                                                  float d_new, int &tp_seq)
+{
+    const bool probe = (blockIdx.x & 15u) == 0u;
+    const unsigned *seen = P->et_stat + ((phase + 2u) % 3u) * kEtSlot + 4 * step;
+    // (no measurement yet -- the previous half-sweep ran the column-per-lane kernel --: assume
+    //  it pays from the fifth half-sweep on)
+    const bool pays = P->et_enable > 1 ||  // (tests: every workgroup bounds every step)
+                      (seen[0] > 0u ? (unsigned long long)seen[1] * 100ull <= (unsigned long long)seen[0] * 85ull
+                                    : phase >= 5u);
+    if (!(probe || pays)) return false;  // (uniform over the workgroup)
+    constexpr int Nc = (BOX + 1) / 2;
+    // phase-1 length: 3/8 of the window, then one column more / less than the previous
+    // half-sweep's probes used if more than 40 % / fewer than 10 % of their items survived it
+    int g0 = (3 * Nc + 4) / 8;
+    if (P->tp_g0 > 0) {
+        g0 = min(P->tp_g0, Nc);
+    } else if (seen[3] > 0u) {
+        g0 = (int)P->et_stat[((phase + 2u) % 3u) * kEtSlot + 12 + step];
+        if ((unsigned long long)seen[2] * 100ull > (unsigned long long)seen[3] * 40ull) g0++;
+        if ((unsigned long long)seen[2] * 100ull < (unsigned long long)seen[3] * 10ull) g0--;
+        g0 = max(2, min(g0, (Nc + 1) / 2 + 1));
+    }
+    const int g0_used = g0;
+    int items_left = 0;
+    float thr = P->et_theta[step] * L.cst;
+    bool need = do_eval;
+    int cols_run = 0;
+    float c = 0.0f;
+    for (int pass = 0; pass < 2; pass++) {
+        float kth;
+        const float cc = refine_two_phase<BOX, CH>(P, L, L.bres, lds, colour, need, cand, thr, g0, &kth, tp_seq,
+                                                   probe ? &cols_run : nullptr, pass == 0 ? &items_left : nullptr);
+        const bool open = need && kth >= thr && cc < L.cst;
+        if (need && !open) c = cc;
+        need = open;
+        thr = __builtin_inff();
+        g0 = 0;
+        if (!__syncthreads_or(need)) break;
+    }
+    if (probe) {
+        const unsigned n_cand = (unsigned)__popcll(__ballot(do_eval));
+        if ((threadIdx.x & 63u) == 0u) {
+            unsigned *mine = P->et_stat + (phase % 3u) * kEtSlot + 4 * step;
+            atomicAdd(&mine[0], (unsigned)(P->n_sel * (Nc + 1)));
+            atomicAdd(&mine[1], (unsigned)cols_run);
+            atomicAdd(&mine[3], n_cand * (unsigned)P->n_sel);
+            if (threadIdx.x == 0) {
+                atomicAdd(&mine[2], (unsigned)items_left);
+                P->et_stat[(phase % 3u) * kEtSlot + 12 + step] = (unsigned)g0_used;
+            }
+        }
+    }
+    if (do_eval && c < L.cst) {  // refinement has no depth-range test, :986
+        L.depth = d_new;
+        L.pl = cand;
+        L.cst = c;
+        L.chg = 1;
+    }
+    return true;
+}
+
 // (the packed-gray instantiations are held at 128 VGPRs = 4 wavefronts per SIMD)
 template <int BOX, bool U8, bool COMBINE_REG, bool INTERIOR, int CH>
 __global__ __launch_bounds__(kThreads, U8 ? 4 : 1) void sweep_kernel(const Problem *__restrict__ P,
@@ -2009,69 +2078,9 @@ __global__ __launch_bounds__(kThreads, U8 ? 4 : 1) void sweep_kernel(const Probl
             refine_next_step(R);
         }
         if constexpr (ET && BOX > 0) {
-            // the first three refinement steps by items instead of wavefronts (refine_two_phase), where
-            // the previous half-sweep's probe workgroups found that bounding the step pays
-            if (et_on && r >= prop_rounds && r - prop_rounds < 3 && !(tune & (Tune::kNoTwoPhase | Tune::kRegroup))) {
-                const int step = r - prop_rounds;
-                const bool probe = (blockIdx.x & 15u) == 0u;
-                const unsigned *seen = P->et_stat + ((phase + 2u) % 3u) * kEtSlot + 4 * step;
-                // (no measurement yet -- the previous half-sweep ran the column-per-lane kernel --: assume
-                //  it pays from the fifth half-sweep on)
-                const bool pays = P->et_enable > 1 ||  // (tests: every workgroup bounds every step)
-                                  (seen[0] > 0u ? (unsigned long long)seen[1] * 100ull <= (unsigned long long)seen[0] * 85ull
-                                                : phase >= 5u);
-                if (probe || pays) {  // (uniform over the workgroup)
-                    constexpr int Nc = (BOX + 1) / 2;
-                    // phase-1 length: 3/8 of the window, then one column more / less than the previous
-                    // half-sweep's probes used if more than 40 % / fewer than 10 % of their items survived it
-                    int g0 = (3 * Nc + 4) / 8;
-                    if (P->tp_g0 > 0) {
-                        g0 = min(P->tp_g0, Nc);
-                    } else if (seen[3] > 0u) {
-                        g0 = (int)P->et_stat[((phase + 2u) % 3u) * kEtSlot + 12 + step];
-                        if ((unsigned long long)seen[2] * 100ull > (unsigned long long)seen[3] * 40ull) g0++;
-                        if ((unsigned long long)seen[2] * 100ull < (unsigned long long)seen[3] * 10ull) g0--;
-                        g0 = max(2, min(g0, (Nc + 1) / 2 + 1));
-                    }
-                    const int g0_used = g0;
-                    int items_left = 0;
-                    float thr = P->et_theta[step] * L.cst;
-                    bool need = do_eval;
-                    int cols_run = 0;
-                    float c = 0.0f;
-                    for (int pass = 0; pass < 2; pass++) {
-                        float kth;
-                        const float cc = refine_two_phase<BOX, CH>(P, L, L.bres, lds, colour, need, cand, thr, g0, &kth, tp_seq,
-                                                               probe ? &cols_run : nullptr, pass == 0 ? &items_left : nullptr);
-                        const bool open = need && kth >= thr && cc < L.cst;
-                        if (need && !open) c = cc;
-                        need = open;
-                        thr = __builtin_inff();
-                        g0 = 0;
-                        if (!__syncthreads_or(need)) break;
-                    }
-                    if (probe) {
-                        const unsigned n_cand = (unsigned)__popcll(__ballot(do_eval));
-                        if ((threadIdx.x & 63u) == 0u) {
-                            unsigned *mine = P->et_stat + (phase % 3u) * kEtSlot + 4 * step;
-                            atomicAdd(&mine[0], (unsigned)(P->n_sel * (Nc + 1)));
-                            atomicAdd(&mine[1], (unsigned)cols_run);
-                            atomicAdd(&mine[3], n_cand * (unsigned)P->n_sel);
-                            if (threadIdx.x == 0) {
-                                atomicAdd(&mine[2], (unsigned)items_left);
-                                P->et_stat[(phase % 3u) * kEtSlot + 12 + step] = (unsigned)g0_used;
-                            }
-                        }
-                    }
-                    if (do_eval && c < L.cst) {  // refinement has no depth-range test, :986
-                        L.depth = d_new;
-                        L.pl = cand;
-                        L.cst = c;
-                        L.chg = 1;
-                    }
-                    continue;
-                }
-            }
+            if (et_on && r >= prop_rounds && r - prop_rounds < 3 && !(tune & (Tune::kNoTwoPhase | Tune::kRegroup)) &&
+                refine_step_items<BOX, CH>(P, L, lds, colour, phase, r - prop_rounds, do_eval, cand, d_new, tp_seq))
+                continue;
         }
         if (do_eval) {
             const float *etp0 = L.tile + (((epy - L.y0) + L.hh) * L.tw + ((epx - L.x0) + L.hw)) * 4;

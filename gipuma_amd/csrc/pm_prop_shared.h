@@ -71,6 +71,7 @@ struct PsLayout {  // offsets in 32-bit words into the dynamic LDS array
     static_assert(D >= kPsHash && D >= ((maxpts + 63) & ~63) && D <= 32 * 4 * 64, "sample buffer");
     static_assert(tw * th <= 8 * kThreads + 1024, "staging plane of stage_tile must end before live data");
     static_assert(D < 8192 && maxpts < 512, "record packing");
+    static_assert(total - bres >= TpLayout::total, "the refinement stage reuses the space from bres on");
 };
 
 struct PsReq {  // one sample point in flight
@@ -132,7 +133,7 @@ template <int BOX>
 __global__ __launch_bounds__(kThreads, 2) void prop_shared_kernel(const Problem *__restrict__ P,
                                                                   float4 *__restrict__ norm4,
                                                                   float *__restrict__ cost, int colour,
-                                                                  unsigned stages, unsigned tune)
+                                                                  unsigned stages, unsigned tune, uint32_t phase)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using LY = PsLayout<BOX>;
@@ -528,6 +529,39 @@ __global__ __launch_bounds__(kThreads, 2) void prop_shared_kernel(const Problem 
     // ---- 4. accepts in the reference order, write back (gipuma.cu:1585-1587) ----
     PS_T(10);
     sweep_replay(L, P, norm4);
+    // ---- 5. refinement in the same launch (stages & 4): the steps of pm::sweep_kernel, by (candidate,
+    //         view) items where that pays (refine_step_items), else unbounded ----
+    if (stages & 4u) {
+        RefineDraws Rd;
+        refine_init(Rd, P, stages);
+        const bool et_on = P->et_enable && !(tune & Tune::kNoEarlyExit);
+        if (et_on && blockIdx.x == 0 && tid < (int)kEtSlot) P->et_stat[((phase + 1u) % 3u) * kEtSlot + tid] = 0u;
+        refine_begin(Rd, L, P, phase);
+        if (tid < 2) reinterpret_cast<int *>(L.bres + TpLayout::cnt)[tid] = 0;
+        __syncthreads();  // the replay has read its candidate costs; refine_two_phase reuses that space
+        int tp_seq = 0;
+        const Win<BOX> win(P);
+        for (int step = 0; step < Rd.nref; step++) {
+            float d_new = 0.f;
+            float4 cand = make_float4(0.f, 0.f, -1.f, 1.f);
+            const bool do_eval = L.active;
+            if (do_eval) cand = refine_candidate(Rd, L, P, d_new);
+            refine_next_step(Rd);
+            if (et_on && step < 3 && !(tune & Tune::kNoTwoPhase) &&
+                refine_step_items<BOX, 1>(P, L, lds, colour, phase, step, do_eval, cand, d_new, tp_seq))
+                continue;
+            if (do_eval) {
+                const float *tp0 = L.tile + ((L.ly + L.hh) * L.tw + (L.lx + L.hw)) * 4;
+                const float c = multiview_cost<BOX, true, true, true, 1>(P, tp0, L.tw, lds, L.cv, L.px, L.py, cand, win);
+                if (c < L.cst) {  // refinement has no depth-range test, :986
+                    L.depth = d_new;
+                    L.pl = cand;
+                    L.cst = c;
+                    L.chg = 1;
+                }
+            }
+        }
+    }
     if (L.active) {
         cost[L.center] = L.cst;
         norm4[L.center] = L.pl;

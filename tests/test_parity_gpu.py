@@ -275,6 +275,23 @@ def test_early_termination_is_exact_for_any_bound(hip, theta, cfg):
         os.environ.pop("GIPUMA_HIP_TUNE", None)
 
 
+def test_shared_sample_kernel_with_fused_refinement(hip):
+    """experiment switch GIPUMA_HIP_SHARED_FUSED: the shared-sample propagation kernel (bit 20) runs the
+    refinement stage -- by (candidate, view) items -- in the same launch"""
+    gs, _ = synth.build_problem(synth.tiny_config(cols=160, rows=112, n_src=4, blocksize=15, iterations=3, n_best=3))
+    o = OracleState(gs).run()
+    os.environ["GIPUMA_HIP_ET_FORCE"] = "2"
+    os.environ["GIPUMA_HIP_SHARED_FUSED"] = "1"
+    os.environ["GIPUMA_HIP_TUNE"] = str(1 << 20)
+    try:
+        a = runcuda(gs)
+    finally:
+        for k in ("GIPUMA_HIP_ET_FORCE", "GIPUMA_HIP_SHARED_FUSED", "GIPUMA_HIP_TUNE"):
+            del os.environ[k]
+    assert_same(a[0], o[0], "shared+fused norm4")
+    assert_same(a[1], o[1], "shared+fused cost")
+
+
 def test_two_phase_refinement_ragged_frame_many_views(hip):
     """the same on a frame that is not a multiple of the 32x16 tile (border tiles take the unbounded
     path, interior ones the item lists) with 12 source views (item groups of 5 + 5 + 2) and best-2"""
