@@ -52,11 +52,13 @@ struct Problem {  // lives in device memory, read through scalar loads (wave-uni
     // per (tile, wavefront, refinement step): > 0 while bounding the evaluation recently did not pay
     // there (a wavefront had to redo lanes); performance only, any content gives the same results
     unsigned char *et_hint;
-    // [3 rotating slots][3 steps][window columns a full evaluation takes, columns evaluated with the
-    // bound incl. redos]: what the probe workgroups (every 16th) measured; the other workgroups
-    // bound a step only if that paid for the previous half-sweep's probes.  Half-sweep k (= phase)
-    // writes slot k % 3, reads slot (k-1) % 3 and clears slot (k+1) % 3.
-    unsigned *et_stat;  // kEtSlot words per slot, see the kernel
+    // [3 rotating slots][kEtSlot words]: what the probe workgroups (every 16th) measured per bounded
+    // refinement step -- window columns a full evaluation takes, columns evaluated with the bound incl.
+    // redos, (candidate, view) items left after phase 1 of refine_two_phase, items, phase-1 length used;
+    // the other workgroups bound a step only if that paid for the previous half-sweep's probes.
+    // Half-sweep k (= phase) writes slot k % 3, reads slot (k-1) % 3 and clears slot (k+1) % 3.
+    // Performance only: any content gives the same results.
+    unsigned *et_stat;
     int tp_g0;  // window columns of phase 1 of refine_two_phase (0: default, 3/8 of the window)
 #ifdef PM_PS_PROFILE
     unsigned long long *prof;  // experiment builds only
