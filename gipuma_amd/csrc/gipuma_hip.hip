@@ -12,6 +12,7 @@
 #include "../../include/gipuma_hip.h"
 #include "pm_device.h"
 #include "pm_prop_shared.h"
+#include "pm_push.h"
 #include "pm_refine_rows.h"
 
 #include <cmath>
@@ -89,6 +90,14 @@ struct gipuma_hip_session {
     unsigned *et_stat = nullptr;       // device, Problem::et_stat
     unsigned char *et_hint = nullptr;  // device, 12 bytes per sweep tile (Problem::et_hint)
     size_t et_hint_bytes = 0;
+    // push propagation (pm_push.h): after a half-sweep the planes of its colour are evaluated once for
+    // all their consumers; the next half-sweep reads those costs instead of evaluating them
+    bool push_ok = false;      // the instantiation exists for this problem
+    int push_launches = 0;     // leading half-sweeps (2*iteration + colour) that consume pushed costs
+    float *push_cost = nullptr;  // device, Problem::push_cost
+    int push_valid = -1;       // colour whose pixels find valid costs in push_cost (-1: nobody)
+    bool push_hist = false;    // ... offered under rule (H) (only the planes that changed)
+    bool push_attr_set = false;
     int box = 0;             // specialised window size, 0 = runtime
     int ch = 1;              // 1 = gray (T=float), 4 = colour (T=float4)
     unsigned tune = 0;
@@ -194,6 +203,25 @@ size_t lds_bytes(const gipuma_hip_session *s, int tile_h, bool with_cv, bool swe
     return n * sizeof(float);
 }
 
+// pm::push_kernel: the planes of `colour` evaluated for their consumers (the pixels of the other colour)
+int launch_push(gipuma_hip_session *s, int colour, bool hist)
+{
+    const int gx = (s->cols + pm::kTileW - 1) / pm::kTileW;
+    const int gy = (s->rows + pm::kSweepTileH - 1) / pm::kSweepTileH;
+    const size_t lds = sizeof(float) * (size_t)pm::PushLayout<15>::total;
+    if (!s->push_attr_set) {
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(pm::push_kernel<15>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        s->push_attr_set = true;
+    }
+    hipLaunchKernelGGL(pm::push_kernel<15>, dim3(gx * gy), dim3(pm::kThreads), lds, s->stream, s->dp, s->norm4, colour,
+                       hist ? 1 : 0, s->tune);
+    HIP_OK(hipGetLastError());
+    s->push_valid = 1 - colour;
+    s->push_hist = hist;
+    return 0;
+}
+
 int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stages)
 {
     const int gx = (s->cols + pm::kTileW - 1) / pm::kTileW;
@@ -206,8 +234,28 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
     const bool qualifies = stages == GIPUMA_STAGE_ALL && !s->unfused && s->costs_trusted;
     if (qualifies && s->prev1 == 1 - colour && s->prev2 == colour && !(tune & (Tune::kNoHistory | Tune::kNoSkip)))
         tune |= Tune::kHistorySkip;
+    // will rule (H) hold for the next half-sweep if it is the other colour's full one?  (then prev1 = colour,
+    // prev2 = today's prev1)
+    const bool hist_next = qualifies && s->prev1 == 1 - colour && !(tune & (Tune::kNoHistory | Tune::kNoSkip));
     s->prev2 = s->prev1;
     s->prev1 = qualifies ? colour : -1;
+    // push propagation: this half-sweep reads the costs of its propagation candidates from push_cost
+    // (written by push_kernel after the previous half-sweep, or right now if nobody did), and offers
+    // its own planes to the next one
+    const int half_sweep = 2 * iteration + colour;
+    const bool push_now = s->push_ok && qualifies && half_sweep < s->push_launches &&
+                          !(tune & (Tune::kNoSkip | Tune::kSharedProp | Tune::kRowsKernel));
+    if (push_now) {
+        const bool hist = (tune & Tune::kHistorySkip) != 0;
+        if (s->push_valid != colour || s->push_hist != hist) {
+            const int rc = launch_push(s, 1 - colour, hist);
+            if (rc) return rc;
+        }
+        tune |= Tune::kPushConsume;
+    }
+    s->push_valid = -1;  // the planes of `colour` are about to change
+    const bool push_next = s->push_ok && qualifies && half_sweep + 1 < s->push_launches &&
+                           !(tune & (Tune::kNoSkip | Tune::kSharedProp | Tune::kRowsKernel));
     // task order (performance only): planes are still incoherent in the first two iterations, where
     // grouping the evaluations of one plane saves cache-line fills; afterwards owner order is faster
     if (iteration >= 2 && !(tune & Tune::kSourceMajorTasks)) tune |= Tune::kOwnerMajorTasks;
@@ -258,6 +306,7 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
     hipLaunchKernelGGL(k, dim3(gx * gy), dim3(pm::kThreads), lds, s->stream, s->dp, s->norm4,
                        s->cost, colour, phase, stages, tune);
     HIP_OK(hipGetLastError());
+    if (push_next) return launch_push(s, colour, hist_next);
     return 0;
 }
 
@@ -360,7 +409,7 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     s->unfused = (d->flags & GIPUMA_HIP_FLAG_UNFUSED) != 0;
     if (const char *t = getenv("GIPUMA_HIP_TUNE")) {
         s->tune = (unsigned)strtoul(t, nullptr, 0);
-        s->tune &= ~(Tune::kHistorySkip | Tune::kUntrustedCosts | Tune::kAccumChanged);  // host-internal bits
+        s->tune &= ~(Tune::kHistorySkip | Tune::kUntrustedCosts | Tune::kAccumChanged | Tune::kPushConsume);  // host-internal bits
     }
     if (const char *t = getenv("GIPUMA_HIP_COLS_LAUNCHES")) s->cols_launches = atoi(t);  // experiment
     if (const char *t = getenv("GIPUMA_HIP_LAUNCH_TIMES")) s->launch_times = atoi(t) != 0;
@@ -594,6 +643,16 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
             }
         }
     }
+    // push propagation (pm_push.h): box 15, register combiner, packed gray planes with float-encoded offsets
+    s->push_ok = s->u8 && s->ch == 1 && hp.magic_addr && s->box == 15 && s->combine_reg && s->n_sel > 0 &&
+                 !(s->tune & (Tune::kNoInterior | Tune::kNoSkip));
+    s->push_launches = 4;  // (measured on config C)
+    if (const char *t = getenv("GIPUMA_HIP_PUSH_LAUNCHES")) s->push_launches = atoi(t);  // A/B runs: 0 = never
+    if (s->push_launches <= 0) s->push_ok = false;
+    if (s->push_ok) {
+        CREATE_OK(hipMalloc(&s->push_cost, 8 * np * sizeof(float)));
+        hp.push_cost = s->push_cost;
+    }
     s->lds_sweep = lds_bytes(s, pm::kSweepTileH, !s->combine_reg, true);
     s->lds_dense = lds_bytes(s, pm::kDenseTileH, true, false);
     if (s->lds_sweep > 160u * 1024u || s->lds_dense > 160u * 1024u) {  // 160 KiB of LDS per CU on gfx950
@@ -637,6 +696,7 @@ int gipuma_hip_destroy(gipuma_hip_session *s)
     if (s->flag) (void)hipFree(s->flag);
     if (s->dp) (void)hipFree(s->dp);
     if (s->changed) (void)hipFree(s->changed);
+    if (s->push_cost) (void)hipFree(s->push_cost);
     if (s->et_hint) (void)hipFree(s->et_hint);
     if (s->et_stat) (void)hipFree(s->et_stat);
     if (s->norm4) (void)hipFree(s->norm4);
@@ -660,6 +720,7 @@ int gipuma_hip_init_planes(gipuma_hip_session *s)
     if (!rc) s->costs_trusted = true;
     s->finalized = false;
     s->prev1 = s->prev2 = -1;
+    s->push_valid = -1;
     return rc;
 }
 
@@ -695,6 +756,7 @@ int gipuma_hip_finalize(gipuma_hip_session *s)
     s->finalized = true;
     s->costs_trusted = false;
     s->prev1 = s->prev2 = -1;
+    s->push_valid = -1;
     return 0;
 }
 
@@ -748,6 +810,7 @@ int gipuma_hip_set_state(gipuma_hip_session *s, const float *norm4_host, const f
     HIP_OK(hipStreamSynchronize(s->stream));
     s->costs_trusted = false;
     s->prev1 = s->prev2 = -1;
+    s->push_valid = -1;
     if (norm4_host) s->finalized = false;
     return 0;
 }

@@ -60,6 +60,10 @@ struct Problem {  // lives in device memory, read through scalar loads (wave-uni
     // Performance only: any content gives the same results.
     unsigned *et_stat;
     int tp_g0;  // window columns of phase 1 of refine_two_phase (0: default, 3/8 of the window)
+    // [8][rows*cols]: cost of neighbour slot k's plane at the pixel, left by pm::push_kernel (pm_push.h)
+    // after the previous half-sweep for the pixels of the other colour; read instead of evaluated
+    // when the host sets Tune::kPushConsume
+    float *push_cost;
 #ifdef PM_PS_PROFILE
     unsigned long long *prof;  // experiment builds only
 #endif
@@ -282,6 +286,7 @@ struct Tune {  // experiment switches (GIPUMA_HIP_TUNE), all default off
     static constexpr unsigned kNoLut = 1, kNoInterior = 2, kNoXcdRemap = 4, kGenericBox = 8,
                               kGenericCombine = 16, kRowMajorTiles = 32, kNoSkip = 64,
                               kUntrustedCosts = 128,  // set by the host after gipuma_hip_set_state
+                              kPushConsume = 1u << 18,   // host-internal: propagation costs come from Problem::push_cost
                               kNoTwoPhase = 1u << 19,    // refinement bounded per wavefront (v11) instead of two-phase (refine_two_phase)
                               kRegroup = 1u << 22,       // opt-in: lanes swap pixels before refinement (see regroup_for_refinement; measured: no gain)
                               kRowsKernel = 1u << 21,    // refinement by the row-per-lane kernel (pm_refine_rows.h); opt-in: not faster when fused
@@ -1533,7 +1538,18 @@ __device__ __forceinline__ void sweep_read_state(SweepLane &L, const Problem *__
                 valid |= 1u << k;
             }
         }
-        if (tune & Tune::kNoSkip) {
+        if (tune & Tune::kPushConsume) {
+            // the neighbours evaluated their planes for this pixel (pm_push.h) unless rule (H) let them
+            // keep silent; a cost that rules (A) / (D) would have skipped is replayed and rejected
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if ((valid >> k) & 1u) {
+                    int nb;
+                    neighbour(k, L.px, L.py, rows, cols, L.center, nb);
+                    if (!history || P->changed[nb] != 0) needmask |= 1u << k;
+                }
+            }
+        } else if (tune & Tune::kNoSkip) {
             needmask = valid;
         } else {
 #pragma unroll
@@ -1562,6 +1578,7 @@ __device__ __forceinline__ void sweep_setup(SweepLane &L, const Problem *__restr
                                             int colour, unsigned stages, unsigned tune, bool want_lut)
 {
     sweep_read_state<BOX, CH, PAD>(L, P, lds, norm4, cost, colour, stages, tune, want_lut);
+    if (tune & Tune::kPushConsume) return;  // nothing to evaluate: L.n_tasks == 0, the replay reads Problem::push_cost
     // Workgroup task list.  Two orders, same set of tasks (the order cannot change a result: a task
     // is a pure function of (pixel, plane) and its cost lands in bres[slot][owner]):
     //  * source-major (default): tasks that evaluate the SAME plane -- the plane of other-colour
@@ -1659,16 +1676,17 @@ __device__ __forceinline__ void sweep_setup(SweepLane &L, const Problem *__restr
 // replay: spatialPropagation_cu's accept test (gipuma.cu:865-872) in slot order, by the owner lane,
 // from the costs the rounds left in bres
 __device__ __forceinline__ void sweep_replay(SweepLane &L, const Problem *__restrict__ P,
-                                             const float4 *__restrict__ norm4)
+                                             const float4 *__restrict__ norm4, bool pushed = false)
 {
     const RefCam &rc = P->rc;
+    const size_t np = (size_t)P->rows * (size_t)P->cols;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         if ((L.needmask >> k) & 1u) {
             int nb;
             neighbour(k, L.px, L.py, P->rows, P->cols, L.center, nb);
             const float4 cand = norm4[nb];
-            const float c = L.bres[k * kThreads + threadIdx.x];
+            const float c = pushed ? P->push_cost[(size_t)k * np + (size_t)L.center] : L.bres[k * kThreads + threadIdx.x];
             const float d_new = depth_from_plane(rc, cand, L.px, L.py);
             if (d_new >= rc.depth_min && d_new <= rc.depth_max && c < L.cst) {  // :829-830, :868
                 L.depth = d_new;
@@ -2046,7 +2064,7 @@ __global__ __launch_bounds__(kThreads, U8 ? 4 : 1) void sweep_kernel(const Probl
     for (int r = 0; r <= prop_rounds + R.nref; r++) {
         if (r == prop_rounds) {
             __syncthreads();  // every wavefront runs the same number of rounds, so this is uniform
-            sweep_replay(L, P, norm4);
+            sweep_replay(L, P, norm4, (tune & Tune::kPushConsume) != 0);
             if constexpr (ET && CH == 1 && BOX > 0)
                 if (et_on && R.nref > 0 && (tune & Tune::kRegroup)) regroup_for_refinement<BOX>(L, P, lds, colour);
             refine_begin(R, L, P, phase);
@@ -2214,7 +2232,7 @@ __global__ __launch_bounds__(kThreads) void sweep_cols_kernel(const Problem *__r
         if (have && col == 0) L.bres[slot * kThreads + owner] = c;
     }
     __syncthreads();
-    sweep_replay(L, P, norm4);
+    sweep_replay(L, P, norm4, (tune & Tune::kPushConsume) != 0);
     refine_begin(R, L, P, phase);
     // refinement steps: the owner draws its candidate, groups evaluate all 256, the owner accepts
     float4 *candbuf = reinterpret_cast<float4 *>(L.btask);  // the task list is dead now (same 4 KB)

@@ -1,0 +1,99 @@
+"""Index model of pm_push.h (box 15): every address formula of the kernel restated in Python and
+checked against the plain definition -- the stencil points a group of 8 lanes evaluates per step,
+where their dis values land, which slots the chain of consumer c reads for window term (i, j), and
+the checkerboard-compressed reference tile.  Run on the CPU; no GPU needed."""
+import itertools, random
+
+N, R, REACH = 8, 7, 5
+FWH = N + REACH           # 13
+NF = N * FWH              # 104
+HALO = R + REACH + 1      # 13
+TILE_W, TILE_H = 32, 16
+TW, TH = TILE_W + 2 * HALO, TILE_H + 2 * HALO  # 58, 42
+TWC = (TW + 1) // 2       # 29
+HBASE = NF                # horizontal family behind the vertical one
+# consumer c = the pixel that sees the producer as its neighbour slot c (pm::neighbour):
+# slot 0 up, 1 down, 2 left, 3 right (distance 1), 4..7 the same at distance 5
+def consumer_offset(c):
+    d = 1 if c < 4 else 5
+    k = c & 3
+    # neighbour offset of slot k: up (0,-d), down (0,+d), left (-d,0), right (+d,0); consumer = producer - offset
+    return [(0, d), (0, -d), (d, 0), (-d, 0)][k]
+
+def eval_point(s, l):
+    """step s (0..25) of lane l (0..7): offset of the sample from the producer, and its dis slot"""
+    if s < FWH:  # vertical family: x = l, y = s
+        return (2 * l - R, 2 * s - (R + REACH)), s * N + l
+    t = s - FWH
+    j0, r0 = (8 * t) // FWH, (8 * t) % FWH
+    w = 1 if l >= FWH - r0 else 0
+    x, y = r0 + l - FWH * w, j0 + w
+    return (2 * x - (R + REACH), 2 * y - R), HBASE + 8 * t + l
+
+def eval_tile_index(s, l, tnx, tny):
+    """compressed-tile index the kernel reads for that point"""
+    if s < FWH:
+        base_v = tny * TWC + ((tnx - R) >> 1) + l
+        return base_v + (2 * s - (R + REACH)) * TWC
+    t = s - FWH
+    j0, r0 = (8 * t) // FWH, (8 * t) % FWH
+    w = 1 if l >= FWH - r0 else 0
+    base_h = tny * TWC + ((tnx - (R + REACH)) >> 1)
+    return base_h + (2 * j0 - R) * TWC + r0 + l + w * (2 * TWC - FWH)
+
+def chain_slot(c, i, j):
+    dx, dy = consumer_offset(c)
+    if dx == 0:
+        return ((dy + REACH) // 2) * N + j * N + i
+    return HBASE + (dx + REACH) // 2 + j * FWH + i
+
+def chain_tile_index(c, i, j, tnx, tny):
+    dx, dy = consumer_offset(c)
+    tpx, tpy = tnx + dx, tny + dy
+    return (tpy - R) * TWC + ((tpx - R) >> 1) + 2 * j * TWC + i
+
+def centre_index(c, tnx, tny):
+    dx, dy = consumer_offset(c)
+    return (tny + dy) * TWC + ((tnx + dx) >> 1)
+
+def main():
+    rnd = random.Random(1)
+    for colour in (0, 1):
+        cpar = 1 - colour
+        # the compressed tile as the kernel stages it: entry k = (ty, cx) holds texel tx = 2 cx + ((cpar + ty) & 1)
+        comp = {}
+        for ty in range(TH):
+            for cx in range(TWC):
+                tx = 2 * cx + ((cpar + ty) & 1)
+                comp[ty * TWC + cx] = (tx, ty) if tx < TW else None
+        for ly in range(TILE_H):
+            for lxh in range(16):
+                lx = 2 * lxh + ((ly + colour) & 1)
+                tnx, tny = lx + HALO, ly + HALO
+                slots = {}
+                for s in range(2 * FWH):
+                    for l in range(8):
+                        (dx, dy), e = eval_point(s, l)
+                        assert e not in slots, "slot written twice"
+                        slots[e] = (dx, dy)
+                        k = eval_tile_index(s, l, tnx, tny)
+                        assert comp[k] == (tnx + dx, tny + dy), (s, l, comp[k], (tnx + dx, tny + dy))
+                        assert 1 <= tnx + dx <= TW - 2 and 1 <= tny + dy <= TH - 2  # gradients stay inside the tile
+                assert sorted(slots) == list(range(2 * NF))
+                for c in range(8):
+                    cdx, cdy = consumer_offset(c)
+                    assert comp[centre_index(c, tnx, tny)] == (tnx + cdx, tny + cdy)
+                    for i, j in itertools.product(range(N), range(N)):
+                        q = (cdx + 2 * i - R, cdy + 2 * j - R)  # window sample of the consumer, relative to the producer
+                        assert slots[chain_slot(c, i, j)] == q, (c, i, j)
+                        assert comp[chain_tile_index(c, i, j, tnx, tny)] == (tnx + q[0], tny + q[1])
+    # the neighbour relation: consumer p = n + consumer_offset(c) has n at slot c
+    for c in range(8):
+        d = 1 if c < 4 else 5
+        off = [(0, -d), (0, d), (-d, 0), (d, 0)][c & 3]
+        co = consumer_offset(c)
+        assert (co[0] + off[0], co[1] + off[1]) == (0, 0)
+    print("push index model: ok")
+
+if __name__ == "__main__":
+    main()

@@ -348,6 +348,56 @@ def test_early_termination_colour(hip, theta, tune):
     assert_same(a[1], o[1], "colour theta %s cost" % theta)
 
 
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("push", [0, 1, 2, 3, 100])
+def test_push_propagation_is_bit_identical(hip, push):
+    """pm_push.h: after a half-sweep every plane of its colour is evaluated once, by a group of 8 lanes,
+    on the 208-point stencil its eight consumers share; the next half-sweep reads those costs instead
+    of evaluating them.  GIPUMA_HIP_PUSH_LAUNCHES = how many leading half-sweeps do that (default 4):
+    never, an odd number (the last push is consumed by the pixel-per-lane kernel's replay), every
+    half-sweep (rule (H) decides who offers) -- not a bit may change, and the default equals the oracle."""
+    gs, _ = synth.build_problem(synth.tiny_config(cols=160, rows=112, n_src=4, blocksize=15, iterations=4,
+                                                  n_best=3))
+    a = runcuda(gs)
+    b = _with_env({"GIPUMA_HIP_PUSH_LAUNCHES": push, "GIPUMA_HIP_ET_FORCE": 1}, lambda: runcuda(gs))
+    assert_same(a[0], b[0], "push %d norm4" % push)
+    assert_same(a[1], b[1], "push %d cost" % push)
+    if push == 0:
+        o = OracleState(gs).run()
+        assert_same(a[0], o[0], "default vs oracle norm4")
+        assert_same(a[1], o[1], "default vs oracle cost")
+
+
+@pytest.mark.parametrize("cols,rows,sel,over", [
+    (33, 17, [1, 2, 3], dict(n_best=2)),                   # ragged, smaller than a tile
+    (21, 9, [1, 2], dict(n_best=1)),                       # smaller than the window and the stencil
+    (70, 40, [1, 2, 3, 4] * 3, dict(n_best=4)),            # 12 views: two homography exchange blocks
+    (96, 64, [3], dict(n_best=3)),                         # one view, n_best > views
+    (5, 3, [1, 2], dict(n_best=2)),                        # consumers at distance 5 fall outside
+])
+def test_push_propagation_edge_cases(hip, cols, rows, sel, over):
+    """the push kernel in every half-sweep on ragged / tiny frames, many / one view(s), against the oracle"""
+    gs, _ = synth.build_problem(synth.tiny_config(cols=96, rows=64, n_src=4, blocksize=15, iterations=3))
+    imgs = [np.ascontiguousarray(im[:rows, :cols]) for im in gs.images]
+    g = _problem_from(gs, imgs, sel, **over)
+    n4, c = _with_env({"GIPUMA_HIP_PUSH_LAUNCHES": 100}, lambda: runcuda(g))
+    o_n4, o_c = OracleState(g).run()
+    assert_same(n4, o_n4, "push %dx%d norm4" % (cols, rows))
+    assert_same(c, o_c, "push %dx%d cost" % (cols, rows))
+
+
 @pytest.mark.parametrize("seq", [
     # (iteration, colour, stages) or "set" = write the state back through set_state
     [(0, 0, 7), (0, 1, 7), (1, 0, 7), (1, 0, 7), (1, 1, 7), (1, 1, 7), (2, 0, 7), (2, 1, 7), (3, 0, 7), (3, 1, 7)],
@@ -355,26 +405,31 @@ def test_early_termination_colour(hip, theta, tune):
     [(0, 0, 7), (0, 1, 7), (1, 0, 7), (1, 1, 7), (2, 0, 7), "set", (2, 1, 7), (3, 0, 7), (3, 1, 7), (4, 0, 7)],
     [(0, 1, 7), (0, 1, 7), (0, 0, 7), (1, 1, 7), (1, 0, 7), (2, 1, 7), (2, 0, 7), (3, 1, 7)],
 ])
-def test_history_rule_survives_any_launch_sequence(hip, seq):
+@pytest.mark.parametrize("push", [4, 100])
+def test_history_rule_survives_any_launch_sequence(hip, seq, push):
     """rule (H) -- skip a neighbour whose plane did not change in its last half-sweep -- is only
     valid inside a strictly alternating sequence of full half-sweeps; the session must notice
     repeated colours, partial stages and rewritten states by itself.  Each sequence is replayed on
-    the oracle launch by launch."""
+    the oracle launch by launch.  push: the leading half-sweeps that read pushed costs (pm_push.h) --
+    the session must also notice by itself when nobody has offered the costs a half-sweep wants."""
     gs, _ = synth.build_problem(synth.tiny_config(cols=128, rows=96, n_src=4, blocksize=15, iterations=5,
                                                   n_best=3))
     o = OracleState(gs)
     o.init_planes()
-    with Session(gs) as s:
-        s.init_planes()
-        for step in seq:
-            if step == "set":
-                n4, c = s.get_state()
-                s.set_state(n4, c)
-                continue
-            it, colour, stages = step
-            s.sweep(it, colour, stages)
-            o.sweep(it, colour, stages)
-        n4, c = s.get_state()
+
+    def run():
+        with Session(gs) as s:
+            s.init_planes()
+            for step in seq:
+                if step == "set":
+                    n4, c = s.get_state()
+                    s.set_state(n4, c)
+                    continue
+                it, colour, stages = step
+                s.sweep(it, colour, stages)
+                o.sweep(it, colour, stages)
+            return s.get_state()
+    n4, c = _with_env({"GIPUMA_HIP_PUSH_LAUNCHES": push}, run)
     assert_same(n4, o.norm4, "sequence norm4")
     assert_same(c, o.cost, "sequence cost")
 
