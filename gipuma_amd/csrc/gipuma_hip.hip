@@ -15,6 +15,7 @@
 #include "pm_push.h"
 #include "pm_refine_rows.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -208,7 +209,8 @@ int launch_push(gipuma_hip_session *s, int colour, bool hist)
 {
     const int gx = (s->cols + pm::kTileW - 1) / pm::kTileW;
     const int gy = (s->rows + pm::kSweepTileH - 1) / pm::kSweepTileH;
-    const size_t lds = sizeof(float) * (size_t)pm::PushLayout<15>::total;
+    size_t lds = sizeof(float) * (size_t)pm::PushLayout<15>::total;
+    if (const char *t = getenv("GIPUMA_HIP_PUSH_LDS_KB")) lds = std::max(lds, (size_t)atoi(t) * 1024);  // experiment: fewer workgroups per CU
     if (!s->push_attr_set) {
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(pm::push_kernel<15>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

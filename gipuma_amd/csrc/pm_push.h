@@ -80,27 +80,58 @@ __device__ __forceinline__ void push_consumer_offset(int c, int &dx, int &dy)
 // dis of the 208 stencil points of one (producer, view) pair: 26 steps of 8 lanes.
 //   steps 0..12   vertical family, point (x = lane, y = step): offset (2x-7, 2y-12) from the producer
 //   steps 13..25  horizontal family, 13 points per row dealt 8 at a time: offset (2x-12, 2y-7)
-// (scripts/exp/push_model.py checks these index formulas against the definition)
-template <int BOX, bool FAST>
-__device__ __forceinline__ void push_eval(const Problem *__restrict__ P, gptr_bytes magic_base,
-                                          const float *__restrict__ H, const float *__restrict__ tile4,
-                                          int base_v, int base_h, float *__restrict__ dgrp, float nxf, float nyf,
-                                          int l)
-{
+// (scripts/exp/push_model.py checks these index formulas against the definition.)  kPushPD window
+// requests are in flight per lane; the first kPushPD of a view are issued by first() BEFORE the
+// chain phase of the previous view, so that their latency -- L2 misses while the planes are random --
+// hides behind it.
+// Measured on config C (first three half-sweeps, same box; scripts/exp/ab_push*.txt): what matters is
+// that the loop neither spills nor starves the scheduler of registers -- 3 wavefronts per SIMD
+// (168 VGPRs, 70-130 scratch accesses per view competing with the window loads for the vector L1)
+// 16.2 / 9.0 / 8.4 ms, 2 wavefronts per SIMD (234 VGPRs, no scratch) 13.4 / 8.0 / 7.7 ms; prefetch depth
+// 2..8 and cross-view prefetch make no difference there, 10-12 lose, one workgroup per CU loses 35 %.
+#ifndef PM_PUSH_PD
+#define PM_PUSH_PD 4
+#endif
+#ifndef PM_PUSH_WAVES
+#define PM_PUSH_WAVES 2
+#endif
+constexpr int kPushPD = PM_PUSH_PD;
+template <int BOX>
+struct PushEval {
     using LY = PushLayout<BOX>;
-    constexpr int FWH = LY::FWH, twc = LY::twc, S = 2 * FWH;
-    const float colsf = (float)P->cols, rowsf = (float)P->rows;
-    const float alpha = P->alpha, oma = 1.f - P->alpha;
-    const float tau_color = P->tau_color, tau_gradient = P->tau_gradient;
-    const float pwf = (float)P->pw;
-    const float magic_c = kMagicF + (float)(2 * P->pw + 2);
-    const float H0 = H[0], H1 = H[1], H2 = H[2], H3 = H[3], H4 = H[4], H5 = H[5], H6 = H[6], H7 = H[7], H8 = H[8];
+    static constexpr int FWH = LY::FWH, twc = LY::twc, S = 2 * FWH, PD = kPushPD;
+    float colsf, rowsf, pwf, magic_c, alpha, oma, tau_color, tau_gradient;  // wave-uniform
+    float qx_v, qx_h, nyf;  // (float)(n + d) == (float)n + (float)d exactly (small integers)
+    int l, base_v, base_h;
 
-    auto request = [&](float qx, float qy) -> WinReq {
+    __device__ __forceinline__ void init(const Problem *__restrict__ P, int lane_in_group)
+    {
+        colsf = (float)P->cols;
+        rowsf = (float)P->rows;
+        pwf = (float)P->pw;
+        magic_c = kMagicF + (float)(2 * P->pw + 2);
+        alpha = P->alpha;
+        oma = 1.f - P->alpha;
+        tau_color = P->tau_color;
+        tau_gradient = P->tau_gradient;
+        l = lane_in_group;
+    }
+    __device__ __forceinline__ void producer(float nxf, float nyf_, int tnx, int tny)
+    {
+        qx_v = nxf + (float)(2 * l - LY::R);                 // vertical family: the lane's column
+        qx_h = nxf + (float)(2 * l - (LY::R + kPushReach));  // horizontal family, before the row wrap
+        nyf = nyf_;
+        // compressed-tile indices of this lane's first point of either family
+        base_v = tny * twc + ((tnx - LY::R) >> 1) + l;
+        base_h = tny * twc + ((tnx - (LY::R + kPushReach)) >> 1) + l;
+    }
+    template <bool FAST>
+    __device__ __forceinline__ WinReq request(const float *__restrict__ H, gptr_bytes magic_base, float qx, float qy) const
+    {
         // getCorrespondingPoint_cu, gipuma.cu:207-217, the fmaf nesting of view_cost_pipe
-        const float X = __builtin_fmaf(H1, qy, __builtin_fmaf(H0, qx, H2));
-        const float Y = __builtin_fmaf(H4, qy, __builtin_fmaf(H3, qx, H5));
-        const float Z = __builtin_fmaf(H7, qy, __builtin_fmaf(H6, qx, H8));
+        const float X = __builtin_fmaf(H[1], qy, __builtin_fmaf(H[0], qx, H[2]));
+        const float Y = __builtin_fmaf(H[4], qy, __builtin_fmaf(H[3], qx, H[5]));
+        const float Z = __builtin_fmaf(H[7], qy, __builtin_fmaf(H[6], qx, H[8]));
         const float rz = recip<FAST>(Z);
         const float sx = X * rz, sy = Y * rz;
         const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
@@ -112,47 +143,59 @@ __device__ __forceinline__ void push_eval(const Problem *__restrict__ P, gptr_by
         const uint32_t off = __float_as_uint(__builtin_fmaf(Yc, pwf, Xc + magic_c));
         r.w = *(gptr_u32x4)(magic_base + off);
         return r;
-    };
-    // (float)(n + d) == (float)n + (float)d exactly (small integers)
-    const float qx_v = nxf + (float)(2 * l - LY::R);                    // vertical family: the lane's column
-    const float qx_h = nxf + (float)(2 * l - (LY::R + kPushReach));     // horizontal family, before the row wrap
-    auto issue = [&](int s) -> WinReq {
-        if (s < FWH) return request(qx_v, nyf + (float)(2 * s - (LY::R + kPushReach)));
+    }
+    template <bool FAST>
+    __device__ __forceinline__ WinReq issue(const float *__restrict__ H, gptr_bytes magic_base, int s) const
+    {
+        if (s < FWH) return request<FAST>(H, magic_base, qx_v, nyf + (float)(2 * s - (LY::R + kPushReach)));
         const int t = s - FWH;
         const int j0 = (8 * t) / FWH, r0 = (8 * t) % FWH;
         const bool wrap = (FWH - r0 < kPushLanes) && l >= FWH - r0;
         const float qx = qx_h + (wrap ? (float)(2 * r0 - 2 * FWH) : (float)(2 * r0));
         const float qy = nyf + (wrap ? (float)(2 * j0 + 2 - LY::R) : (float)(2 * j0 - LY::R));
-        return request(qx, qy);
-    };
-    auto tile_index = [&](int s) -> int {
+        return request<FAST>(H, magic_base, qx, qy);
+    }
+    __device__ __forceinline__ int tile_index(int s) const
+    {
         if (s < FWH) return base_v + (2 * s - (LY::R + kPushReach)) * twc;
         const int t = s - FWH;
         const int j0 = (8 * t) / FWH, r0 = (8 * t) % FWH;
         const bool wrap = (FWH - r0 < kPushLanes) && l >= FWH - r0;
         return base_h + (2 * j0 - LY::R) * twc + r0 + (wrap ? 2 * twc - FWH : 0);
-    };
-
-    constexpr int PD = 8;  // window requests in flight per lane
-    WinReq req[PD];
-#pragma unroll
-    for (int p = 0; p < PD; p++) req[p] = issue(p);
-#pragma unroll
-    for (int s = 0; s < S; s++) {
-        const WinReq cur = req[s % PD];
-        if (s + PD < S) req[s % PD] = issue(s + PD);
-        // {I(q), gx1(q), gy1(q), I(q)} of the reference tile
-        const float4 t4 = *reinterpret_cast<const float4 *>(tile4 + 4 * tile_index(s));
-        const Taps tp5 = taps_u8(cur.a, cur.b, cur.w.x, cur.w.y, cur.w.z, cur.w.w);
-        // pmCostComputation_shared, gipuma.cu:251-274
-        const float colDiff = t4.w - tp5.sc;
-        const float gradX = t4.y - tp5.gx2;
-        const float gradY = t4.z - tp5.gy2;
-        const float gradDis = min_nc((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
-        const float colDis = min_abs_nc(colDiff, tau_color);
-        dgrp[(s < FWH ? 0 : LY::hbase - 8 * FWH) + 8 * s + l] = __builtin_fmaf(alpha, gradDis, oma * colDis);
     }
-}
+    // the first PD requests of a view
+    template <bool FAST>
+    __device__ __forceinline__ void first(const float *__restrict__ H, gptr_bytes magic_base, WinReq (&req)[kPushPD]) const
+    {
+#pragma unroll
+        for (int p = 0; p < PD; p++) req[p] = issue<FAST>(H, magic_base, p);
+    }
+    // all S steps of a view whose first PD requests are in `req`
+    template <bool FAST>
+    __device__ __forceinline__ void body(const float *__restrict__ H, gptr_bytes magic_base, WinReq (&req)[kPushPD],
+                                         const float *__restrict__ tile4, float *__restrict__ dgrp) const
+    {
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const WinReq cur = req[s % PD];
+            if (s + PD < S) req[s % PD] = issue<FAST>(H, magic_base, s + PD);
+            // {I(q), gx1(q), gy1(q), I(q)} of the reference tile
+            const float4 t4 = *reinterpret_cast<const float4 *>(tile4 + 4 * tile_index(s));
+            const Taps tp5 = taps_u8(cur.a, cur.b, cur.w.x, cur.w.y, cur.w.z, cur.w.w);
+            // pmCostComputation_shared, gipuma.cu:251-274
+            const float colDiff = t4.w - tp5.sc;
+            const float gradX = t4.y - tp5.gx2;
+            const float gradY = t4.z - tp5.gy2;
+            const float gradDis = min_nc((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
+            const float colDis = min_abs_nc(colDiff, tau_color);
+            dgrp[(s < FWH ? 0 : LY::hbase - 8 * FWH) + 8 * s + l] = __builtin_fmaf(alpha, gradDis, oma * colDis);
+#ifndef PM_PUSH_NO_SCHED_BARRIER
+            // keep the steps apart: left alone, the scheduler interleaves many of them and spills
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+    }
+};
 
 // the reference's summation for one consumer: columns outer, rows inner, one fmaf per sample
 // (gipuma.cu:633-676); `ipl` = the compressed I plane at the consumer's window corner, `dch` = the
@@ -163,7 +206,11 @@ __device__ __forceinline__ float push_chain(const float *__restrict__ ipl, float
 {
     using LY = PushLayout<BOX>;
     float cost = 0.0f;
+#ifdef PM_PUSH_CHAIN_UNROLLED
 #pragma unroll
+#else
+#pragma unroll 1  // (8 terms per iteration; all 64 unrolled: +12 KB of code, no faster)
+#endif
     for (int i = 0; i < LY::N; i++)
 #pragma unroll
         for (int j = 0; j < LY::N; j++) {
@@ -178,7 +225,7 @@ __device__ __forceinline__ float push_chain(const float *__restrict__ ipl, float
 // grid = the sweep tiles of the frame; `colour` = the colour of the producers (the colour that was
 // swept last); hist: offer only the planes that changed in that half-sweep (rule (H))
 template <int BOX>
-__global__ __launch_bounds__(kThreads, 3) void push_kernel(const Problem *__restrict__ P,
+__global__ __launch_bounds__(kThreads, PM_PUSH_WAVES) void push_kernel(const Problem *__restrict__ P,
                                                            const float4 *__restrict__ norm4, int colour, int hist,
                                                            unsigned tune)
 {
@@ -255,6 +302,8 @@ __global__ __launch_bounds__(kThreads, 3) void push_kernel(const Problem *__rest
     // where consumer l's samples start in the group's buffer, and how far its window rows are apart
     const int dbase = cdx == 0 ? ((cdy + kPushReach) / 2) * N : LY::hbase + (cdx + kPushReach) / 2;
     const int jstride = cdx == 0 ? N : LY::FWH;
+    PushEval<BOX> E;
+    E.init(P, l);
 
     for (int r = 0; r * kPushGroups < n_live; r++) {
         const int idx = r * kPushGroups + grp;
@@ -266,10 +315,8 @@ __global__ __launch_bounds__(kThreads, 3) void push_kernel(const Problem *__rest
         const float4 pl = norm4[npy * cols + npx];
         const int tnx = olx + halo, tny = oly + halo;
         const float nxf = (float)npx, nyf = (float)npy;
-        // compressed-tile indices: this lane's first point of either family, its consumer's centre
-        // and window corner
-        const int base_v = tny * twc + ((tnx - R) >> 1) + l;
-        const int base_h = tny * twc + ((tnx - (R + kPushReach)) >> 1) + l;
+        E.producer(nxf, nyf, tnx, tny);
+        // this lane's consumer: its centre and window corner in the compressed I plane
         const int cpx = npx + cdx, cpy = npy + cdy;
         const bool cvalid = have && cpx >= 0 && cpx < cols && cpy >= 0 && cpy < rows;
         const int tpx = tnx + cdx, tpy = tny + cdy;
@@ -277,30 +324,43 @@ __global__ __launch_bounds__(kThreads, 3) void push_kernel(const Problem *__rest
         const float *ipl = iplane + (tpy - R) * twc + ((tpx - R) >> 1);
 
         ViewCombiner<true> comb;
-        // the homography of a (plane, view) pair is the same for the lanes of a group: lane c computes
-        // it for view vb + c (the literal arithmetic of homography()), the lanes then pass them round
-        for (int vb = 0; vb < n; vb += kPushLanes) {
-            float Hl[9];
-            homography(P->rc.K_inv, P->view[min(vb + l, n - 1)], pl, Hl);
-            const int vend = min(vb + kPushLanes, n);
-            for (int v = vb; v < vend; v++) {
-                float H[9];
+        // The homography of a (plane, view) pair is the same for the lanes of a group: lane c computes
+        // it for view 8b + c (the literal arithmetic of homography()), the lanes then pass them round.
+        // 1/Z by rcp + Newton where the whole stencil is provably inside its exact range (any such
+        // proof gives the bits of the IEEE division, see rcp_newton).
+        float Hl[9], H[9];
+        bool fast = false;
+        gptr_bytes magic_base = nullptr;
+        WinReq req[kPushPD];
+        auto load_view = [&](int v) {
+#ifdef PM_PUSH_DIRECT_H
+            homography(P->rc.K_inv, P->view[v], pl, H);  // (experiment: every lane, no exchange)
+            (void)Hl;
+            (void)grp_lane0;
+#else
+            if ((v & (kPushLanes - 1)) == 0) homography(P->rc.K_inv, P->view[min(v + l, n - 1)], pl, Hl);
 #pragma unroll
-                for (int k = 0; k < 9; k++) H[k] = __shfl(Hl[k], grp_lane0 + (v - vb));
-                // 1/Z by rcp + Newton where the whole stencil is provably inside its exact range
-                // (any such proof gives the bits of the IEEE division, see rcp_newton)
-                const float reach = (float)(R + kPushReach);
-                const bool safe = window_z_safe(H, nxf - reach, nxf + reach, nyf - reach, nyf + reach);
-                const gptr_bytes magic_base = (gptr_bytes)((uintptr_t)P->view[v].packed - (uintptr_t)kMagicBits);
-                if (__all(safe))
-                    push_eval<BOX, true>(P, magic_base, H, tile4, base_v, base_h, dgrp, nxf, nyf, l);
-                else
-                    push_eval<BOX, false>(P, magic_base, H, tile4, base_v, base_h, dgrp, nxf, nyf, l);
-                __builtin_amdgcn_wave_barrier();  // (the group's samples are read by other lanes of this wavefront)
-                const float c = push_chain<BOX>(ipl, centre, lut_magic, dgrp + dbase, jstride);
-                __builtin_amdgcn_wave_barrier();
-                comb.add(c, v, nullptr);
-            }
+            for (int k = 0; k < 9; k++) H[k] = __shfl(Hl[k], grp_lane0 + (v & (kPushLanes - 1)));
+#endif
+            const float reach = (float)(R + kPushReach);
+            fast = __all(window_z_safe(H, nxf - reach, nxf + reach, nyf - reach, nyf + reach));
+            magic_base = (gptr_bytes)((uintptr_t)P->view[v].packed - (uintptr_t)kMagicBits);
+            if (fast)
+                E.template first<true>(H, magic_base, req);
+            else
+                E.template first<false>(H, magic_base, req);
+        };
+        load_view(0);
+        for (int v = 0; v < n; v++) {
+            if (fast)
+                E.template body<true>(H, magic_base, req, tile4, dgrp);
+            else
+                E.template body<false>(H, magic_base, req, tile4, dgrp);
+            if (v + 1 < n) load_view(v + 1);  // the next view's first windows travel during the chain
+            __builtin_amdgcn_wave_barrier();  // (the group's samples are read by other lanes of this wavefront)
+            const float c = push_chain<BOX>(ipl, centre, lut_magic, dgrp + dbase, jstride);
+            __builtin_amdgcn_wave_barrier();
+            comb.add(c, v, nullptr);
         }
         const float F = comb.finish(P, n, nullptr);
         if (cvalid) P->push_cost[(size_t)l * np + (size_t)(cpy * cols + cpx)] = F;
