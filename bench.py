@@ -356,6 +356,10 @@ def main():
         samples_per_frame = n_pix * (1 + iterations * (8 + r_ref)) * n_views * S
         cols_l = int(os.environ.get("GIPUMA_HIP_COLS_LAUNCHES", {15: "4", 25: "3"}.get(box, "0"))) if not args.colour else 0
         n_launch = 2 * iterations
+        # leading half-sweeps whose propagation costs are pushed by pm::push_kernel (pm_push.h: box 15, gray, best-N <= 4)
+        push_l = int(os.environ.get("GIPUMA_HIP_PUSH_LAUNCHES", "4")) if (box == 15 and not args.colour and
+                                                                        gs.params.n_best <= 4 and n_views > 0) else 0
+        push_l = max(0, min(push_l, n_launch))
         out = {
             "metric": "Mpixels/sec/GPU (1600x1200, 10 src views, 8 iters)"
                       if args.config == "C" and not args.colour and args.scene == "smooth"
@@ -386,9 +390,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": "GB per launch (L2<->fabric incl. Infinity Cache hits)",
                          "traffic_source": imported,
-                         "kernel": "one half-sweep launch (one colour: close+far+refine fused); mean over the %d of a "
-                                   "view: pm::sweep_cols_kernel x%d + pm::sweep_kernel x%d"
-                                   % (n_launch, min(cols_l, n_launch), n_launch - min(cols_l, n_launch)),
+                         "kernel": "one half-sweep (one colour: close+far+refine); mean over the %d of a view: "
+                                   "pm::sweep_cols_kernel x%d + pm::sweep_kernel x%d fused launches, plus pm::push_kernel x%d "
+                                   "(the propagation costs of the first %d half-sweeps, evaluated once per plane)"
+                                   % (n_launch, min(cols_l, n_launch), n_launch - min(cols_l, n_launch), push_l, push_l),
                          "kernel_ms": ms_launch,
                          "kernel_ms_source": "HIP events on the library's stream inside gipuma_hip_solve, this run",
                          "algorithmic_bytes_per_launch": alg,
