@@ -209,15 +209,17 @@ int launch_push(gipuma_hip_session *s, int colour, bool hist)
 {
     const int gx = (s->cols + pm::kTileW - 1) / pm::kTileW;
     const int gy = (s->rows + pm::kSweepTileH - 1) / pm::kSweepTileH;
-    size_t lds = sizeof(float) * (size_t)pm::PushLayout<15>::total;
+    typedef void (*push_fn)(const pm::Problem *, const float4 *, int, int, unsigned);
+    const push_fn k = s->box == 15 ? pm::push_kernel<15> : s->box == 25 ? pm::push_kernel<25> : pm::push_kernel<11>;
+    size_t lds = sizeof(float) * (size_t)(s->box == 15 ? pm::PushLayout<15>::total
+                                          : s->box == 25 ? pm::PushLayout<25>::total : pm::PushLayout<11>::total);
     if (const char *t = getenv("GIPUMA_HIP_PUSH_LDS_KB")) lds = std::max(lds, (size_t)atoi(t) * 1024);  // experiment: fewer workgroups per CU
     if (!s->push_attr_set) {
-        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(pm::push_kernel<15>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         s->push_attr_set = true;
     }
-    hipLaunchKernelGGL(pm::push_kernel<15>, dim3(gx * gy), dim3(pm::kThreads), lds, s->stream, s->dp, s->norm4, colour,
-                       hist ? 1 : 0, s->tune);
+    hipLaunchKernelGGL(k, dim3(gx * gy), dim3(pm::kThreads), lds, s->stream, s->dp, s->norm4, colour, hist ? 1 : 0,
+                       s->tune);
     HIP_OK(hipGetLastError());
     s->push_valid = 1 - colour;
     s->push_hist = hist;
@@ -645,10 +647,11 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
             }
         }
     }
-    // push propagation (pm_push.h): box 15, register combiner, packed gray planes with float-encoded offsets
-    s->push_ok = s->u8 && s->ch == 1 && hp.magic_addr && s->box == 15 && s->combine_reg && s->n_sel > 0 &&
-                 !(s->tune & (Tune::kNoInterior | Tune::kNoSkip));
-    s->push_launches = 4;  // (measured on config C)
+    // push propagation (pm_push.h): box 11 / 15 / 25, register combiner, packed gray planes with float-encoded offsets
+    s->push_ok = s->u8 && s->ch == 1 && hp.magic_addr && (s->box == 11 || s->box == 15 || s->box == 25) &&
+                 s->combine_reg && s->n_sel > 0 && !(s->tune & (Tune::kNoInterior | Tune::kNoSkip));
+    // measured: config C 4 (5 and 6 level), config D 3 (4 level, 6 loses), config B 2 (+1 %)
+    s->push_launches = s->box == 15 ? 4 : s->box == 25 ? 3 : 2;
     if (const char *t = getenv("GIPUMA_HIP_PUSH_LAUNCHES")) s->push_launches = atoi(t);  // A/B runs: 0 = never
     if (s->push_launches <= 0) s->push_ok = false;
     if (s->push_ok) {

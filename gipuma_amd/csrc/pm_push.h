@@ -35,7 +35,9 @@
 // No workgroup barrier after the set-up: a group's dis values are written and read by lanes of one
 // wavefront (LDS operations of a wavefront complete in order).
 //
-// Supported: gray window-packed planes with float-encoded offsets, box 15, best-N with n_best <= 4.
+// Supported: gray window-packed planes with float-encoded offsets, box 11 / 15 / 25, best-N with
+// n_best <= 4.  Box 15 (8 window columns = 8 lanes) has its steps unrolled with compile-time stencil
+// positions; the other boxes run PushEval::family.
 #pragma once
 #include "pm_device.h"
 
@@ -47,17 +49,21 @@ constexpr int kPushGroups = kThreads / kPushLanes;    // producers evaluated con
 
 template <int BOX>
 struct PushLayout {  // offsets in 32-bit words into the dynamic LDS array
-    static_assert(BOX == 15, "8 window columns = 8 lanes");
+    static_assert(BOX == 11 || BOX == 15 || BOX == 25, "instantiated window sizes");
     static constexpr int R = (BOX - 1) / 2, N = R + 1;
-    static constexpr int FWH = N + kPushReach;        // 13: rows of the vertical family / columns of the horizontal one
+    static constexpr int FWH = N + kPushReach;        // box 15: 13 rows of the vertical family / columns of the horizontal one
     static constexpr int NF = N * FWH;                // 104 points per family
     static constexpr int halo = R + kPushReach + 1;   // 13: samples reach 12 texels, their gradients one more
     static constexpr int tw = kTileW + 2 * halo, th = kSweepTileH + 2 * halo;  // 58 x 42
     // only texels of the consumers' colour are ever sampled (producer + odd + even offsets): the tile
     // is stored checkerboard-compressed, entry (ty, tx >> 1)
-    static constexpr int twc = (tw + 1) / 2;          // 29 (odd: rows land in different banks)
-    static constexpr int hbase = NF;                  // horizontal family behind the vertical one
-    static constexpr int dstride = 2 * NF + 2;        // words per group (bank spread, scripts/exp/push_banks.py)
+    static constexpr int twc = ((tw + 1) / 2) | 1;    // 29 (odd: rows land in different banks)
+    // box 25: 2 x 234 samples per group would leave one workgroup per CU -- the group's buffer holds
+    // one family at a time, and the chain phase runs once per family (half of its lanes idle)
+    static constexpr bool two_pass = BOX > 15;
+    static constexpr int hbase = two_pass ? 0 : NF;   // horizontal family behind the vertical one
+    // words per group (bank spread of the chain reads, scripts/exp/push_banks.py)
+    static constexpr int dstride = BOX == 15 ? 2 * NF + 2 : BOX == 11 ? 2 * NF + 4 : NF + 2;
     static constexpr int tile4 = kLutSize;            // {I, gx1, gy1, I} per compressed texel
     static constexpr int iplane = tile4 + 4 * twc * th;  // I alone (conflict-free 4-byte reads of the chain)
     static constexpr int dis = iplane + twc * th;     // [kPushGroups][dstride]; before that the staging plane
@@ -65,6 +71,7 @@ struct PushLayout {  // offsets in 32-bit words into the dynamic LDS array
     static constexpr int cnt = list + kThreads / 2;
     static constexpr int total = cnt + 8;
     static_assert(tw * th <= kPushGroups * dstride, "the staging plane aliases the sample buffers");
+    static_assert(total * 4 <= 80 * 1024, "two workgroups per CU");
 };
 
 // consumer c of a producer = the pixel that meets the producer as its neighbour slot c
@@ -194,6 +201,96 @@ struct PushEval {
             __builtin_amdgcn_sched_barrier(0);
 #endif
         }
+    }
+
+    // ---- any box: one family of the stencil, W points per row, HH rows, first point at offset
+    //      (-OX, -OY) from the producer, dealt 8 consecutive points (row-major) per step.  The stream
+    //      position (row j0, first column r0 of a step) is wave-uniform; a lane is one or -- rows
+    //      shorter than 8 points -- two rows further when r0 + l runs past the row end.  Steps past the
+    //      end of the family (the prefetch) and the spare lanes of its last step compute harmless
+    //      points just outside it and store nothing. ----
+    template <bool FAST, int W, int HH, int OX, int OY>
+    __device__ __forceinline__ void family(const float *__restrict__ H, gptr_bytes magic_base,
+                                           const float *__restrict__ tile4, float *__restrict__ dfam, float nxf,
+                                           int tnx, int tny) const
+    {
+        constexpr int NFp = W * HH, SF = (NFp + kPushLanes - 1) / kPushLanes;
+        static_assert(2 * W >= kPushLanes, "at most two row wraps per step");
+        const float qx0 = nxf + (float)(2 * l - OX);
+        const float qy0 = nyf - (float)OY;
+        const int tbase = (tny - OY) * twc + ((tnx - OX) >> 1) + l;
+        struct Pos {
+            int r0, j0;
+        };
+        auto advance = [](Pos &p) {
+            p.r0 += kPushLanes;
+            if (p.r0 >= W) {
+                p.r0 -= W;
+                p.j0++;
+            }
+            if (W < kPushLanes && p.r0 >= W) {
+                p.r0 -= W;
+                p.j0++;
+            }
+        };
+        auto wraps = [&](const Pos &p, bool &w1, bool &w2) {
+            w1 = l >= W - p.r0;
+            w2 = W < kPushLanes && l >= 2 * W - p.r0;
+        };
+        auto issue_at = [&](const Pos &p) -> WinReq {
+            bool w1, w2;
+            wraps(p, w1, w2);
+            const float qx = qx0 + (float)(2 * p.r0) - (w1 ? (float)(2 * W) : 0.0f) - (w2 ? (float)(2 * W) : 0.0f);
+            const float qy = qy0 + (float)(2 * p.j0) + (w1 ? 2.0f : 0.0f) + (w2 ? 2.0f : 0.0f);
+            return request<FAST>(H, magic_base, qx, qy);
+        };
+        auto tile_at = [&](const Pos &p) -> int {
+            bool w1, w2;
+            wraps(p, w1, w2);
+            return tbase + p.r0 + 2 * twc * p.j0 + (w1 ? 2 * twc - W : 0) + (w2 ? 2 * twc - W : 0);
+        };
+        Pos pi{0, 0}, pr{0, 0};
+        WinReq req[PD];
+#pragma unroll
+        for (int p = 0; p < PD; p++) {
+            req[p] = issue_at(pi);
+            advance(pi);
+        }
+#pragma unroll 1
+        for (int sb = 0; sb < SF; sb += PD) {
+#pragma unroll
+            for (int p = 0; p < PD; p++) {
+                const int s = sb + p;
+                const WinReq cur = req[p];
+                req[p] = issue_at(pi);  // (unconditional: clamped, valid addresses past the end, dropped)
+                advance(pi);
+                if (s < SF) {
+                    const float4 t4 = *reinterpret_cast<const float4 *>(tile4 + 4 * tile_at(pr));
+                    const Taps tp5 = taps_u8(cur.a, cur.b, cur.w.x, cur.w.y, cur.w.z, cur.w.w);
+                    const float colDiff = t4.w - tp5.sc;
+                    const float gradX = t4.y - tp5.gx2;
+                    const float gradY = t4.z - tp5.gy2;
+                    const float gradDis = min_nc((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
+                    const float colDis = min_abs_nc(colDiff, tau_color);
+                    const int e = kPushLanes * s + l;
+                    if (e < NFp) dfam[e] = __builtin_fmaf(alpha, gradDis, oma * colDis);
+                }
+                advance(pr);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    template <bool FAST>
+    __device__ __forceinline__ void family_v(const float *__restrict__ H, gptr_bytes mb, const float *__restrict__ tile4,
+                                             float *__restrict__ dfam, float nxf, int tnx, int tny) const
+    {
+        family<FAST, LY::N, FWH, LY::R, LY::R + kPushReach>(H, mb, tile4, dfam, nxf, tnx, tny);
+    }
+    template <bool FAST>
+    __device__ __forceinline__ void family_h(const float *__restrict__ H, gptr_bytes mb, const float *__restrict__ tile4,
+                                             float *__restrict__ dfam, float nxf, int tnx, int tny) const
+    {
+        family<FAST, FWH, LY::N, LY::R + kPushReach, LY::R>(H, mb, tile4, dfam, nxf, tnx, tny);
     }
 };
 
@@ -331,8 +428,7 @@ __global__ __launch_bounds__(kThreads, PM_PUSH_WAVES) void push_kernel(const Pro
         float Hl[9], H[9];
         bool fast = false;
         gptr_bytes magic_base = nullptr;
-        WinReq req[kPushPD];
-        auto load_view = [&](int v) {
+        auto next_h = [&](int v) {
 #ifdef PM_PUSH_DIRECT_H
             homography(P->rc.K_inv, P->view[v], pl, H);  // (experiment: every lane, no exchange)
             (void)Hl;
@@ -345,22 +441,67 @@ __global__ __launch_bounds__(kThreads, PM_PUSH_WAVES) void push_kernel(const Pro
             const float reach = (float)(R + kPushReach);
             fast = __all(window_z_safe(H, nxf - reach, nxf + reach, nyf - reach, nyf + reach));
             magic_base = (gptr_bytes)((uintptr_t)P->view[v].packed - (uintptr_t)kMagicBits);
-            if (fast)
-                E.template first<true>(H, magic_base, req);
-            else
-                E.template first<false>(H, magic_base, req);
         };
-        load_view(0);
-        for (int v = 0; v < n; v++) {
-            if (fast)
-                E.template body<true>(H, magic_base, req, tile4, dgrp);
-            else
-                E.template body<false>(H, magic_base, req, tile4, dgrp);
-            if (v + 1 < n) load_view(v + 1);  // the next view's first windows travel during the chain
-            __builtin_amdgcn_wave_barrier();  // (the group's samples are read by other lanes of this wavefront)
-            const float c = push_chain<BOX>(ipl, centre, lut_magic, dgrp + dbase, jstride);
-            __builtin_amdgcn_wave_barrier();
-            comb.add(c, v, nullptr);
+#ifdef PM_PUSH_GENERIC15
+        if constexpr (false) {
+#else
+        if constexpr (BOX == 15) {
+#endif
+            WinReq req[kPushPD];
+            auto load_view = [&](int v) {
+                next_h(v);
+                if (fast)
+                    E.template first<true>(H, magic_base, req);
+                else
+                    E.template first<false>(H, magic_base, req);
+            };
+            load_view(0);
+            for (int v = 0; v < n; v++) {
+                if (fast)
+                    E.template body<true>(H, magic_base, req, tile4, dgrp);
+                else
+                    E.template body<false>(H, magic_base, req, tile4, dgrp);
+                if (v + 1 < n) load_view(v + 1);  // the next view's first windows travel during the chain
+                __builtin_amdgcn_wave_barrier();  // (the group's samples are read by other lanes of this wavefront)
+                const float c = push_chain<BOX>(ipl, centre, lut_magic, dgrp + dbase, jstride);
+                __builtin_amdgcn_wave_barrier();
+                comb.add(c, v, nullptr);
+            }
+        } else {
+            for (int v = 0; v < n; v++) {
+                next_h(v);
+                float c;
+                if constexpr (LY::two_pass) {
+                    if (fast)
+                        E.template family_v<true>(H, magic_base, tile4, dgrp, nxf, tnx, tny);
+                    else
+                        E.template family_v<false>(H, magic_base, tile4, dgrp, nxf, tnx, tny);
+                    __builtin_amdgcn_wave_barrier();
+                    // (lanes of the other family read in-bounds values they do not use)
+                    const float cv_ = push_chain<BOX>(ipl, centre, lut_magic, dgrp + dbase, jstride);
+                    __builtin_amdgcn_wave_barrier();
+                    if (fast)
+                        E.template family_h<true>(H, magic_base, tile4, dgrp, nxf, tnx, tny);
+                    else
+                        E.template family_h<false>(H, magic_base, tile4, dgrp, nxf, tnx, tny);
+                    __builtin_amdgcn_wave_barrier();
+                    const float ch_ = push_chain<BOX>(ipl, centre, lut_magic, dgrp + dbase, jstride);
+                    __builtin_amdgcn_wave_barrier();
+                    c = cdx == 0 ? cv_ : ch_;
+                } else {
+                    if (fast) {
+                        E.template family_v<true>(H, magic_base, tile4, dgrp, nxf, tnx, tny);
+                        E.template family_h<true>(H, magic_base, tile4, dgrp + LY::hbase, nxf, tnx, tny);
+                    } else {
+                        E.template family_v<false>(H, magic_base, tile4, dgrp, nxf, tnx, tny);
+                        E.template family_h<false>(H, magic_base, tile4, dgrp + LY::hbase, nxf, tnx, tny);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    c = push_chain<BOX>(ipl, centre, lut_magic, dgrp + dbase, jstride);
+                    __builtin_amdgcn_wave_barrier();
+                }
+                comb.add(c, v, nullptr);
+            }
         }
         const float F = comb.finish(P, n, nullptr);
         if (cvalid) P->push_cost[(size_t)l * np + (size_t)(cpy * cols + cpx)] = F;

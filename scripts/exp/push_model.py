@@ -95,5 +95,83 @@ def main():
         assert (co[0] + off[0], co[1] + off[1]) == (0, 0)
     print("push index model: ok")
 
-if __name__ == "__main__":
+# ---- PushEval::family, the loop used for boxes other than 15 (and checked for 15 as well) ----
+def family_points(W, HH, OX, OY, twc, tnx, tny):
+    """what the kernel's stream computes: {slot: (offset from the producer, compressed tile index)}"""
+    NFp = W * HH
+    SF = (NFp + 7) // 8
+    out = {}
+    r0 = j0 = 0
+    for s in range(SF):
+        for l in range(8):
+            w1 = 1 if l >= W - r0 else 0
+            w2 = 1 if (W < 8 and l >= 2 * W - r0) else 0
+            dqx = (2 * l - OX) + 2 * r0 - 2 * W * w1 - 2 * W * w2
+            dqy = -OY + 2 * j0 + 2 * w1 + 2 * w2
+            tbase = (tny - OY) * twc + ((tnx - OX) >> 1) + l
+            tix = tbase + r0 + 2 * twc * j0 + (2 * twc - W) * (w1 + w2)
+            e = 8 * s + l
+            if e < NFp:
+                assert e not in out
+                out[e] = ((dqx, dqy), tix)
+        r0 += 8
+        if r0 >= W:
+            r0 -= W
+            j0 += 1
+        if W < 8 and r0 >= W:
+            r0 -= W
+            j0 += 1
+    assert sorted(out) == list(range(NFp))
+    return out
+
+
+def check_generic(box):
+    n = (box + 1) // 2
+    r = n - 1
+    fwh = n + REACH
+    nf = n * fwh
+    halo = r + REACH + 1
+    tw, th = TILE_W + 2 * halo, TILE_H + 2 * halo
+    twc = ((tw + 1) // 2) | 1
+    two_pass = box > 15
+    hbase = 0 if two_pass else nf
+    for colour in (0, 1):
+        cpar = 1 - colour
+        comp = {}
+        for ty in range(th):
+            for cx in range(twc):
+                tx = 2 * cx + ((cpar + ty) & 1)
+                comp[ty * twc + cx] = (tx, ty) if tx < tw else None
+        for ly in range(TILE_H):
+            for lxh in range(16):
+                lx = 2 * lxh + ((ly + colour) & 1)
+                tnx, tny = lx + halo, ly + halo
+                fam_v = family_points(n, fwh, r, r + REACH, twc, tnx, tny)
+                fam_h = family_points(fwh, n, r + REACH, r, twc, tnx, tny)
+                for fam in (fam_v, fam_h):
+                    for e, ((dx, dy), tix) in fam.items():
+                        assert comp[tix] == (tnx + dx, tny + dy), (box, e)
+                        assert 1 <= tnx + dx <= tw - 2 and 1 <= tny + dy <= th - 2
+                for c in range(8):
+                    cdx, cdy = consumer_offset(c)
+                    tpx, tpy = tnx + cdx, tny + cdy
+                    assert comp[tpy * twc + (tpx >> 1)] == (tpx, tpy)
+                    dbase = ((cdy + REACH) // 2) * n if cdx == 0 else hbase + (cdx + REACH) // 2
+                    jstride = n if cdx == 0 else fwh
+                    fam, off = (fam_v, 0) if cdx == 0 else (fam_h, hbase)
+                    for i, j in itertools.product(range(n), range(n)):
+                        q = (cdx + 2 * i - r, cdy + 2 * j - r)
+                        slot = dbase + j * jstride + i
+                        assert fam[slot - off][0] == q, (box, c, i, j)
+                        assert comp[(tpy - r) * twc + ((tpx - r) >> 1) + 2 * j * twc + i] == (tnx + q[0], tny + q[1])
+    print("push family model, box %d: ok" % box)
+
+
+def main_all():
     main()
+    for box in (11, 15, 25):
+        check_generic(box)
+
+
+if __name__ == "__main__":
+    main_all()

@@ -380,6 +380,22 @@ def test_push_propagation_is_bit_identical(hip, push):
         assert_same(a[1], o[1], "default vs oracle cost")
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(cols=96, rows=80, n_src=3, blocksize=11, iterations=4, n_best=2),    # rows of 6 points: two wraps per step
+    dict(cols=130, rows=70, n_src=4, blocksize=25, iterations=3, n_best=3),   # one family at a time in LDS
+    dict(cols=45, rows=37, n_src=9, blocksize=25, iterations=2, n_best=4),    # ragged, two homography blocks
+    dict(cols=40, rows=33, n_src=2, blocksize=11, iterations=3, n_best=1),
+])
+def test_push_propagation_other_boxes(hip, cfg):
+    """boxes 11 and 25 run the push kernel's generic stencil loop (PushEval::family; box 25 with one
+    family of the stencil in LDS at a time): every half-sweep pushed, against the oracle"""
+    gs, _ = synth.build_problem(synth.tiny_config(**cfg))
+    n4, c = _with_env({"GIPUMA_HIP_PUSH_LAUNCHES": 100}, lambda: runcuda(gs))
+    o_n4, o_c = OracleState(gs).run()
+    assert_same(n4, o_n4, "push box %d norm4" % cfg["blocksize"])
+    assert_same(c, o_c, "push box %d cost" % cfg["blocksize"])
+
+
 @pytest.mark.parametrize("cols,rows,sel,over", [
     (33, 17, [1, 2, 3], dict(n_best=2)),                   # ragged, smaller than a tile
     (21, 9, [1, 2], dict(n_best=1)),                       # smaller than the window and the stencil

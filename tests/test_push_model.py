@@ -16,7 +16,7 @@ def _load(name):
 
 
 def test_push_index_model():
-    _load("push_model").main()
+    _load("push_model").main_all()
 
 
 def test_push_sample_buffer_layout_is_at_most_two_way_conflicted():
