@@ -22,8 +22,10 @@ FETCH_SIZE
 WRITE_SIZE
 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT
 LIST
-# all 16 half-sweep launches of a view (both kernels), then each kernel on its own
-python $R/scripts/rocprof_summary.py pmc $OUT sweep_ > $OUT/pmc_summary.json
+# per half-sweep of a view (16: a sweep kernel each + pm::push_kernel where the costs are pushed), then
+# each kernel on its own (mean per dispatch)
+python $R/scripts/rocprof_summary.py pmcunits $OUT ${PMC_UNITS:-16} sweep_ push_kernel > $OUT/pmc_summary.json
+python $R/scripts/rocprof_summary.py pmc $OUT push_kernel > $OUT/pmc_summary_push.json
 python $R/scripts/rocprof_summary.py pmc $OUT sweep_kernel > $OUT/pmc_summary_pixel_per_lane.json
 python $R/scripts/rocprof_summary.py pmc $OUT sweep_cols_kernel > $OUT/pmc_summary_column_per_lane.json
 python $R/scripts/rocprof_summary.py pmc $OUT init_kernel > $OUT/pmc_summary_init.json

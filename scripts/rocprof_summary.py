@@ -4,6 +4,7 @@ profiles/.
 
     python scripts/rocprof_summary.py stats  <results.db>            # per-kernel time table
     python scripts/rocprof_summary.py pmc    <dir-with-pmc*_results.db> [kernel-substring]
+    python scripts/rocprof_summary.py pmcunits <dir> <n_units> <kernel-substring> [...]   # sums / n_units
 
 `pmc` prints, for kernels whose name contains the substring (default "sweep_kernel"), the mean
 per-dispatch value of every collected counter plus the derived figures used in DESIGN.md.
@@ -65,6 +66,47 @@ def pmc(d, sub="sweep_kernel"):
     print(json.dumps(res, indent=1, sort_keys=True))
 
 
+def pmc_units(d, n_units, subs):
+    """per-UNIT counter values: the sum over every dispatch whose kernel name contains one of `subs`,
+    divided by n_units -- e.g. the 16 half-sweeps of a view, each of which is one sweep kernel plus,
+    where the propagation costs are pushed, one pm::push_kernel (17 + 4 dispatches)"""
+    vals, dur, ndisp = {}, [], 0
+    where = " or ".join(["kernel_name like ?"] * len(subs))
+    where_k = " or ".join(["name like ?"] * len(subs))
+    args = ["%" + x + "%" for x in subs]
+    for db in sorted(glob.glob(os.path.join(d, "*_results.db"))):
+        cur = sqlite3.connect(db).cursor()
+        try:
+            for name, v, n in cur.execute("select counter_name, sum(value), count(*) from counters_collection "
+                                          "where %s group by counter_name" % where, args):
+                vals[name] = v / n_units
+                ndisp = max(ndisp, n)
+            for (a,) in cur.execute("select sum(duration) from kernels where %s" % where_k, args):
+                if a:
+                    dur.append(a / 1e6 / n_units)
+        except sqlite3.Error as e:
+            print("skip", db, e)
+    res = dict(vals)
+    res["_units"] = n_units
+    res["_dispatches_per_counter"] = ndisp
+    res["_kernels"] = subs
+    res["_kernel_ms_profiled_mean"] = sum(dur) / len(dur) if dur else None
+    g = res.get
+    if g("FETCH_SIZE") is not None:
+        res["hbm_read_bytes_per_launch_x2corr"] = 2.0 * g("FETCH_SIZE") * 1024.0
+    if g("WRITE_SIZE") is not None:
+        res["hbm_write_bytes_per_launch"] = g("WRITE_SIZE") * 1024.0
+    if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None:
+        res["l2_hit_rate"] = g("TCC_HIT_sum") / max(1.0, g("TCC_HIT_sum") + g("TCC_MISS_sum"))
+    if g("TCP_TOTAL_CACHE_ACCESSES_sum") and g("TCP_TCC_READ_REQ_sum") is not None:
+        res["l1_hit_rate_est"] = 1.0 - g("TCP_TCC_READ_REQ_sum") / g("TCP_TOTAL_CACHE_ACCESSES_sum")
+    if g("SQ_WAVE_CYCLES") and g("SQ_ACTIVE_INST_VALU") is not None:
+        res["valu_active_frac_of_wave_cycles"] = g("SQ_ACTIVE_INST_VALU") / g("SQ_WAVE_CYCLES")
+    if g("SQ_WAVE_CYCLES") and g("SQ_WAIT_ANY") is not None:
+        res["wait_any_frac_of_wave_cycles"] = g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES")
+    print(json.dumps(res, indent=1, sort_keys=True))
+
+
 def series(db, sub="sweep_kernel"):
     """durations of consecutive dispatches of one kernel, in launch order"""
     cur = sqlite3.connect(db).cursor()
@@ -101,6 +143,8 @@ if __name__ == "__main__":
         stats(sys.argv[2])
     elif sys.argv[1] == "pmcseries":
         pmcseries(sys.argv[2], *(sys.argv[3:4]))
+    elif sys.argv[1] == "pmcunits":  # pmcunits <dir> <n_units> <substring> [...]
+        pmc_units(sys.argv[2], int(sys.argv[3]), sys.argv[4:])
     elif sys.argv[1] == "series":
         series(sys.argv[2], *(sys.argv[3:4]))
     else:
