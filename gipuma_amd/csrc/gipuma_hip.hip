@@ -210,9 +210,14 @@ int launch_push(gipuma_hip_session *s, int colour, bool hist)
     const int gx = (s->cols + pm::kTileW - 1) / pm::kTileW;
     const int gy = (s->rows + pm::kSweepTileH - 1) / pm::kSweepTileH;
     typedef void (*push_fn)(const pm::Problem *, const float4 *, int, int, unsigned);
-    const push_fn k = s->box == 15 ? pm::push_kernel<15> : s->box == 25 ? pm::push_kernel<25> : pm::push_kernel<11>;
-    size_t lds = sizeof(float) * (size_t)(s->box == 15 ? pm::PushLayout<15>::total
-                                          : s->box == 25 ? pm::PushLayout<25>::total : pm::PushLayout<11>::total);
+    const push_fn k = s->ch == 4    ? pm::push_kernel_c4<15>
+                      : s->box == 15 ? pm::push_kernel<15>
+                      : s->box == 25 ? pm::push_kernel<25>
+                                     : pm::push_kernel<11>;
+    size_t lds = sizeof(float) * (size_t)(s->ch == 4      ? pm::PushLayoutC4<15>::total
+                                          : s->box == 15 ? pm::PushLayout<15>::total
+                                          : s->box == 25 ? pm::PushLayout<25>::total
+                                                         : pm::PushLayout<11>::total);
     if (const char *t = getenv("GIPUMA_HIP_PUSH_LDS_KB")) lds = std::max(lds, (size_t)atoi(t) * 1024);  // experiment: fewer workgroups per CU
     if (!s->push_attr_set) {
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -648,10 +653,13 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         }
     }
     // push propagation (pm_push.h): box 11 / 15 / 25, register combiner, packed gray planes with float-encoded offsets
-    s->push_ok = s->u8 && s->ch == 1 && hp.magic_addr && (s->box == 11 || s->box == 15 || s->box == 25) &&
-                 s->combine_reg && s->n_sel > 0 && !(s->tune & (Tune::kNoInterior | Tune::kNoSkip));
+    // ... or colour (three words per texel, integer addressing), box 15
+    s->push_ok = s->u8 && s->combine_reg && s->n_sel > 0 && !(s->tune & (Tune::kNoInterior | Tune::kNoSkip)) &&
+                 ((s->ch == 1 && hp.magic_addr && (s->box == 11 || s->box == 15 || s->box == 25)) ||
+                  (s->ch == 4 && s->box == 15));
     // measured: config C 4 (5 and 6 level), config D 3 (4 level, 6 loses), config B 2 (+1 %)
-    s->push_launches = s->box == 15 ? 4 : s->box == 25 ? 3 : 2;
+    // colour (config C geometry): 6 (4: -1.3 %, 8: -0.7 %, 16: -7 %)
+    s->push_launches = s->ch == 4 ? 6 : s->box == 15 ? 4 : s->box == 25 ? 3 : 2;
     if (const char *t = getenv("GIPUMA_HIP_PUSH_LAUNCHES")) s->push_launches = atoi(t);  // A/B runs: 0 = never
     if (s->push_launches <= 0) s->push_ok = false;
     if (s->push_ok) {

@@ -103,6 +103,7 @@ __device__ __forceinline__ void push_consumer_offset(int c, int &dx, int &dy)
 #define PM_PUSH_WAVES 2
 #endif
 constexpr int kPushPD = PM_PUSH_PD;
+constexpr int kPushPDFamily = 2;  // PushEval::family (boxes 11, 25; colour): 2 / 4 / 8 within 1.5 % on config D, 2 best
 template <int BOX>
 struct PushEval {
     using LY = PushLayout<BOX>;
@@ -249,6 +250,7 @@ struct PushEval {
             wraps(p, w1, w2);
             return tbase + p.r0 + 2 * twc * p.j0 + (w1 ? 2 * twc - W : 0) + (w2 ? 2 * twc - W : 0);
         };
+        constexpr int PD = kPushPDFamily;
         Pos pi{0, 0}, pr{0, 0};
         WinReq req[PD];
 #pragma unroll
@@ -276,7 +278,9 @@ struct PushEval {
                     if (e < NFp) dfam[e] = __builtin_fmaf(alpha, gradDis, oma * colDis);
                 }
                 advance(pr);
+#ifndef PM_PUSH_NO_SCHED_BARRIER
                 __builtin_amdgcn_sched_barrier(0);
+#endif
             }
         }
     }
@@ -463,7 +467,11 @@ __global__ __launch_bounds__(kThreads, PM_PUSH_WAVES) void push_kernel(const Pro
                     E.template body<false>(H, magic_base, req, tile4, dgrp);
                 if (v + 1 < n) load_view(v + 1);  // the next view's first windows travel during the chain
                 __builtin_amdgcn_wave_barrier();  // (the group's samples are read by other lanes of this wavefront)
+#ifdef PM_PUSH_EXP_NOCHAIN  // timing experiment only (wrong results): what the chain phase costs
+                const float c = dgrp[dbase + (v & 63)];
+#else
                 const float c = push_chain<BOX>(ipl, centre, lut_magic, dgrp + dbase, jstride);
+#endif
                 __builtin_amdgcn_wave_barrier();
                 comb.add(c, v, nullptr);
             }
@@ -502,6 +510,283 @@ __global__ __launch_bounds__(kThreads, PM_PUSH_WAVES) void push_kernel(const Pro
                 }
                 comb.add(c, v, nullptr);
             }
+        }
+        const float F = comb.finish(P, n, nullptr);
+        if (cvalid) P->push_cost[(size_t)l * np + (size_t)(cpy * cols + cpx)] = F;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same kernel for -color_processing (T = float4, gipuma.cu:1965-1968; view_cost_c4_loop in
+// pm_device.h): three 16-byte window loads and three tap sets per stencil point, l1_norm(float4)
+// reductions in the reference's order, support weights from the 766-entry table indexed by the
+// integer |dB|+|dG|+|dR|.  Integer window addressing (three words per texel do not fit the
+// float-encoded offsets).  The reference tile holds, per texel of the consumers' colour, {B, G, R}
+// and the central differences right-left, down-up of each channel (the reference-side terms of
+// pmCostComputation_shared, gipuma.cu:254-259) -- the neighbours themselves have the other parity and
+// are not kept.  Box 15, packed 8-bit planes, best-N with n_best <= 4.
+// ---------------------------------------------------------------------------------------------
+template <int BOX>
+struct PushLayoutC4 {
+    static_assert(BOX == 15, "instantiated window size");
+    using G = PushLayout<BOX>;
+    static constexpr int R = G::R, N = G::N, FWH = G::FWH, NF = G::NF, halo = G::halo, tw = G::tw, th = G::th, twc = G::twc;
+    static constexpr int hbase = NF, dstride = G::dstride;
+    static constexpr int tile_a = lut_size<4>();           // float4 {B, G, R, gxB} per compressed texel
+    static constexpr int tile_b = tile_a + 4 * twc * th;   // float4 {gxG, gxR, gyB, gyG}
+    static constexpr int tile_c = tile_b + 4 * twc * th;   // float gyR
+    static constexpr int dis = tile_c + twc * th;
+    static constexpr int list = dis + kPushGroups * dstride;
+    static constexpr int cnt = list + kThreads / 2;
+    static constexpr int total = cnt + 8;
+    static_assert(total * 4 <= 80 * 1024, "two workgroups per CU");
+};
+
+struct WinReqC4 {
+    float a, b;
+    u32x4_a4 q0, q1, q2;
+};
+
+template <int BOX>
+struct PushEvalC4 {
+    using LY = PushLayoutC4<BOX>;
+    static constexpr int FWH = LY::FWH, twc = LY::twc;
+    float alpha, oma, tau_color, tau_gradient;
+    uint32_t pw, xmax, ymax;
+    float nyf;
+    int l;
+
+    __device__ __forceinline__ void init(const Problem *__restrict__ P, int lane_in_group)
+    {
+        alpha = P->alpha;
+        oma = 1.f - P->alpha;
+        tau_color = P->tau_color;
+        tau_gradient = P->tau_gradient;
+        pw = (uint32_t)P->pw;
+        xmax = (uint32_t)(P->cols + 2);
+        ymax = (uint32_t)(P->rows + 2);
+        l = lane_in_group;
+    }
+    template <bool FAST>
+    __device__ __forceinline__ WinReqC4 request(const float *__restrict__ H, gptr_bytes packed, float qx, float qy) const
+    {
+        const float X = __builtin_fmaf(H[1], qy, __builtin_fmaf(H[0], qx, H[2]));
+        const float Y = __builtin_fmaf(H[4], qy, __builtin_fmaf(H[3], qx, H[5]));
+        const float Z = __builtin_fmaf(H[7], qy, __builtin_fmaf(H[6], qx, H[8]));
+        const float rz = recip<FAST>(Z);
+        const float sx = X * rz, sy = Y * rz;
+        const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
+        WinReqC4 r;
+        r.a = sx - fx0;
+        r.b = sy - fy0;
+        const uint32_t Xw = min(cvt_u32_sat(fx0 + 2.0f), xmax);
+        const uint32_t Yw = min(cvt_u32_sat(fy0 + 2.0f), ymax);
+        const gptr_bytes base = packed + (Yw * pw + Xw) * 12u;
+        r.q0 = *(gptr_u32x4)(base);
+        r.q1 = *(gptr_u32x4)(base + 16);
+        r.q2 = *(gptr_u32x4)(base + 32);
+        return r;
+    }
+    // one family of the stencil: the stream of PushEval::family with the colour request / reduction
+    template <bool FAST, int W, int HH, int OX, int OY>
+    __device__ __forceinline__ void family(const float *__restrict__ H, gptr_bytes packed, const float *__restrict__ lds,
+                                           float *__restrict__ dfam, float nxf, int tnx, int tny) const
+    {
+        constexpr int NFp = W * HH, SF = (NFp + kPushLanes - 1) / kPushLanes;
+        static_assert(W >= kPushLanes, "one row wrap per step");
+        const float qx0 = nxf + (float)(2 * l - OX);
+        const float qy0 = nyf - (float)OY;
+        const int tbase = (tny - OY) * twc + ((tnx - OX) >> 1) + l;
+        struct Pos {
+            int r0, j0;
+        };
+        auto advance = [](Pos &p) {
+            p.r0 += kPushLanes;
+            if (p.r0 >= W) {
+                p.r0 -= W;
+                p.j0++;
+            }
+        };
+        auto issue_at = [&](const Pos &p) -> WinReqC4 {
+            const bool w1 = l >= W - p.r0;
+            const float qx = qx0 + (float)(2 * p.r0) - (w1 ? (float)(2 * W) : 0.0f);
+            const float qy = qy0 + (float)(2 * p.j0) + (w1 ? 2.0f : 0.0f);
+            return request<FAST>(H, packed, qx, qy);
+        };
+        auto tile_at = [&](const Pos &p) -> int {
+            const bool w1 = l >= W - p.r0;
+            return tbase + p.r0 + 2 * twc * p.j0 + (w1 ? 2 * twc - W : 0);
+        };
+        constexpr int PD = kPushPDFamily;
+        Pos pi{0, 0}, pr{0, 0};
+        WinReqC4 req[PD];
+#pragma unroll
+        for (int p = 0; p < PD; p++) {
+            req[p] = issue_at(pi);
+            advance(pi);
+        }
+#pragma unroll 1
+        for (int sb = 0; sb < SF; sb += PD) {
+#pragma unroll
+            for (int p = 0; p < PD; p++) {
+                const int s = sb + p;
+                const WinReqC4 cur = req[p];
+                req[p] = issue_at(pi);  // (unconditional: clamped, valid addresses past the end, dropped)
+                advance(pi);
+                if (s < SF) {
+                    const int k = tile_at(pr);
+                    const float4 ta = *reinterpret_cast<const float4 *>(lds + LY::tile_a + 4 * k);  // B, G, R, gxB
+                    const float4 tb = *reinterpret_cast<const float4 *>(lds + LY::tile_b + 4 * k);  // gxG, gxR, gyB, gyG
+                    const float tc = lds[LY::tile_c + k];                                           // gyR
+                    // word 3k+c = column k, channel c (view_cost_c4_loop)
+                    Taps t[3];
+                    t[0] = taps_u8(cur.a, cur.b, cur.q0.x, cur.q0.w, cur.q1.z, cur.q2.y);
+                    t[1] = taps_u8(cur.a, cur.b, cur.q0.y, cur.q1.x, cur.q1.w, cur.q2.z);
+                    t[2] = taps_u8(cur.a, cur.b, cur.q0.z, cur.q1.y, cur.q2.x, cur.q2.w);
+                    // pmCostComputation_shared for T = float4, gipuma.cu:251-274
+                    const float colDiff = l1_3(ta.x - t[0].sc, ta.y - t[1].sc, ta.z - t[2].sc);
+                    const float gX = l1_3(ta.w - t[0].gx2, tb.x - t[1].gx2, tb.y - t[2].gx2);
+                    const float gY = l1_3(tb.z - t[0].gy2, tb.w - t[1].gy2, tc - t[2].gy2);
+                    const float gradDis = min_nc((gX + gY) * 0.0625f, tau_gradient);
+                    const float colDis = min_nc(colDiff, tau_color);
+                    const int e = kPushLanes * s + l;
+                    if (e < NFp) dfam[e] = __builtin_fmaf(alpha, gradDis, oma * colDis);
+                }
+                advance(pr);
+#ifndef PM_PUSH_NO_SCHED_BARRIER
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+        }
+    }
+};
+
+// the reference's summation for one consumer, T = float4: weight table indexed by |dB|+|dG|+|dR|
+template <int BOX>
+__device__ __forceinline__ float push_chain_c4(const float *__restrict__ ta, float4 centre, const float *__restrict__ lut,
+                                               const float *__restrict__ dch, int jstride)
+{
+    using LY = PushLayoutC4<BOX>;
+    float cost = 0.0f;
+#pragma unroll 1
+    for (int i = 0; i < LY::N; i++)
+#pragma unroll
+        for (int j = 0; j < LY::N; j++) {
+            const float4 lv = *reinterpret_cast<const float4 *>(ta + 4 * (2 * j * LY::twc + i));
+            const float S = __builtin_fabsf(lv.x - centre.x) + __builtin_fabsf(lv.y - centre.y) +
+                            __builtin_fabsf(lv.z - centre.z);  // exact integer 0..765
+            cost = __builtin_fmaf(lut[(int)S], dch[j * jstride + i], cost);
+        }
+    return cost;
+}
+
+template <int BOX>
+__global__ __launch_bounds__(kThreads, PM_PUSH_WAVES) void push_kernel_c4(const Problem *__restrict__ P,
+                                                              const float4 *__restrict__ norm4, int colour, int hist,
+                                                              unsigned tune)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using LY = PushLayoutC4<BOX>;
+    constexpr int R = LY::R, N = LY::N, twc = LY::twc, halo = LY::halo;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rows = P->rows, cols = P->cols;
+    const int gx = (cols + kTileW - 1) / kTileW;
+    const int gy = (rows + kSweepTileH - 1) / kSweepTileH;
+    const TileXY txy = tile_of(blockIdx.x, gx, gy, tune);
+    const int x0 = txy.x * kTileW, y0 = txy.y * kSweepTileH;
+    unsigned short *list = reinterpret_cast<unsigned short *>(lds + LY::list);
+    int *cnt = reinterpret_cast<int *>(lds + LY::cnt);
+
+    // ---- producers of this tile with something to offer ----
+    const int ly = tid >> 4, lx = 2 * (tid & 15) + ((ly + colour) & 1);
+    const int px = x0 + lx, py = y0 + ly;
+    const bool inside = px < cols && py < rows;
+    const bool live = inside && (!hist || P->changed[py * cols + px] != 0);
+    const unsigned long long bal = __ballot(live);
+    if (lane == 0) cnt[wave] = (int)__popcll(bal);
+
+    // ---- reference tile: texels of the consumers' colour, clamp-to-edge point samples like the
+    //      reference's (gipuma.cu:1393-1402), each with its channel-wise central differences ----
+    {
+        const gptr_f32 ref = (gptr_f32)P->ref;
+        const int pitch = P->pitch;
+        const int cpar = 1 - colour;
+        for (int k = tid; k < lut_size<4>(); k += kThreads) lds[k] = exp_model(-((float)k * 0.3333333f) / P->gamma);
+        for (int k = tid; k < twc * LY::th; k += kThreads) {
+            const int ty = k / twc, cx = k - ty * twc;
+            const int tx = 2 * cx + ((cpar + ty) & 1);
+            const int gxp = x0 - halo + tx, gyp = y0 - halo + ty;
+            const int xc = clampi(gxp, 0, cols - 1), xl = clampi(gxp - 1, 0, cols - 1), xr = clampi(gxp + 1, 0, cols - 1);
+            const int yc = clampi(gyp, 0, rows - 1), yu = clampi(gyp - 1, 0, rows - 1), yd = clampi(gyp + 1, 0, rows - 1);
+            const gptr_f32 c = ref + (yc * pitch + 4 * xc);
+            const gptr_f32 le = ref + (yc * pitch + 4 * xl), ri = ref + (yc * pitch + 4 * xr);
+            const gptr_f32 up = ref + (yu * pitch + 4 * xc), dn = ref + (yd * pitch + 4 * xc);
+            *reinterpret_cast<float4 *>(lds + LY::tile_a + 4 * k) = make_float4(c[0], c[1], c[2], ri[0] - le[0]);
+            *reinterpret_cast<float4 *>(lds + LY::tile_b + 4 * k) =
+                make_float4(ri[1] - le[1], ri[2] - le[2], dn[0] - up[0], dn[1] - up[1]);
+            lds[LY::tile_c + k] = dn[2] - up[2];
+        }
+    }
+    __syncthreads();
+    const int c0 = cnt[0], c1 = cnt[1], c2 = cnt[2], c3 = cnt[3];
+    const int n_live = c0 + c1 + c2 + c3;
+    if (live) {
+        const int first = (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+        list[first + rank] = (unsigned short)tid;
+    }
+    __syncthreads();
+    if (n_live == 0) return;
+
+    const int n = P->n_sel;
+    const size_t np = (size_t)rows * (size_t)cols;
+    const int grp = tid / kPushLanes, l = tid % kPushLanes;
+    const int grp_lane0 = lane & ~(kPushLanes - 1);
+    float *dgrp = lds + LY::dis + grp * LY::dstride;
+    int cdx, cdy;
+    push_consumer_offset(l, cdx, cdy);
+    const int dbase = cdx == 0 ? ((cdy + kPushReach) / 2) * N : LY::hbase + (cdx + kPushReach) / 2;
+    const int jstride = cdx == 0 ? N : LY::FWH;
+    PushEvalC4<BOX> E;
+    E.init(P, l);
+
+    for (int r = 0; r * kPushGroups < n_live; r++) {
+        const int idx = r * kPushGroups + grp;
+        const bool have = idx < n_live;
+        if (!__any(have)) break;
+        const int ptid = (int)list[have ? idx : 0];
+        const int oly = ptid >> 4, olx = 2 * (ptid & 15) + ((oly + colour) & 1);
+        const int npx = x0 + olx, npy = y0 + oly;
+        const float4 pl = norm4[npy * cols + npx];
+        const int tnx = olx + halo, tny = oly + halo;
+        const float nxf = (float)npx, nyf = (float)npy;
+        E.nyf = nyf;
+        const int cpx = npx + cdx, cpy = npy + cdy;
+        const bool cvalid = have && cpx >= 0 && cpx < cols && cpy >= 0 && cpy < rows;
+        const int tpx = tnx + cdx, tpy = tny + cdy;
+        const float4 centre = *reinterpret_cast<const float4 *>(lds + LY::tile_a + 4 * (tpy * twc + (tpx >> 1)));
+        const float *ta_c = lds + LY::tile_a + 4 * ((tpy - R) * twc + ((tpx - R) >> 1));
+
+        ViewCombiner<true> comb;
+        float Hl[9], H[9];
+        for (int v = 0; v < n; v++) {
+            if ((v & (kPushLanes - 1)) == 0) homography(P->rc.K_inv, P->view[min(v + l, n - 1)], pl, Hl);
+#pragma unroll
+            for (int k = 0; k < 9; k++) H[k] = __shfl(Hl[k], grp_lane0 + (v & (kPushLanes - 1)));
+            const float reach = (float)(R + kPushReach);
+            const bool fast = __all(window_z_safe(H, nxf - reach, nxf + reach, nyf - reach, nyf + reach));
+            const gptr_bytes packed = (gptr_bytes)P->view[v].packed;
+            if (fast) {
+                E.template family<true, N, LY::FWH, R, R + kPushReach>(H, packed, lds, dgrp, nxf, tnx, tny);
+                E.template family<true, LY::FWH, N, R + kPushReach, R>(H, packed, lds, dgrp + LY::hbase, nxf, tnx, tny);
+            } else {
+                E.template family<false, N, LY::FWH, R, R + kPushReach>(H, packed, lds, dgrp, nxf, tnx, tny);
+                E.template family<false, LY::FWH, N, R + kPushReach, R>(H, packed, lds, dgrp + LY::hbase, nxf, tnx, tny);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const float c = push_chain_c4<BOX>(ta_c, centre, lds, dgrp + dbase, jstride);
+            __builtin_amdgcn_wave_barrier();
+            comb.add(c, v, nullptr);
         }
         const float F = comb.finish(P, n, nullptr);
         if (cvalid) P->push_cost[(size_t)l * np + (size_t)(cpy * cols + cpx)] = F;

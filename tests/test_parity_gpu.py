@@ -380,6 +380,22 @@ def test_push_propagation_is_bit_identical(hip, push):
         assert_same(a[1], o[1], "default vs oracle cost")
 
 
+@pytest.mark.parametrize("cfg,push", [
+    (dict(cols=112, rows=80, n_src=4, blocksize=15, iterations=4, n_best=3), 100),
+    (dict(cols=112, rows=80, n_src=4, blocksize=15, iterations=4, n_best=3), 3),
+    (dict(cols=45, rows=37, n_src=9, blocksize=15, iterations=2, n_best=2), 100),   # ragged, two homography blocks
+    (dict(cols=70, rows=21, n_src=1, blocksize=15, iterations=3, n_best=1), 100),
+])
+def test_push_propagation_colour(hip, cfg, push):
+    """-color_processing (T = float4): pm::push_kernel_c4 -- three window loads and tap sets per stencil
+    point, l1_norm reductions, the 766-entry weight table -- against the oracle's colour path"""
+    gs, _ = synth.build_problem(synth.tiny_config(**cfg), colour=True)
+    n4, c = _with_env({"GIPUMA_HIP_PUSH_LAUNCHES": push, "GIPUMA_HIP_ET_FORCE": 1}, lambda: runcuda(gs))
+    o_n4, o_c = OracleState(gs).run()
+    assert_same(n4, o_n4, "colour push norm4")
+    assert_same(c, o_c, "colour push cost")
+
+
 @pytest.mark.parametrize("cfg", [
     dict(cols=96, rows=80, n_src=3, blocksize=11, iterations=4, n_best=2),    # rows of 6 points: two wraps per step
     dict(cols=130, rows=70, n_src=4, blocksize=25, iterations=3, n_best=3),   # one family at a time in LDS
