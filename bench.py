@@ -291,7 +291,7 @@ def main():
     iterations = gs.params.iterations
 
     sess = Session(gs)
-    sweep_ms, total_ms, init_ms = [], [], []
+    sweep_ms, total_ms, init_ms, half_sweeps, hs_pushed = [], [], [], [], 0
     for _ in range(args.warmup):
         sess.solve(timing=True)
     torch.cuda.synchronize()
@@ -299,6 +299,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         t = sess.solve(timing=True)  # returns after the last kernel's HIP event
+        hs_ms, hs_pushed = sess.launch_times()
+        half_sweeps.append(hs_ms)
         sweep_ms.append(t.ms_sweep_avg)
         total_ms.append(t.ms_total)
         init_ms.append(t.ms_init)
@@ -326,8 +328,20 @@ def main():
 
     if rank == 0:
         value = world * args.steps * n_pix / elapsed / 1e6
-        ms_launch = float(np.mean(sweep_ms))
+        ms_half_sweep = float(np.mean(sweep_ms))
         alg = algorithmic_bytes_per_sweep_launch(n_pix, n_views)
+        # The dominant kernel: the fused pixel-per-lane sweep kernel.  Every half-sweep after the
+        # column-per-lane / pushed ones is exactly one launch of it, timed by its own pair of HIP events on
+        # the library's stream (gipuma_hip_launch_times); the earlier half-sweeps (other kernels, push
+        # launches) only enter the per-view mean reported beside it.
+        hs = np.asarray(half_sweeps, dtype=np.float64)  # [steps][2 * iterations]
+        first_plain = 0
+        if hs.size:
+            cols_first = int(os.environ.get("GIPUMA_HIP_COLS_LAUNCHES", {15: "4", 25: "3"}.get(gs.params.box_hsize, "0"))) \
+                if not args.colour else 0
+            first_plain = min(hs.shape[1], max(cols_first, hs_pushed))
+        dominant = hs[:, first_plain:] if hs.size and first_plain < hs.shape[1] else None
+        ms_launch = float(dominant.mean()) if dominant is not None else ms_half_sweep
         achieved = alg / (ms_launch * 1e-3) / 1e9
         # HBM-side bytes per sweep launch and VALU instruction counts are NOT measured in this run: they
         # come from the PMC passes of the same command (scripts/pmc_passes.sh -> profiles/pmc_latest.json),
@@ -340,9 +354,20 @@ def main():
                 pj = json.load(open(pmc))
             except Exception:  # noqa: BLE001
                 pj = None
+        # ... the traffic of the dominant kernel from its own summary of the same passes
+        pd = None
+        pmc_dom = os.path.join(ROOT, "profiles", "pmc_latest_sweep_kernel.json")
+        if pj is not None and os.path.exists(pmc_dom):
+            try:
+                pd = json.load(open(pmc_dom))
+            except Exception:  # noqa: BLE001
+                pd = None
         traffic = None
-        if pj and "hbm_read_bytes_per_launch_x2corr" in pj:
-            traffic = (pj["hbm_read_bytes_per_launch_x2corr"] + pj["hbm_write_bytes_per_launch"]) / 1e9
+        if pd and "hbm_read_bytes_per_launch_x2corr" in pd:
+            traffic = (pd["hbm_read_bytes_per_launch_x2corr"] + pd["hbm_write_bytes_per_launch"]) / 1e9
+        imported_dom = {"measured_in_this_run": False, "file": "profiles/pmc_latest_sweep_kernel.json",
+                        "collected_at_kernel_ms": pd.get("_kernel_ms_profiled_mean") if pd else None,
+                        "note": pd.get("_note") if pd else None}
         imported = {"measured_in_this_run": False, "file": "profiles/pmc_latest.json",
                     "collected_at_kernel_ms": pj.get("_kernel_ms_profiled_mean") if pj else None,
                     "note": pj.get("_note") if pj else None}
@@ -389,13 +414,17 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": "GB per launch (L2<->fabric incl. Infinity Cache hits)",
-                         "traffic_source": imported,
-                         "kernel": "one half-sweep (one colour: close+far+refine); mean over the %d of a view: "
-                                   "pm::sweep_cols_kernel x%d + pm::sweep_kernel x%d fused launches, plus pm::push_kernel x%d "
-                                   "(the propagation costs of the first %d half-sweeps, evaluated once per plane)"
-                                   % (n_launch, min(cols_l, n_launch), n_launch - min(cols_l, n_launch), push_l, push_l),
+                         "traffic_source": imported_dom,
+                         "kernel": "pm::sweep_kernel: one fused launch per half-sweep (one colour: close+far+refine), "
+                                   "%d of the %d half-sweeps of a view (the %d before them: pm::sweep_cols_kernel x%d, "
+                                   "and pm::push_kernel x%d, which evaluates the propagation costs of the first %d "
+                                   "half-sweeps once per plane)"
+                                   % (n_launch - first_plain, n_launch, first_plain, min(cols_l, n_launch), push_l, push_l),
                          "kernel_ms": ms_launch,
-                         "kernel_ms_source": "HIP events on the library's stream inside gipuma_hip_solve, this run",
+                         "kernel_ms_source": "HIP events around each half-sweep on the library's stream "
+                                             "(gipuma_hip_launch_times), mean over the kernel's launches, this run",
+                         "half_sweep_ms_mean_all": ms_half_sweep,
+                         "half_sweep_ms": [float(x) for x in hs.mean(axis=0)] if hs.size else None,
                          "algorithmic_bytes_per_launch": alg,
                          "note": "compute/gather bound by construction (SURVEY F5): "
                                  "%.3g patch samples/s" % (samples_per_frame / (np.mean(total_ms) * 1e-3))},
@@ -407,8 +436,9 @@ def main():
             lane_ops = pj["SQ_INSTS_VALU"] * 64.0
             peak = 256 * 4 * 32 * 2.4e9
             out["roofline_valu"] = {
-                "bound": "valu", "achieved": lane_ops / (ms_launch * 1e-3) / 1e12, "peak": peak / 1e12,
-                "unit": "T lane-instr/s", "frac": lane_ops / (ms_launch * 1e-3) / peak,
+                "bound": "valu", "achieved": lane_ops / (ms_half_sweep * 1e-3) / 1e12, "peak": peak / 1e12,
+                "unit": "T lane-instr/s", "frac": lane_ops / (ms_half_sweep * 1e-3) / peak,
+                "per": "half-sweep of a view (all its kernels: sums over the dispatches / %d)" % n_launch,
                 "valu_instr_per_window_load": pj["SQ_INSTS_VALU"] / max(1.0, pj.get("SQ_INSTS_VMEM_RD", 0.0)),
                 "source": dict(imported, counter="rocprofv3 --pmc SQ_INSTS_VALU")}
         if world == 1 and not args.no_extras:

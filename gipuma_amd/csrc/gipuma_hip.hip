@@ -110,6 +110,9 @@ struct gipuma_hip_session {
     bool prop_attr_set = false;
     bool launch_times = false;
     std::vector<hipEvent_t> lev;
+    std::vector<float> half_sweep_ms;  // of the last timed gipuma_hip_solve (gipuma_hip_launch_times)
+    int n_pushed = 0;                  // leading half-sweeps of that solve that read pushed costs
+    int n_push_consumed = 0;           // ... counted while the solve runs
 };
 
 namespace {
@@ -261,6 +264,7 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
             if (rc) return rc;
         }
         tune |= Tune::kPushConsume;
+        s->n_push_consumed++;
     }
     s->push_valid = -1;  // the planes of `colour` are about to change
     const bool push_next = s->push_ok && qualifies && half_sweep + 1 < s->push_launches &&
@@ -845,12 +849,13 @@ int gipuma_hip_solve(gipuma_hip_session *s, gipuma_hip_timing *timing)
     HIP_OK(hipEventRecord(s->ev[0], s->stream));
     if ((rc = gipuma_hip_init_planes(s))) return rc;
     HIP_OK(hipEventRecord(s->ev[1], s->stream));
-    const size_t n_lev = s->launch_times ? (size_t)(2 * s->iterations + 1) : 0;
+    const size_t n_lev = (timing || s->launch_times) ? (size_t)(2 * s->iterations + 1) : 0;
     while (s->lev.size() < n_lev) {
         hipEvent_t e;
         HIP_OK(hipEventCreate(&e));
         s->lev.push_back(e);
     }
+    s->n_push_consumed = 0;
     if (n_lev) HIP_OK(hipEventRecord(s->lev[0], s->stream));
     for (int it = 0; it < s->iterations; it++) {  // gipuma.cu:1911-1941
         if ((rc = gipuma_hip_sweep(s, it, GIPUMA_BLACK, GIPUMA_STAGE_ALL))) return rc;
@@ -873,14 +878,26 @@ int gipuma_hip_solve(gipuma_hip_session *s, gipuma_hip_timing *timing)
     }
     if (n_lev) {
         HIP_OK(hipEventSynchronize(s->ev[3]));
-        fprintf(stderr, "gipuma_hip launch_ms:");
-        for (size_t i = 1; i < n_lev; i++) {
-            float ms = 0.0f;
-            HIP_OK(hipEventElapsedTime(&ms, s->lev[i - 1], s->lev[i]));
-            fprintf(stderr, " %.3f", ms);
+        s->half_sweep_ms.assign(n_lev - 1, 0.0f);
+        for (size_t i = 1; i < n_lev; i++) HIP_OK(hipEventElapsedTime(&s->half_sweep_ms[i - 1], s->lev[i - 1], s->lev[i]));
+        s->n_pushed = s->n_push_consumed;
+        if (s->launch_times) {
+            fprintf(stderr, "gipuma_hip launch_ms:");
+            for (float ms : s->half_sweep_ms) fprintf(stderr, " %.3f", ms);
+            fprintf(stderr, "\n");
         }
-        fprintf(stderr, "\n");
     }
+    return 0;
+}
+
+int gipuma_hip_launch_times(gipuma_hip_session *s, float *ms_half_sweep, int capacity, int *n_half_sweeps, int *n_pushed)
+{
+    if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
+    const int n = (int)s->half_sweep_ms.size();
+    if (ms_half_sweep)
+        for (int i = 0; i < n && i < capacity; i++) ms_half_sweep[i] = s->half_sweep_ms[i];
+    if (n_half_sweeps) *n_half_sweeps = n;
+    if (n_pushed) *n_pushed = s->n_pushed;
     return 0;
 }
 

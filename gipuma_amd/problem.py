@@ -203,6 +203,16 @@ class Session:
                   "gipuma_hip_solve")
         return t
 
+    def launch_times(self):
+        """(ms per half-sweep of the last timed solve, number of leading half-sweeps that include a
+        pm::push_kernel launch)"""
+        n, npush = C.c_int(0), C.c_int(0)
+        cap = 2 * max(1, int(self.gs.params.iterations))
+        buf = (C.c_float * cap)()
+        abi.check(self.lib, self.lib.gipuma_hip_launch_times(self.h, buf, cap, C.byref(n), C.byref(npush)),
+                  "gipuma_hip_launch_times")
+        return [float(buf[i]) for i in range(min(cap, n.value))], npush.value
+
     def eval_cost(self, planes):
         planes = np.ascontiguousarray(planes, dtype=np.float32)
         out = np.empty((self.gs.rows, self.gs.cols), dtype=np.float32)

@@ -173,6 +173,14 @@ int gipuma_hip_state_device_ptrs(gipuma_hip_session *s, float **norm4_dev, float
 /* init + iterations x (black, red) + finalize on the session, timed with HIP events.
  * Does not synchronise the host unless `timing` is non-NULL. */
 int gipuma_hip_solve(gipuma_hip_session *s, gipuma_hip_timing *timing);
+/* Device time of every half-sweep (one colour of one iteration: the launches at gipuma.cu:1915-1923 or
+ * :1927-1935) of the last gipuma_hip_solve that was given a `timing`, in launch order: up to `capacity`
+ * values to ms_half_sweep, their number (2 x iterations) to *n_half_sweeps.  *n_pushed = how many leading
+ * half-sweeps read their propagation costs from pm::push_kernel launches that are timed with them
+ * (DESIGN.md 5); every later half-sweep is exactly one fused sweep launch.  (The reference times the whole loop
+ * with one cudaEvent pair, gipuma.cu:1908-1952.)  Pointers may be NULL. */
+int gipuma_hip_launch_times(gipuma_hip_session *s, float *ms_half_sweep, int capacity, int *n_half_sweeps,
+                            int *n_pushed);
 
 /* ---- one-shot: the whole of runcuda() ---- */
 /* norm4_out: rows*cols*4 host floats, cost_out: rows*cols host floats (either may be NULL).

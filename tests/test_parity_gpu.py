@@ -412,6 +412,25 @@ def test_push_propagation_other_boxes(hip, cfg):
     assert_same(c, o_c, "push box %d cost" % cfg["blocksize"])
 
 
+def test_launch_times_of_a_solve(hip):
+    """gipuma_hip_launch_times: one device time per half-sweep of the last timed solve, and how many
+    leading half-sweeps read pushed costs (box 15: 4 by default, none when switched off)"""
+    gs, _ = synth.build_problem(synth.tiny_config(cols=96, rows=64, n_src=3, blocksize=15, iterations=3, n_best=2))
+    with Session(gs) as s:
+        assert s.launch_times() == ([], 0)
+        t = s.solve(timing=True)
+        ms, pushed = s.launch_times()
+    assert len(ms) == 6 and pushed == 4 and all(m > 0 for m in ms)
+    assert abs(sum(ms) - t.ms_sweeps) < 0.05 * t.ms_sweeps + 0.05
+
+    def off():
+        with Session(gs) as s2:
+            s2.solve(timing=True)
+            return s2.launch_times()
+    ms0, pushed0 = _with_env({"GIPUMA_HIP_PUSH_LAUNCHES": 0}, off)
+    assert len(ms0) == 6 and pushed0 == 0
+
+
 @pytest.mark.parametrize("cols,rows,sel,over", [
     (33, 17, [1, 2, 3], dict(n_best=2)),                   # ragged, smaller than a tile
     (21, 9, [1, 2], dict(n_best=1)),                       # smaller than the window and the stencil
