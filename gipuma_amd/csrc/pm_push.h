@@ -37,7 +37,10 @@
 //
 // Supported: gray window-packed planes with float-encoded offsets, box 11 / 15 / 25, best-N with
 // n_best <= 4.  Box 15 (8 window columns = 8 lanes) has its steps unrolled with compile-time stencil
-// positions; the other boxes run PushEval::family.
+// positions; the other boxes run PushEval::family.  Colour (T = float4, box 15): push_kernel_c4 below.
+// What binds it (config C, profiles/r02_push_pmc_push_kernel.json): the vector L1 -- 1.39e9 accesses per
+// launch, and its miss handling while the planes are random -- not VALU issue: a timing build without
+// the chain phase is no faster.
 #pragma once
 #include "pm_device.h"
 
