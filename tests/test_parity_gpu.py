@@ -642,6 +642,17 @@ def test_config_d_every_launch_at_full_size(hip):
 # ------------------------------------------------------------------------------------------------
 # -color_processing (T = float4)
 # ------------------------------------------------------------------------------------------------
+def test_colour_every_launch_at_full_size(hip):
+    """the colour variant of config C's geometry (1600x1200, 10 source views, box 15, best-3) as bench.py
+    --colour runs it, four iterations: every one of the 8 half-sweep launches -- six of them fed by
+    pm::push_kernel_c4, then the plain colour sweep kernel with the history rule -- checked exactly on
+    two bands of rows (top border, interior across a tile boundary)"""
+    gs, info = synth.build_problem("C", colour=True, iterations=4)
+    n = _teacher_forced_bands(gs, [(0, 5), (604, 612)], "colour config C")
+    print("colour config C: %d pixel updates compared exactly" % n)
+
+
+
 @pytest.mark.parametrize("cfg", [
     dict(blocksize=7, n_src=3, n_best=2),              # runtime-sized window
     dict(cols=80, rows=56, blocksize=15, n_src=4, n_best=3, iterations=1),
