@@ -276,14 +276,17 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
     // (pixel, plane) pair, pm::sweep_cols_kernel) when the problem has that instantiation
     // (box 15 only: its 8 window columns fill the 8 lanes of a group; box 11, 6 of 8 lanes, measured
     // slower than one lane per pixel on config B: 18.0 vs 19.8 Mpix/s)
-    const bool cols_ok = s->u8 && s->ch == 1 && s->hp.magic_addr && (s->box == 15 || s->box == 25) &&
+    const bool cols_ok = s->u8 && ((s->ch == 1 && s->hp.magic_addr && (s->box == 15 || s->box == 25)) ||
+                                   (s->ch == 4 && s->box == 15)) &&
                          !(tune & (Tune::kNoColsKernel | Tune::kNoInterior));
     size_t lds = s->lds_sweep;
     // measured: box 15 (groups of 8 lanes) wins the first four half-sweeps of config C, box 25 (13 of 16
     // lanes) the first three of config D (128.7 / 90.9 / 73.7 -> 88.3 / 78.7 / 72.0 ms, the fourth loses)
     const int cols_launches = s->cols_launches >= 0 ? s->cols_launches : (s->box == 25 ? 3 : 4);
     if (cols_ok && (2 * iteration + colour < cols_launches || (tune & Tune::kColsAlways))) {
-        if (s->box == 15)
+        if (s->ch == 4)
+            k = s->combine_reg ? pm::sweep_cols_kernel<15, true, 4> : pm::sweep_cols_kernel<15, false, 4>;
+        else if (s->box == 15)
             k = s->combine_reg ? pm::sweep_cols_kernel<15, true> : pm::sweep_cols_kernel<15, false>;
         else
             k = s->combine_reg ? pm::sweep_cols_kernel<25, true> : pm::sweep_cols_kernel<25, false>;
@@ -329,8 +332,10 @@ int launch_dense(gipuma_hip_session *s, bool generate, float4 *planes, float *co
     const int gy = (s->rows + pm::kDenseTileH - 1) / pm::kDenseTileH;
     init_fn k = generate ? pick_init<true>(s) : pick_init<false>(s);
     // random (or arbitrary caller-supplied) planes: column-per-lane evaluation where it exists
-    if (s->u8 && s->ch == 1 && s->hp.magic_addr && (s->box == 15 || s->box == 25) &&
-        !(s->tune & (Tune::kNoColsKernel | Tune::kNoInterior))) {
+    if (s->u8 && s->ch == 4 && s->box == 15 && !(s->tune & (Tune::kNoColsKernel | Tune::kNoInterior))) {
+        k = generate ? pm::init_cols_kernel<15, true, 4> : pm::init_cols_kernel<15, false, 4>;
+    } else if (s->u8 && s->ch == 1 && s->hp.magic_addr && (s->box == 15 || s->box == 25) &&
+               !(s->tune & (Tune::kNoColsKernel | Tune::kNoInterior))) {
         if (s->box == 15)
             k = generate ? pm::init_cols_kernel<15, true> : pm::init_cols_kernel<15, false>;
         else

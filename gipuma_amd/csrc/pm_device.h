@@ -1170,9 +1170,105 @@ __device__ __forceinline__ float view_cost_cols(const Problem *__restrict__ P, c
     return out;  // exact in lane N-1 of the group
 }
 
+// view_cost_cols for T = float4 (-color_processing): lane c evaluates window column c by the
+// arithmetic of view_cost_c4_loop (three 16-byte window loads and tap sets per sample, l1_norm(float4)
+// reductions, weight table indexed by |dB|+|dG|+|dR|, integer window addressing), the relay keeps the
+// reference's summation order.  `tp0` points at the pixel's own texel in the float4 {B, G, R, 0} tile.
+struct WinReq3 {
+    float a, b;
+    u32x4_a4 q0, q1, q2;
+};
+template <int BOX, bool FAST>
+__device__ __forceinline__ float view_cost_cols_c4(const Problem *__restrict__ P, const ViewCam &vc,
+                                                   const float *__restrict__ H, const float *__restrict__ tp0,
+                                                   int tw, const float *__restrict__ lut, int px, int py, int col)
+{
+    constexpr int R = (BOX - 1) / 2, N = R + 1;
+    static_assert(BOX > 0 && N <= col_group<BOX>(), "one lane per window column");
+    const gptr_bytes packed = (gptr_bytes)vc.packed;
+    const uint32_t pw = (uint32_t)P->pw;
+    const uint32_t xmax = (uint32_t)(P->cols + 2), ymax = (uint32_t)(P->rows + 2);
+    const float alpha = P->alpha, oma = 1.f - P->alpha;
+    const float tau_color = P->tau_color, tau_gradient = P->tau_gradient;
+    const float4 centre = *reinterpret_cast<const float4 *>(tp0);
+    const float H1 = H[1], H4 = H[4], H7 = H[7];
+    const int mycol = col < N ? col : N - 1;
+    const float qx = (float)(px - R + 2 * mycol);
+    const float X0 = __builtin_fmaf(H[0], qx, H[2]);
+    const float Y0 = __builtin_fmaf(H[3], qx, H[5]);
+    const float Z0 = __builtin_fmaf(H[6], qx, H[8]);
+
+    auto request = [&](float qy) -> WinReq3 {
+        const float X = __builtin_fmaf(H1, qy, X0);
+        const float Y = __builtin_fmaf(H4, qy, Y0);
+        const float Z = __builtin_fmaf(H7, qy, Z0);
+        const float rz = recip<FAST>(Z);
+        const float sx = X * rz, sy = Y * rz;
+        const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
+        WinReq3 r;
+        r.a = sx - fx0;
+        r.b = sy - fy0;
+        const uint32_t Xw = min(cvt_u32_sat(fx0 + 2.0f), xmax);
+        const uint32_t Yw = min(cvt_u32_sat(fy0 + 2.0f), ymax);
+        const gptr_bytes base = packed + (Yw * pw + Xw) * 12u;
+        r.q0 = *(gptr_u32x4)(base);
+        r.q1 = *(gptr_u32x4)(base + 16);
+        r.q2 = *(gptr_u32x4)(base + 32);
+        return r;
+    };
+
+    const float qy0 = (float)(py - R);
+    const float *tcol = tp0 + 4 * (-R * tw - R + 2 * mycol);  // texel (column, -R) of the window
+    float wgt[N], dis[N];
+#ifndef PM_COLS_C4_PD
+#define PM_COLS_C4_PD 3
+#endif
+    constexpr int PD = PM_COLS_C4_PD < N ? PM_COLS_C4_PD : N;  // window requests (three loads each) in flight
+    WinReq3 req[PD];
+#pragma unroll
+    for (int p = 0; p < PD; p++) req[p] = request(qy0 + (float)(2 * p));
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const WinReq3 cur = req[k % PD];
+        if (k + PD < N) req[k % PD] = request(qy0 + (float)(2 * (k + PD)));
+        const float *tp = tcol + 8 * k * tw;
+        const float4 lv = *reinterpret_cast<const float4 *>(tp);
+        const float S = __builtin_fabsf(lv.x - centre.x) + __builtin_fabsf(lv.y - centre.y) +
+                        __builtin_fabsf(lv.z - centre.z);  // exact integer 0..765
+        wgt[k] = lut[(int)S];
+        Taps t[3];  // word 3k+c = column k, channel c
+        t[0] = taps_u8(cur.a, cur.b, cur.q0.x, cur.q0.w, cur.q1.z, cur.q2.y);
+        t[1] = taps_u8(cur.a, cur.b, cur.q0.y, cur.q1.x, cur.q1.w, cur.q2.z);
+        t[2] = taps_u8(cur.a, cur.b, cur.q0.z, cur.q1.y, cur.q2.x, cur.q2.w);
+        const float4 up = *reinterpret_cast<const float4 *>(tp - 4 * tw);
+        const float4 down = *reinterpret_cast<const float4 *>(tp + 4 * tw);
+        const float4 left = *reinterpret_cast<const float4 *>(tp - 4);
+        const float4 right = *reinterpret_cast<const float4 *>(tp + 4);
+        const float colDiff = l1_3(lv.x - t[0].sc, lv.y - t[1].sc, lv.z - t[2].sc);
+        const float gX = l1_3((right.x - left.x) - t[0].gx2, (right.y - left.y) - t[1].gx2,
+                              (right.z - left.z) - t[2].gx2);
+        const float gY = l1_3((down.x - up.x) - t[0].gy2, (down.y - up.y) - t[1].gy2,
+                              (down.z - up.z) - t[2].gy2);
+        const float gradDis = min_nc((gX + gY) * 0.0625f, tau_gradient);
+        const float colDis = min_nc(colDiff, tau_color);
+        dis[k] = __builtin_fmaf(alpha, gradDis, oma * colDis);
+    }
+    // relay: after step c, lane c of the group holds the sum over columns 0..c in reference order
+    float out = 0.0f;
+#pragma unroll
+    for (int c = 0; c < N; c++) {
+        float acc = c == 0 ? 0.0f
+                           : __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(out), 0x111, 0xf, 0xf, false));
+#pragma unroll
+        for (int k = 0; k < N; k++) acc = __builtin_fmaf(wgt[k], dis[k], acc);
+        out = acc;
+    }
+    return out;  // exact in lane N-1 of the group
+}
+
 // pmCostMultiview_cu for one (pixel, plane) pair evaluated by a group of col_group<BOX>() lanes; the
 // result is exact in every lane of the group
-template <int BOX, bool COMBINE_REG>
+template <int BOX, bool COMBINE_REG, int CH = 1>
 __device__ __forceinline__ float multiview_cost_cols(const Problem *__restrict__ P, const float *__restrict__ tp0,
                                                      int tw, const float *__restrict__ lut, float *cv, int px,
                                                      int py, float4 pl, int col)
@@ -1195,7 +1291,12 @@ __device__ __forceinline__ float multiview_cost_cols(const Problem *__restrict__
             for (int k = 0; k < 9; k++) H[k] = __shfl(Hl[k], grp_lane0 + (v - vb));
             const bool safe = window_z_safe(H, (float)(px - R), (float)(px + R), (float)(py - R), (float)(py + R));
             float c;
-            if (__all(safe))
+            if constexpr (CH == 4) {
+                if (__all(safe))
+                    c = view_cost_cols_c4<BOX, true>(P, P->view[v], H, tp0, tw, lut, px, py, col);
+                else
+                    c = view_cost_cols_c4<BOX, false>(P, P->view[v], H, tp0, tw, lut, px, py, col);
+            } else if (__all(safe))
                 c = view_cost_cols<BOX, true>(P, P->view[v], H, tp0, tw, lut, px, py, col);
             else
                 c = view_cost_cols<BOX, false>(P, P->view[v], H, tp0, tw, lut, px, py, col);
@@ -1362,13 +1463,12 @@ __global__ __launch_bounds__(kThreads) void init_kernel(const Problem *__restric
 // init_kernel with the column-per-lane evaluation (view_cost_cols): every lane draws / reads the
 // plane of its own pixel as above, the 256 planes of the tile go through LDS and are evaluated by
 // groups of col_group<BOX>() lanes -- random planes are the worst case for one lane per pixel.
-template <int BOX, bool GENERATE>
+template <int BOX, bool GENERATE, int CH = 1>
 __global__ __launch_bounds__(kThreads) void init_cols_kernel(const Problem *__restrict__ P,
                                                              float4 *__restrict__ norm4, float *__restrict__ cost,
                                                              unsigned tune)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int CH = 1;
     const Win<BOX> win(P);
     const int gx = (P->cols + kTileW - 1) / kTileW;
     const int gy = (P->rows + kDenseTileH - 1) / kDenseTileH;
@@ -1405,7 +1505,7 @@ __global__ __launch_bounds__(kThreads) void init_cols_kernel(const Problem *__re
         const int epx = min(x0 + (owner & 31), P->cols - 1), epy = min(y0 + (owner >> 5), P->rows - 1);
         const float4 ecand = candbuf[owner];
         const float *etp0 = tile + (((epy - y0) + hh) * tw + ((epx - x0) + hw)) * 4;
-        const float c = multiview_cost_cols<BOX, false>(P, etp0, tw, lds, cv, epx, epy, ecand, col);
+        const float c = multiview_cost_cols<BOX, false, CH>(P, etp0, tw, lds, cv, epx, epy, ecand, col);
         if (col == 0) bres[owner] = c;
     }
     __syncthreads();
@@ -2198,14 +2298,13 @@ __global__ __launch_bounds__(kThreads, U8 ? 4 : 1) void sweep_kernel(const Probl
 // groups of col_group<BOX>() lanes, col_tasks<BOX>() (pixel, plane) pairs at a time, exchanging planes and costs
 // through LDS.  Gray packed planes with float-encoded offsets and a compile-time box only (the host
 // uses it for box 15, whose 8 columns fill a group of 8, and for box 25: 13 of 16 lanes).
-template <int BOX, bool COMBINE_REG>
+template <int BOX, bool COMBINE_REG, int CH = 1>
 __global__ __launch_bounds__(kThreads) void sweep_cols_kernel(const Problem *__restrict__ P,
                                                               float4 *__restrict__ norm4, float *__restrict__ cost,
                                                               int colour, uint32_t phase, unsigned stages,
                                                               unsigned tune)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int CH = 1;
     const int rows = P->rows, cols = P->cols;
     SweepLane L;
     sweep_setup<BOX, CH>(L, P, lds, norm4, cost, colour, stages, tune, true);
@@ -2228,7 +2327,7 @@ __global__ __launch_bounds__(kThreads) void sweep_cols_kernel(const Problem *__r
         neighbour(slot, epx, epy, rows, cols, epy * cols + epx, nb);
         const float4 cand = norm4[nb];
         const float *etp0 = L.tile + ((oly + L.hh) * L.tw + (olx + L.hw)) * 4;
-        const float c = multiview_cost_cols<BOX, COMBINE_REG>(P, etp0, L.tw, lds, L.cv, epx, epy, cand, col);
+        const float c = multiview_cost_cols<BOX, COMBINE_REG, CH>(P, etp0, L.tw, lds, L.cv, epx, epy, cand, col);
         if (have && col == 0) L.bres[slot * kThreads + owner] = c;
     }
     __syncthreads();
@@ -2253,7 +2352,7 @@ __global__ __launch_bounds__(kThreads) void sweep_cols_kernel(const Problem *__r
             const int epx = min(L.x0 + olx, cols - 1), epy = min(L.y0 + oly, rows - 1);
             const float4 ecand = candbuf[owner];
             const float *etp0 = L.tile + (((epy - L.y0) + L.hh) * L.tw + ((epx - L.x0) + L.hw)) * 4;
-            const float c = multiview_cost_cols<BOX, COMBINE_REG>(P, etp0, L.tw, lds, L.cv, epx, epy, ecand, col);
+            const float c = multiview_cost_cols<BOX, COMBINE_REG, CH>(P, etp0, L.tw, lds, L.cv, epx, epy, ecand, col);
             if (col == 0) L.bres[owner] = c;
         }
         __syncthreads();

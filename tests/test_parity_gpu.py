@@ -642,6 +642,26 @@ def test_config_d_every_launch_at_full_size(hip):
 # ------------------------------------------------------------------------------------------------
 # -color_processing (T = float4)
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tune", [1 << 27, 1 << 26, (1 << 26) | (1 << 23)])
+def test_colour_column_per_lane_kernels(hip, tune):
+    """colour, box 15: init and the first half-sweeps evaluate column-per-lane (view_cost_cols_c4: lane c
+    = window column c, three window loads per sample, the relay keeps the summation order) -- never
+    (bit 27) / in every half-sweep (bit 26) must give the bits of the default schedule and of the oracle;
+    12 views: two homography exchange blocks"""
+    gs, _ = synth.build_problem(synth.tiny_config(cols=112, rows=72, n_src=4, blocksize=15, iterations=3, n_best=3),
+                                colour=True)
+    imgs = gs.images
+    g = _problem_from(gs, imgs, [1, 2, 3, 4] * 3, n_best=3)
+    a = runcuda(g)
+    b = _with_env({"GIPUMA_HIP_TUNE": tune, "GIPUMA_HIP_PUSH_LAUNCHES": 2}, lambda: runcuda(g))
+    assert_same(a[0], b[0], "colour cols variant %d norm4" % tune)
+    assert_same(a[1], b[1], "colour cols variant %d cost" % tune)
+    if tune == 1 << 27:
+        o = OracleState(g).run()
+        assert_same(a[0], o[0], "colour default vs oracle norm4")
+        assert_same(a[1], o[1], "colour default vs oracle cost")
+
+
 def test_colour_every_launch_at_full_size(hip):
     """the colour variant of config C's geometry (1600x1200, 10 source views, box 15, best-3) as bench.py
     --colour runs it, four iterations: every one of the 8 half-sweep launches -- six of them fed by
