@@ -470,6 +470,45 @@ def main():
                                             "what": "same cameras and parameters, scene with +-30 mm depth steps, a raised "
                                                     "disc (occlusions) and sigma=2 sensor noise"}
                 del gs3, info3
+            # (d) throughput of a batch runner that keeps several reference views in flight on one GPU: one
+            #     session (= one HIP stream) per view, whole solves enqueued back to back, one host wait
+            #     at the end.  Launch tails of one view fill with workgroups of another, and kernels bound
+            #     by different units (the push kernels by the vector L1, the sweep kernels by VALU issue)
+            #     overlap.  Reported beside `value`, which stays one view at a time.
+            if args.config in ("C", "D") and args.scene == "smooth":
+                inflight = {}
+                others = [v for v in synth.DTU_REF_VIEWS if v != ref_view]
+                extra = []
+                for v in others[:2]:
+                    g_k, _ = synth.build_problem(args.config, ref_view=v, device=dev, keep_on_device=True,
+                                                 colour=args.colour, scene=args.scene, **over)
+                    g_k.desc.device_id = dev_index
+                    extra.append(g_k)
+                for kfl in (2, 3):
+                    group = [gs] + extra[:kfl - 1]
+                    sessions = [Session(g) for g in group]
+                    try:
+                        for ss in sessions:
+                            ss.solve(timing=True)  # warm-up, one at a time
+                        reps = 3
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        for _ in range(reps):
+                            for ss in sessions:
+                                ss.solve(timing=False)  # asynchronous: nothing waits for the stream
+                        for ss in sessions:
+                            ss.sync()
+                        dt = time.perf_counter() - t1
+                    finally:
+                        for ss in sessions:
+                            ss.close()
+                    inflight["%d_views" % kfl] = {"value": kfl * reps * n_pix / dt / 1e6, "unit": "Mpix/s",
+                                                  "ms_per_view": dt / (kfl * reps) * 1e3,
+                                                  "ref_views": [ref_view] + others[:kfl - 1]}
+                out["value_views_in_flight"] = dict(inflight, what="the same workload with 2 / 3 reference views "
+                                                    "in flight on this GPU (one session and stream each, solves "
+                                                    "enqueued asynchronously); `value` is one view at a time")
+                del extra
             # (c) the boundary as the reference's main.cpp uses it: host images in, host planes out
             #     (upload + window packing + solve + download); reported, never `value`
             gs_host = GlobalState([im.cpu().numpy() for im in gs.images], gs.cameras, gs.selected,
