@@ -12,12 +12,17 @@ MI355X-first differences from the shell loop:
     them by device pointer -- no per-view process start, disk read or PCIe upload;
   * reference views are sharded round-robin over the ranks (gipuma_amd.shard); there is no
     inter-GPU communication;
+  * several reference views are kept in flight per GPU (--in_flight, default 2): one session and HIP
+    stream each, the solves enqueued asynchronously -- launch tails of one view fill with workgroups of
+    another and kernels bound by different units overlap (bench.py `value_views_in_flight`: +5 % / +6 %
+    throughput with 2 / 3 views on config C);
   * results land in <output>/<refname>/{disp.dmb, normals.dmb, cost.dmb} -- the dumps the
     reference writes (main.cpp:1001-1015) and fusibile reads.
 
 Images: binary PGM (P5, 8 bit).  Calibration: <p-folder>/<image name>.P (fileIoUtils.h:83-110).
 """
 import argparse
+import collections
 import ctypes as C
 import json
 import os
@@ -88,6 +93,8 @@ def main(argv=None):
     pa.add_argument("--max_views", type=int, default=9)
     pa.add_argument("--cam_scale", type=float, default=1.0)
     pa.add_argument("--seed", type=int, default=1)
+    pa.add_argument("--in_flight", type=int, default=2,
+                    help="reference views kept in flight per GPU (1: one at a time, with per-view device times)")
     args = pa.parse_args(argv)
     # the reference parses these with sscanf("%f") into float fields (main.cpp:300-360)
     for k in ("cost_gamma", "depth_min", "depth_max", "min_angle", "max_angle", "cam_scale"):
@@ -122,6 +129,28 @@ def main(argv=None):
     ap.set_blocksize(args.blocksize)
     os.makedirs(args.output_folder, exist_ok=True)
     report = []
+    in_flight = max(1, args.in_flight)
+    pending = collections.deque()  # (session, reference name, source names, start time, timing or None)
+
+    def retire():
+        s, ref_name, sources, tw0, t = pending.popleft()
+        try:
+            n4, cost = s.get_state()  # waits for the session's stream
+        finally:
+            s.close()
+        wall_ms = (time.perf_counter() - tw0) * 1e3  # session set-up + solve (+ what ran beside it) + download
+        folder = os.path.join(args.output_folder, os.path.splitext(ref_name)[0])
+        os.makedirs(folder, exist_ok=True)
+        dmb.write_dmb(os.path.join(folder, "disp.dmb"), n4[..., 3])
+        dmb.write_dmb(os.path.join(folder, "normals.dmb"), n4[..., :3])
+        dmb.write_dmb(os.path.join(folder, "cost.dmb"), cost)
+        entry = {"ref": ref_name, "sources": sources, "wall_ms": wall_ms,
+                 "mpix_per_s_wall": rows * cols / (wall_ms * 1e-3) / 1e6}
+        if t is not None:  # one view at a time: the device time is that view's alone
+            entry.update({"device_ms": t.ms_total, "mpix_per_s": rows * cols / (t.ms_total * 1e-3) / 1e6})
+        report.append(entry)
+
+    t_batch0 = time.perf_counter()
     for ref_name in mine:
         ref_idx = names.index(ref_name)
         cs, used, ap_view = plan_views(P_all, names, ref_idx, cols, rows, ap, args.cam_scale)
@@ -135,21 +164,24 @@ def main(argv=None):
                          device_ptrs=[t.data_ptr() for t in imgs], rows=rows, cols=cols, device_id=dev_index,
                          flags=abi.FLAG_CACHE_IMAGES)
         tw0 = time.perf_counter()
-        with Session(gs) as s:
-            t = s.solve(timing=True)
-            n4, cost = s.get_state()
-        wall_ms = (time.perf_counter() - tw0) * 1e3  # session set-up + solve + download
-        folder = os.path.join(args.output_folder, os.path.splitext(ref_name)[0])
-        os.makedirs(folder, exist_ok=True)
-        dmb.write_dmb(os.path.join(folder, "disp.dmb"), n4[..., 3])
-        dmb.write_dmb(os.path.join(folder, "normals.dmb"), n4[..., :3])
-        dmb.write_dmb(os.path.join(folder, "cost.dmb"), cost)
-        report.append({"ref": ref_name, "sources": [names[i] for i in used[1:]], "device_ms": t.ms_total,
-                       "mpix_per_s": rows * cols / (t.ms_total * 1e-3) / 1e6, "wall_ms": wall_ms,
-                       "mpix_per_s_wall": rows * cols / (wall_ms * 1e-3) / 1e6})
+        s = Session(gs)
+        try:
+            t = s.solve(timing=True) if in_flight == 1 else (s.solve(timing=False), None)[1]
+        except Exception:
+            s.close()
+            raise
+        pending.append((s, ref_name, [names[i] for i in used[1:]], tw0, t))
+        while len(pending) >= in_flight:
+            retire()
+    while pending:
+        retire()
+    t_batch = time.perf_counter() - t_batch0
     abi.load_library().gipuma_hip_cache_clear()
     with open(os.path.join(args.output_folder, "batch_rank%d.json" % rank), "w") as f:
+        n_done = sum(1 for r in report if "skipped" not in r)
         json.dump({"rank": rank, "world": world, "device": dev_index, "load_seconds": t_load,
+                   "in_flight": in_flight, "batch_seconds": t_batch,
+                   "mpix_per_s_batch": n_done * rows * cols / max(t_batch, 1e-9) / 1e6,
                    "views": report}, f, indent=1)
     print("rank %d/%d: %d reference views on cuda:%d" % (rank, world, len(report), dev_index))
     return 0

@@ -39,9 +39,11 @@ def test_compute_normal_error():
 
 
 @pytest.mark.gpu
-def test_batch_runner_matches_single_view_runs(hip, tmp_path):
+@pytest.mark.parametrize("in_flight", [1, 2, 3])
+def test_batch_runner_matches_single_view_runs(hip, tmp_path, in_flight):
     """three reference views of a small scan through the batch runner (images resident once,
-    per-view selectViews) == the same views solved one by one"""
+    per-view selectViews; one at a time, or 2 / 3 views in flight on their own streams) == the same
+    views solved one by one"""
     from gipuma_amd import batch
     from gipuma_amd.problem import runcuda, GlobalState
     cfg = synth.tiny_config(cols=96, rows=64, n_src=4, blocksize=9, iterations=2, n_best=2)
@@ -65,7 +67,8 @@ def test_batch_runner_matches_single_view_runs(hip, tmp_path):
     rc = batch.main(["--images-folder", str(img_dir), "--p-folder", str(p_dir), "--output-folder", str(out),
                      "--views", ",".join(refs), "--blocksize=9", "--iterations=2", "--n_best=2",
                      "--depth_min=300", "--depth_max=800", "--min_angle=2", "--max_angle=60",
-                     "--max_views=10", "--cam_scale=%.9g" % np.float32(cfg["cam_scale"])])
+                     "--max_views=10", "--cam_scale=%.9g" % np.float32(cfg["cam_scale"]),
+                     "--in_flight=%d" % in_flight])
     assert rc == 0
     rep = json.load(open(out / "batch_rank0.json"))
     assert [v["ref"] for v in rep["views"]] == refs
@@ -87,4 +90,8 @@ def test_batch_runner_matches_single_view_runs(hip, tmp_path):
             o4, oc = OracleState(g1).run()
             assert np.array_equal(o4.view(np.uint32), n4.view(np.uint32))
             assert np.array_equal(oc.view(np.uint32), c.view(np.uint32))
-    assert all("wall_ms" in v and v["wall_ms"] >= v["device_ms"] for v in rep["views"])
+    assert rep["in_flight"] == in_flight and rep["mpix_per_s_batch"] > 0
+    if in_flight == 1:
+        assert all("wall_ms" in v and v["wall_ms"] >= v["device_ms"] for v in rep["views"])
+    else:
+        assert all("wall_ms" in v and "device_ms" not in v for v in rep["views"])
