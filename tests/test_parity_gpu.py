@@ -815,6 +815,31 @@ def test_maximum_number_of_views(hip):
     g.desc.n_selected = 32
 
 
+@pytest.mark.parametrize("box,colour", [(15, False), (25, False), (15, True)])
+def test_maximum_number_of_views_pushed(hip, box, colour):
+    """32 selected views with the push kernels in every half-sweep: four homography exchange blocks per
+    plane (gray unrolled loop, generic loop with one stencil family in LDS at a time, colour)"""
+    from gipuma_amd.cameras import CameraSet
+    from gipuma_amd.problem import AlgorithmParameters, GlobalState
+    gs, _ = synth.build_problem(synth.tiny_config(cols=72, rows=40, n_src=4, blocksize=box, iterations=2),
+                                colour=colour)
+    n = 33
+    cs = CameraSet(n)
+    imgs = []
+    for i in range(n):
+        src = 0 if i == 0 else 1 + (i - 1) % 4
+        C.memmove(C.byref(cs.c_array[i]), C.byref(gs.cameras.c_array[src]), C.sizeof(abi.Camera))
+        imgs.append(gs.images[src])
+    cs.f = gs.cameras.f
+    ap = AlgorithmParameters(iterations=2, n_best=4, depthMin=300.0, depthMax=800.0)
+    ap.set_blocksize(box)
+    g = GlobalState(imgs, cs, list(range(1, n)), ap, seed=3)
+    n4, c = _with_env({"GIPUMA_HIP_PUSH_LAUNCHES": 100}, lambda: runcuda(g))
+    o_n4, o_c = OracleState(g).run()
+    assert_same(n4, o_n4, "32 views pushed, box %d norm4" % box)
+    assert_same(c, o_c, "32 views pushed, box %d cost" % box)
+
+
 def test_largest_window_and_rectangular_window(hip):
     gs, _ = synth.build_problem(synth.tiny_config(cols=64, rows=48, n_src=2, blocksize=7, iterations=1))
     for bh, bv in ((49, 49), (11, 5), (3, 25), (1, 1)):
