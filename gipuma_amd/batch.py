@@ -151,30 +151,39 @@ def main(argv=None):
         report.append(entry)
 
     t_batch0 = time.perf_counter()
-    for ref_name in mine:
-        ref_idx = names.index(ref_name)
-        cs, used, ap_view = plan_views(P_all, names, ref_idx, cols, rows, ap, args.cam_scale)
-        if len(used) < 2:
-            report.append({"ref": ref_name, "skipped": "no source view inside the angle cone"})
-            continue
-        imgs = [dev[i] for i in used]
-        # the scan's planes stay put for the whole batch: what the library derives from them (8-bit
-        # check, window-packed copies) is made once per image, not once per reference view that uses it
-        gs = GlobalState(imgs, cs, list(range(1, len(used))), ap_view, seed=args.seed,
-                         device_ptrs=[t.data_ptr() for t in imgs], rows=rows, cols=cols, device_id=dev_index,
-                         flags=abi.FLAG_CACHE_IMAGES)
-        tw0 = time.perf_counter()
-        s = Session(gs)
-        try:
-            t = s.solve(timing=True) if in_flight == 1 else (s.solve(timing=False), None)[1]
-        except Exception:
-            s.close()
-            raise
-        pending.append((s, ref_name, [names[i] for i in used[1:]], tw0, t))
-        while len(pending) >= in_flight:
+    try:
+        for ref_name in mine:
+            ref_idx = names.index(ref_name)
+            cs, used, ap_view = plan_views(P_all, names, ref_idx, cols, rows, ap, args.cam_scale)
+            if len(used) < 2:
+                report.append({"ref": ref_name, "skipped": "no source view inside the angle cone"})
+                continue
+            imgs = [dev[i] for i in used]
+            # the scan's planes stay put for the whole batch: what the library derives from them (8-bit
+            # check, window-packed copies) is made once per image, not once per reference view that uses it
+            gs = GlobalState(imgs, cs, list(range(1, len(used))), ap_view, seed=args.seed,
+                             device_ptrs=[t.data_ptr() for t in imgs], rows=rows, cols=cols, device_id=dev_index,
+                             flags=abi.FLAG_CACHE_IMAGES)
+            tw0 = time.perf_counter()
+            s = Session(gs)
+            try:
+                if in_flight == 1:
+                    t = s.solve(timing=True)
+                else:
+                    t = None
+                    s.solve(timing=False)  # asynchronous: returns once the launches are enqueued
+            except Exception:
+                s.close()
+                raise
+            pending.append((s, ref_name, [names[i] for i in used[1:]], tw0, t))
+            while len(pending) >= in_flight:
+                retire()
+        while pending:
             retire()
-    while pending:
-        retire()
+    finally:  # (an error above: do not leave sessions of this batch behind)
+        for leftover in pending:
+            leftover[0].close()
+        pending.clear()
     t_batch = time.perf_counter() - t_batch0
     abi.load_library().gipuma_hip_cache_clear()
     with open(os.path.join(args.output_folder, "batch_rank%d.json" % rank), "w") as f:
