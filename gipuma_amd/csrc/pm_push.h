@@ -488,15 +488,18 @@ __global__ __launch_bounds__(kThreads, PM_PUSH_WAVES) void push_kernel(const Pro
                     else
                         E.template family_v<false>(H, magic_base, tile4, dgrp, nxf, tnx, tny);
                     __builtin_amdgcn_wave_barrier();
-                    // (lanes of the other family read in-bounds values they do not use)
-                    const float cv_ = push_chain<BOX>(ipl, centre, lut_magic, dgrp + dbase, jstride);
+                    // (only the lanes whose consumer belongs to the family in the buffer: the others would
+                    //  read values they do not use, and their reads collide with the useful ones in the
+                    //  LDS banks -- measured: the box-25 kernel was LDS-bound, half of it bank conflicts)
+                    float cv_ = 0.0f, ch_ = 0.0f;
+                    if (cdx == 0) cv_ = push_chain<BOX>(ipl, centre, lut_magic, dgrp + dbase, jstride);
                     __builtin_amdgcn_wave_barrier();
                     if (fast)
                         E.template family_h<true>(H, magic_base, tile4, dgrp, nxf, tnx, tny);
                     else
                         E.template family_h<false>(H, magic_base, tile4, dgrp, nxf, tnx, tny);
                     __builtin_amdgcn_wave_barrier();
-                    const float ch_ = push_chain<BOX>(ipl, centre, lut_magic, dgrp + dbase, jstride);
+                    if (cdx != 0) ch_ = push_chain<BOX>(ipl, centre, lut_magic, dgrp + dbase, jstride);
                     __builtin_amdgcn_wave_barrier();
                     c = cdx == 0 ? cv_ : ch_;
                 } else {
