@@ -64,12 +64,24 @@ struct PushLayout {  // offsets in 32-bit words into the dynamic LDS array
     // box 25: 2 x 234 samples per group would leave one workgroup per CU -- the group's buffer holds
     // one family at a time, and the chain phase runs once per family (half of its lanes idle)
     static constexpr bool two_pass = BOX > 15;
-    static constexpr int hbase = two_pass ? 0 : NF;   // horizontal family behind the vertical one
-    // words per group (bank spread of the chain reads, scripts/exp/push_banks.py)
-    static constexpr int dstride = BOX == 15 ? 2 * NF + 2 : BOX == 11 ? 2 * NF + 4 : NF + 2;
+    // The group's sample buffer: rows of the vertical family `vs` words apart, of the horizontal one `hs`,
+    // the horizontal family at `hbase`, groups `dstride` apart; the I plane's rows `ips` apart.  Box 15
+    // (unrolled loop): strides searched with the bank model so that EVERY read of the chain phase -- 32
+    // lanes = 4 producers x 8 consumers per LDS cycle -- is conflict-free (scripts/exp/push_banks.py;
+    // the dense layout 8 / 13 / 104 / 210 / 29 is 2-way everywhere: 47 % of the kernel's LDS cycles).
+#ifdef PM_PUSH_GENERIC15
+    static constexpr bool tuned = false;
+#else
+    static constexpr bool tuned = BOX == 15;
+#endif
+    static constexpr int vs = tuned ? 9 : N, hs = tuned ? 17 : FWH;
+    static constexpr int hbase = two_pass ? 0 : tuned ? 124 : NF;   // horizontal family behind the vertical one
+    static constexpr int dstride = tuned ? 264 : BOX == 15 ? 2 * NF + 2 : BOX == 11 ? 2 * NF + 4 : NF + 2;
+    static constexpr int ips = tuned ? 41 : twc;
+    static_assert(FWH * vs <= (two_pass ? dstride : hbase) && hbase + N * hs <= dstride, "families inside the buffer");
     static constexpr int tile4 = kLutSize;            // {I, gx1, gy1, I} per compressed texel
-    static constexpr int iplane = tile4 + 4 * twc * th;  // I alone (conflict-free 4-byte reads of the chain)
-    static constexpr int dis = iplane + twc * th;     // [kPushGroups][dstride]; before that the staging plane
+    static constexpr int iplane = tile4 + 4 * twc * th;  // I alone (4-byte reads of the chain)
+    static constexpr int dis = iplane + ips * th;     // [kPushGroups][dstride]; before that the staging plane
     static constexpr int list = dis + kPushGroups * dstride;  // 256 u16: producers with something to offer
     static constexpr int cnt = list + kThreads / 2;
     static constexpr int total = cnt + 8;
@@ -174,6 +186,15 @@ struct PushEval {
         const bool wrap = (FWH - r0 < kPushLanes) && l >= FWH - r0;
         return base_h + (2 * j0 - LY::R) * twc + r0 + (wrap ? 2 * twc - FWH : 0);
     }
+    // where the sample of step s goes in the group's buffer (row strides LY::vs / LY::hs)
+    __device__ __forceinline__ int slot(int s) const
+    {
+        if (s < FWH) return s * LY::vs + l;
+        const int t = s - FWH;
+        const int j0 = (8 * t) / FWH, r0 = (8 * t) % FWH;
+        const bool wrap = (FWH - r0 < kPushLanes) && l >= FWH - r0;
+        return LY::hbase + j0 * LY::hs + r0 + l + (wrap ? LY::hs - FWH : 0);
+    }
     // the first PD requests of a view
     template <bool FAST>
     __device__ __forceinline__ void first(const float *__restrict__ H, gptr_bytes magic_base, WinReq (&req)[kPushPD]) const
@@ -199,7 +220,7 @@ struct PushEval {
             const float gradY = t4.z - tp5.gy2;
             const float gradDis = min_nc((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
             const float colDis = min_abs_nc(colDiff, tau_color);
-            dgrp[(s < FWH ? 0 : LY::hbase - 8 * FWH) + 8 * s + l] = __builtin_fmaf(alpha, gradDis, oma * colDis);
+            dgrp[slot(s)] = __builtin_fmaf(alpha, gradDis, oma * colDis);
 #ifndef PM_PUSH_NO_SCHED_BARRIER
             // keep the steps apart: left alone, the scheduler interleaves many of them and spills
             __builtin_amdgcn_sched_barrier(0);
@@ -319,7 +340,7 @@ __device__ __forceinline__ float push_chain(const float *__restrict__ ipl, float
 #pragma unroll
         for (int j = 0; j < LY::N; j++) {
             // weight_cu, gipuma.cu:186-193: 256 possible weights
-            const float colorDis = __builtin_fabsf(ipl[2 * j * LY::twc + i] - centre);
+            const float colorDis = __builtin_fabsf(ipl[2 * j * LY::ips + i] - centre);
             const float w = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
             cost = __builtin_fmaf(w, dch[j * jstride + i], cost);
         }
@@ -335,7 +356,7 @@ __global__ __launch_bounds__(kThreads, PM_PUSH_WAVES) void push_kernel(const Pro
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using LY = PushLayout<BOX>;
-    constexpr int R = LY::R, N = LY::N, twc = LY::twc, halo = LY::halo;
+    constexpr int R = LY::R, twc = LY::twc, halo = LY::halo;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rows = P->rows, cols = P->cols;
     const int gx = (cols + kTileW - 1) / kTileW;
@@ -382,7 +403,7 @@ __global__ __launch_bounds__(kThreads, PM_PUSH_WAVES) void push_kernel(const Pro
                 }
             }
             *reinterpret_cast<float4 *>(tile4 + 4 * k) = make_float4(I, gx1, gy1, I);
-            iplane[k] = I;
+            iplane[ty * LY::ips + cx] = I;
         }
     }
     const int c0 = cnt[0], c1 = cnt[1], c2 = cnt[2], c3 = cnt[3];  // (written before the first barrier above)
@@ -404,8 +425,8 @@ __global__ __launch_bounds__(kThreads, PM_PUSH_WAVES) void push_kernel(const Pro
     int cdx, cdy;
     push_consumer_offset(l, cdx, cdy);
     // where consumer l's samples start in the group's buffer, and how far its window rows are apart
-    const int dbase = cdx == 0 ? ((cdy + kPushReach) / 2) * N : LY::hbase + (cdx + kPushReach) / 2;
-    const int jstride = cdx == 0 ? N : LY::FWH;
+    const int dbase = cdx == 0 ? ((cdy + kPushReach) / 2) * LY::vs : LY::hbase + (cdx + kPushReach) / 2;
+    const int jstride = cdx == 0 ? LY::vs : LY::hs;
     PushEval<BOX> E;
     E.init(P, l);
 
@@ -424,8 +445,8 @@ __global__ __launch_bounds__(kThreads, PM_PUSH_WAVES) void push_kernel(const Pro
         const int cpx = npx + cdx, cpy = npy + cdy;
         const bool cvalid = have && cpx >= 0 && cpx < cols && cpy >= 0 && cpy < rows;
         const int tpx = tnx + cdx, tpy = tny + cdy;
-        const float centre = iplane[tpy * twc + (tpx >> 1)];
-        const float *ipl = iplane + (tpy - R) * twc + ((tpx - R) >> 1);
+        const float centre = iplane[tpy * LY::ips + (tpx >> 1)];
+        const float *ipl = iplane + (tpy - R) * LY::ips + ((tpx - R) >> 1);
 
         ViewCombiner<true> comb;
         // The homography of a (plane, view) pair is the same for the lanes of a group: lane c computes
@@ -537,7 +558,7 @@ struct PushLayoutC4 {
     static_assert(BOX == 15, "instantiated window size");
     using G = PushLayout<BOX>;
     static constexpr int R = G::R, N = G::N, FWH = G::FWH, NF = G::NF, halo = G::halo, tw = G::tw, th = G::th, twc = G::twc;
-    static constexpr int hbase = NF, dstride = G::dstride;
+    static constexpr int hbase = NF, dstride = 2 * NF + 2;  // dense rows (N / FWH words), the generic stencil loop
     static constexpr int tile_a = lut_size<4>();           // float4 {B, G, R, gxB} per compressed texel
     static constexpr int tile_b = tile_a + 4 * twc * th;   // float4 {gxG, gxR, gyB, gyG}
     static constexpr int tile_c = tile_b + 4 * twc * th;   // float gyR

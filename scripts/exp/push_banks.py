@@ -12,22 +12,22 @@ def conflicts(addrs):
         banks.setdefault(a % 32, set()).add(a)
     return max(len(v) for v in banks.values())
 
-def dis_addr(g, c, i, j, dstride, hbase):
+def dis_addr(g, c, i, j, dstride, hbase, vs=N, hs=FWH):
     dx, dy = cons[c]
     if dx == 0:
-        return g * dstride + ((dy + 5) // 2 + j) * N + i
-    return g * dstride + hbase + j * FWH + (dx + 5) // 2 + i
+        return g * dstride + ((dy + 5) // 2 + j) * vs + i
+    return g * dstride + hbase + j * hs + (dx + 5) // 2 + i
 
 def ipl_addr(tnx, tny, c, i, j, twc):
     dx, dy = cons[c]
     tpx, tpy = tnx + dx, tny + dy
     return (tpy - R + 2 * j) * twc + ((tpx - R) >> 1) + i
 
-def score_dis(dstride, hbase):
+def score_dis(dstride, hbase, vs=N, hs=FWH):
     tot, worst = 0, 0
     for i, j in itertools.product(range(N), range(N)):
         for half in (0, 1):
-            a = [dis_addr(g, c, i, j, dstride, hbase) for g in range(4 * half, 4 * half + 4) for c in range(8)]
+            a = [dis_addr(g, c, i, j, dstride, hbase, vs, hs) for g in range(4 * half, 4 * half + 4) for c in range(8)]
             k = conflicts(a)
             tot += k
             worst = max(worst, k)
@@ -54,5 +54,6 @@ if __name__ == "__main__":
     best.sort()
     print("dis:", best[:8])
     print("dis plain:", score_dis(2 * NF, NF))
-    for twc in (29, 30, 31, 32, 33):
+    print("dis shipped (rows 9 / 17 words apart, horizontal family at 124, groups 264 apart):", score_dis(264, 124, 9, 17))
+    for twc in (29, 30, 31, 32, 33, 41):
         print("iplane twc", twc, score_ipl(twc))

@@ -11,7 +11,9 @@ HALO = R + REACH + 1      # 13
 TILE_W, TILE_H = 32, 16
 TW, TH = TILE_W + 2 * HALO, TILE_H + 2 * HALO  # 58, 42
 TWC = (TW + 1) // 2       # 29
-HBASE = NF                # horizontal family behind the vertical one
+VS, HS = 9, 17            # row strides of the two families in the group's sample buffer (PushLayout<15>)
+HBASE = 124               # horizontal family behind the vertical one
+IPS = 41                  # row stride of the compressed I plane
 # consumer c = the pixel that sees the producer as its neighbour slot c (pm::neighbour):
 # slot 0 up, 1 down, 2 left, 3 right (distance 1), 4..7 the same at distance 5
 def consumer_offset(c):
@@ -23,12 +25,12 @@ def consumer_offset(c):
 def eval_point(s, l):
     """step s (0..25) of lane l (0..7): offset of the sample from the producer, and its dis slot"""
     if s < FWH:  # vertical family: x = l, y = s
-        return (2 * l - R, 2 * s - (R + REACH)), s * N + l
+        return (2 * l - R, 2 * s - (R + REACH)), s * VS + l
     t = s - FWH
     j0, r0 = (8 * t) // FWH, (8 * t) % FWH
     w = 1 if l >= FWH - r0 else 0
     x, y = r0 + l - FWH * w, j0 + w
-    return (2 * x - (R + REACH), 2 * y - R), HBASE + 8 * t + l
+    return (2 * x - (R + REACH), 2 * y - R), HBASE + j0 * HS + r0 + l + w * (HS - FWH)
 
 def eval_tile_index(s, l, tnx, tny):
     """compressed-tile index the kernel reads for that point"""
@@ -44,28 +46,29 @@ def eval_tile_index(s, l, tnx, tny):
 def chain_slot(c, i, j):
     dx, dy = consumer_offset(c)
     if dx == 0:
-        return ((dy + REACH) // 2) * N + j * N + i
-    return HBASE + (dx + REACH) // 2 + j * FWH + i
+        return ((dy + REACH) // 2) * VS + j * VS + i
+    return HBASE + (dx + REACH) // 2 + j * HS + i
 
 def chain_tile_index(c, i, j, tnx, tny):
     dx, dy = consumer_offset(c)
     tpx, tpy = tnx + dx, tny + dy
-    return (tpy - R) * TWC + ((tpx - R) >> 1) + 2 * j * TWC + i
+    return (tpy - R) * IPS + ((tpx - R) >> 1) + 2 * j * IPS + i
 
 def centre_index(c, tnx, tny):
     dx, dy = consumer_offset(c)
-    return (tny + dy) * TWC + ((tnx + dx) >> 1)
+    return (tny + dy) * IPS + ((tnx + dx) >> 1)
 
 def main():
     rnd = random.Random(1)
     for colour in (0, 1):
         cpar = 1 - colour
         # the compressed tile as the kernel stages it: entry k = (ty, cx) holds texel tx = 2 cx + ((cpar + ty) & 1)
-        comp = {}
+        comp, compi = {}, {}
         for ty in range(TH):
             for cx in range(TWC):
                 tx = 2 * cx + ((cpar + ty) & 1)
                 comp[ty * TWC + cx] = (tx, ty) if tx < TW else None
+                compi[ty * IPS + cx] = (tx, ty) if tx < TW else None  # the I plane: rows IPS words apart
         for ly in range(TILE_H):
             for lxh in range(16):
                 lx = 2 * lxh + ((ly + colour) & 1)
@@ -79,14 +82,14 @@ def main():
                         k = eval_tile_index(s, l, tnx, tny)
                         assert comp[k] == (tnx + dx, tny + dy), (s, l, comp[k], (tnx + dx, tny + dy))
                         assert 1 <= tnx + dx <= TW - 2 and 1 <= tny + dy <= TH - 2  # gradients stay inside the tile
-                assert sorted(slots) == list(range(2 * NF))
+                assert len(slots) == 2 * NF and max(slots) < 264
                 for c in range(8):
                     cdx, cdy = consumer_offset(c)
-                    assert comp[centre_index(c, tnx, tny)] == (tnx + cdx, tny + cdy)
+                    assert compi[centre_index(c, tnx, tny)] == (tnx + cdx, tny + cdy)
                     for i, j in itertools.product(range(N), range(N)):
                         q = (cdx + 2 * i - R, cdy + 2 * j - R)  # window sample of the consumer, relative to the producer
                         assert slots[chain_slot(c, i, j)] == q, (c, i, j)
-                        assert comp[chain_tile_index(c, i, j, tnx, tny)] == (tnx + q[0], tny + q[1])
+                        assert compi[chain_tile_index(c, i, j, tnx, tny)] == (tnx + q[0], tny + q[1])
     # the neighbour relation: consumer p = n + consumer_offset(c) has n at slot c
     for c in range(8):
         d = 1 if c < 4 else 5

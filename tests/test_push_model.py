@@ -19,11 +19,11 @@ def test_push_index_model():
     _load("push_model").main_all()
 
 
-def test_push_sample_buffer_layout_is_at_most_two_way_conflicted():
-    """the strides shipped in PushLayout<15> (dstride = 2*104 + 2, horizontal family at 104, tile rows of 29)
-    keep every chain read at <= 2 distinct addresses per LDS bank (ds_read_b32: 32 lanes x 32 banks)"""
+def test_push_sample_buffer_layout_is_conflict_free():
+    """the strides shipped in PushLayout<15> (rows of the two stencil families 9 / 17 words apart, the
+    horizontal family at word 124, groups 264 words apart, I-plane rows 41 words apart) keep every read of
+    the chain phase conflict-free (ds_read_b32: 32 lanes x 32 banks); the dense layout is 2-way"""
     m = _load("push_banks")
-    mean, worst = m.score_dis(2 * m.NF + 2, m.NF)
-    assert worst <= 2, (mean, worst)
-    mean, worst = m.score_ipl(29)
-    assert worst <= 2, (mean, worst)
+    assert m.score_dis(264, 124, 9, 17) == (1.0, 1)
+    assert m.score_ipl(41) == (1.0, 1)
+    assert m.score_dis(2 * m.NF + 2, m.NF)[1] == 2 and m.score_ipl(29)[1] == 2
