@@ -296,17 +296,57 @@ void gipuma_oracle_sample5(const float *img, int rows, int cols, int pitch, floa
  * (pmCost/pmCostComputation, :455-518/:278-320, used by the init kernel, are the same function
  * of the images -- SURVEY 3.4)
  * ---------------------------------------------------------------------------------------- */
-static float go_view_cost(const gipuma_hip_desc *d, int view, int px, int py, const float pl[4])
+/* dis of one window sample: the warp of q = (ix, iy) through H (getCorrespondingPoint_cu, gipuma.cu:207-217),
+ * the five bilinear taps and the truncated colour / gradient differences of pmCostComputation_shared
+ * (gipuma.cu:251-274).  A function of (q, H, view) only -- not of the pixel whose window q belongs to
+ * (what pm_push.h builds on, see gipuma_oracle_push_costs). */
+static inline float go_dis_at(const gipuma_hip_desc *d, int view, const float *H, int ix, int iy,
+                              float leftValue)
 {
     const gipuma_hip_params *ap = &d->params;
     const int rows = d->rows, cols = d->cols, pitch = d->pitch;
     const float *ref = d->images[0];
     const float *src = d->images[view];
+    const float alpha = ap->alpha, tau_color = ap->tau_color, tau_gradient = ap->tau_gradient;
+    const float oma = 1.f - alpha;
+    const float qx = (float)ix, qy = (float)iy;
+    /* M3: H*(qx,qy,1) as fmaf(h1, qy, fmaf(h0, qx, h2)) (matvecmul4noz, config.h:150-162) */
+    const float X0 = fmaf(H[0], qx, H[2]);
+    const float Y0 = fmaf(H[3], qx, H[5]);
+    const float Z0 = fmaf(H[6], qx, H[8]);
+    /* getCorrespondingPoint_cu, gipuma.cu:207-217 (M2: multiply by 1/z) */
+    const float X = fmaf(H[1], qy, X0);
+    const float Y = fmaf(H[4], qy, Y0);
+    const float Z = fmaf(H[7], qy, Z0);
+    const float rz = 1.0f / Z;
+    const float sx = X * rz, sy = Y * rz;
+    /* pmCostComputation_shared, gipuma.cu:251-274 */
+    float s[5];
+    go_sample5(src, rows, cols, pitch, sx, sy, s);
+    const float gx2 = s[1] - s[2];
+    const float gy2 = s[3] - s[4];
+    const float colDiff = fabsf(leftValue - s[0]);
+    const float up = go_texel(ref, rows, cols, pitch, ix, iy - 1);
+    const float down = go_texel(ref, rows, cols, pitch, ix, iy + 1);
+    const float left = go_texel(ref, rows, cols, pitch, ix - 1, iy);
+    const float right = go_texel(ref, rows, cols, pitch, ix + 1, iy);
+    const float gx1 = right - left;
+    const float gy1 = down - up;
+    const float gradX = gx1 - gx2;
+    const float gradY = gy1 - gy2;
+    const float gradDis = fminf((fabsf(gradX) + fabsf(gradY)) * 0.0625f, tau_gradient);
+    const float colDis = fminf(colDiff, tau_color);
+    return fmaf(alpha, gradDis, oma * colDis);
+}
+
+static float go_view_cost(const gipuma_hip_desc *d, int view, int px, int py, const float pl[4])
+{
+    const gipuma_hip_params *ap = &d->params;
+    const int rows = d->rows, cols = d->cols, pitch = d->pitch;
+    const float *ref = d->images[0];
     const int hRad = (ap->box_hsize - 1) / 2; /* gipuma.cu:1474 (init uses box/2, same for odd) */
     const int vRad = (ap->box_vsize - 1) / 2;
-    const float alpha = ap->alpha, tau_color = ap->tau_color, tau_gradient = ap->tau_gradient;
     const float gamma = ap->gamma;
-    const float oma = 1.f - alpha;
 
     float H[9];
     go_homography(&d->cameras[0], &d->cameras[view], pl, pl[3], H);
@@ -314,41 +354,13 @@ static float go_view_cost(const gipuma_hip_desc *d, int view, int px, int py, co
     const float centre = go_texel(ref, rows, cols, pitch, px, py);
     float cost = 0.0f;
     for (int i = -hRad; i < hRad + 1; i += GO_WIN_INCREMENT) {
-        const float qx = (float)(px + i);
-        /* M3: H*(qx,qy,1) as fmaf(h1, qy, fmaf(h0, qx, h2)) (matvecmul4noz, config.h:150-162) */
-        const float X0 = fmaf(H[0], qx, H[2]);
-        const float Y0 = fmaf(H[3], qx, H[5]);
-        const float Z0 = fmaf(H[6], qx, H[8]);
         for (int j = -vRad; j < vRad + 1; j += GO_WIN_INCREMENT) {
             const int ix = px + i, iy = py + j;
-            const float qy = (float)iy;
             /* weight_cu, gipuma.cu:186-193 */
             const float leftValue = go_texel(ref, rows, cols, pitch, ix, iy);
             const float colorDis = fabsf(leftValue - centre);
             const float w = go_exp(-colorDis / gamma);
-            /* getCorrespondingPoint_cu, gipuma.cu:207-217 (M2: multiply by 1/z) */
-            const float X = fmaf(H[1], qy, X0);
-            const float Y = fmaf(H[4], qy, Y0);
-            const float Z = fmaf(H[7], qy, Z0);
-            const float rz = 1.0f / Z;
-            const float sx = X * rz, sy = Y * rz;
-            /* pmCostComputation_shared, gipuma.cu:251-274 */
-            float s[5];
-            go_sample5(src, rows, cols, pitch, sx, sy, s);
-            const float gx2 = s[1] - s[2];
-            const float gy2 = s[3] - s[4];
-            const float colDiff = fabsf(leftValue - s[0]);
-            const float up = go_texel(ref, rows, cols, pitch, ix, iy - 1);
-            const float down = go_texel(ref, rows, cols, pitch, ix, iy + 1);
-            const float left = go_texel(ref, rows, cols, pitch, ix - 1, iy);
-            const float right = go_texel(ref, rows, cols, pitch, ix + 1, iy);
-            const float gx1 = right - left;
-            const float gy1 = down - up;
-            const float gradX = gx1 - gx2;
-            const float gradY = gy1 - gy2;
-            const float gradDis = fminf((fabsf(gradX) + fabsf(gradY)) * 0.0625f, tau_gradient);
-            const float colDis = fminf(colDiff, tau_color);
-            const float dis = fmaf(alpha, gradDis, oma * colDis);
+            const float dis = go_dis_at(d, view, H, ix, iy, leftValue);
             cost = fmaf(w, dis, cost);
         }
     }
@@ -501,6 +513,71 @@ float gipuma_oracle_multiview_cost(const gipuma_hip_desc *d, int x, int y, const
 {
     return go_multiview_cost(d, x, y, plane);
 }
+
+/* The push formulation of gipuma_amd/csrc/pm_push.h restated on the CPU (gray images, square window):
+ * the plane of producer (nx, ny) is a propagation candidate of its eight neighbours of the other
+ * checkerboard colour -- slot c of pm::neighbour: the pixel that sees the producer up, down, left, right
+ * at distance 1 (c = 0..3) and 5 (c = 4..7; gipuma.cu:1437-1462, 1571-1582).  dis is evaluated ONCE per
+ * view on the stencil those eight windows share -- (N+5) x N points per family instead of 4 x N x N --,
+ * then every consumer runs the reference's chain over its own window (its own support weights, columns
+ * outer, rows inner, gipuma.cu:633-676) on the stored values, and its view costs are combined as in
+ * pmCostMultiview_cu.  out[c] must equal go_multiview_cost(consumer c, plane) bit for bit wherever the
+ * consumer lies inside the image; valid[c] = 0 elsewhere.  Returns the number of dis evaluations per view. */
+int gipuma_oracle_push_costs(const gipuma_hip_desc *d, int nx, int ny, const float plane[4], float out[8],
+                             int valid[8])
+{
+    const gipuma_hip_params *ap = &d->params;
+    const int rows = d->rows, cols = d->cols, pitch = d->pitch;
+    const float *ref = d->images[0];
+    if (d->channels != 1 || ap->box_hsize != ap->box_vsize) return -1;
+    const int R = (ap->box_hsize - 1) / 2, N = (2 * R) / GO_WIN_INCREMENT + 1, FW = N + 5; /* offsets -R, -R+2, ..., R */
+    if (N * FW > 512) return -1;
+    float cv[8][GIPUMA_HIP_MAX_VIEWS];
+    int cdx[8], cdy[8];
+    for (int c = 0; c < 8; c++) {
+        const int dist = c < 4 ? 1 : 5, k = c & 3;
+        cdx[c] = k == 2 ? dist : k == 3 ? -dist : 0; /* consumer = producer - neighbour offset of slot k */
+        cdy[c] = k == 0 ? dist : k == 1 ? -dist : 0;
+        const int px = nx + cdx[c], py = ny + cdy[c];
+        valid[c] = px >= 0 && px < cols && py >= 0 && py < rows;
+    }
+    for (int v = 0; v < d->n_selected; v++) {
+        const int view = d->selected[v];
+        float H[9];
+        go_homography(&d->cameras[0], &d->cameras[view], plane, plane[3], H);
+        /* vertical family (consumers above / below): offsets (2x - R, 2y - R - 5), x < N, y < N + 5;
+         * horizontal family: offsets (2x - R - 5, 2y - R), x < N + 5, y < N */
+        float disV[512], disH[512];
+        for (int y = 0; y < FW; y++)
+            for (int x = 0; x < N; x++) {
+                const int ix = nx + 2 * x - R, iy = ny + 2 * y - R - 5;
+                disV[y * N + x] = go_dis_at(d, view, H, ix, iy, go_texel(ref, rows, cols, pitch, ix, iy));
+            }
+        for (int y = 0; y < N; y++)
+            for (int x = 0; x < FW; x++) {
+                const int ix = nx + 2 * x - R - 5, iy = ny + 2 * y - R;
+                disH[y * FW + x] = go_dis_at(d, view, H, ix, iy, go_texel(ref, rows, cols, pitch, ix, iy));
+            }
+        for (int c = 0; c < 8; c++) {
+            const int px = nx + cdx[c], py = ny + cdy[c];
+            const float centre = go_texel(ref, rows, cols, pitch, px, py);
+            float cost = 0.0f;
+            for (int i = 0; i < N; i++)
+                for (int j = 0; j < N; j++) {
+                    const float leftValue = go_texel(ref, rows, cols, pitch, px + 2 * i - R, py + 2 * j - R);
+                    const float w = go_exp(-fabsf(leftValue - centre) / ap->gamma);
+                    const float dis = cdx[c] == 0 ? disV[((cdy[c] + 5) / 2 + j) * N + i]
+                                                  : disH[j * FW + (cdx[c] + 5) / 2 + i];
+                    cost = fmaf(w, dis, cost);
+                }
+            cv[c][v] = cost;
+        }
+    }
+    for (int c = 0; c < 8; c++)
+        out[c] = go_aggregate(cv[c], d->n_selected, ap->cost_comb, ap->n_best, ap->good_factor);
+    return 2 * N * FW;
+}
+
 
 /* ------------------------------------------------------------------------------------------
  * per-pixel stages

@@ -57,6 +57,11 @@ float gipuma_oracle_aggregate(const float *view_costs, int n, int cost_comb, int
 float gipuma_oracle_view_cost(const gipuma_hip_desc *d, int view, int x, int y,
                               const float plane[4]);
 float gipuma_oracle_multiview_cost(const gipuma_hip_desc *d, int x, int y, const float plane[4]);
+/* the push formulation of gipuma_amd/csrc/pm_push.h restated on the CPU: the costs of producer (nx, ny)'s
+ * plane at its eight consumers from ONE evaluation of dis per view on the stencil their windows share;
+ * out[c] == gipuma_oracle_multiview_cost(consumer c, plane) bit for bit (tests/test_oracle_kat.py) */
+int gipuma_oracle_push_costs(const gipuma_hip_desc *d, int nx, int ny, const float plane[4], float out[8],
+                             int valid[8]);
 float gipuma_oracle_depth_from_plane(const gipuma_hip_camera *cam, const float plane[4], int x,
                                      int y);
 float gipuma_oracle_plane_d(const gipuma_hip_camera *cam, const float n[3], int x, int y,

@@ -49,6 +49,7 @@ def lib():
         L.gipuma_oracle_view_cost.restype = C.c_float
         L.gipuma_oracle_multiview_cost.argtypes = [D, C.c_int, C.c_int, _FP]
         L.gipuma_oracle_multiview_cost.restype = C.c_float
+        L.gipuma_oracle_push_costs.argtypes = [D, C.c_int, C.c_int, _FP, _FP, C.POINTER(C.c_int)]
         L.gipuma_oracle_depth_from_plane.argtypes = [C.POINTER(abi.Camera), _FP, C.c_int, C.c_int]
         L.gipuma_oracle_depth_from_plane.restype = C.c_float
         L.gipuma_oracle_plane_d.argtypes = [C.POINTER(abi.Camera), _FP, C.c_int, C.c_int, C.c_float]

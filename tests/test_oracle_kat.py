@@ -305,3 +305,45 @@ def test_view_selection_matches_survey():
         assert len(sub) == want
         # reference camera is K[I|0] after re-centring (cameraGeometryUtils.h:268-298)
         assert np.allclose(cs.R[0], np.eye(3), atol=1e-9) and np.allclose(cs.t[0], 0, atol=1e-6)
+
+
+@pytest.mark.parametrize("box,n_best,comb", [(15, 3, abi.COMB_BEST_N), (11, 2, abi.COMB_BEST_N), (25, 3, abi.COMB_BEST_N),
+                                             (7, 1, abi.COMB_ALL), (9, 2, abi.COMB_GOOD)])
+def test_push_formulation_is_exact_on_the_cpu(box, n_best, comb):
+    """What gipuma_amd/csrc/pm_push.h builds on, checked without a GPU: dis_v(q, plane) does not depend on
+    the pixel whose window q belongs to (gipuma.cu:207-274), so the plane of a pixel can be evaluated ONCE per
+    view on the stencil that the windows of its eight checkerboard consumers share (n +- 1, n +- 5 in x and
+    y, gipuma.cu:1437-1462) -- 2 x (N+5) x N points instead of 8 x N x N -- and every consumer's cost follows
+    from the reference's summation over its own window (gipuma.cu:633-676).  gipuma_oracle_push_costs restates
+    that data flow; it must give the bits of pmCostMultiview_cu (gipuma_oracle_multiview_cost) at every consumer,
+    for planes of every kind, at image borders, for every combiner."""
+    gs, _ = synth.build_problem(synth.tiny_config(cols=72, rows=56, n_src=4, blocksize=box, iterations=1,
+                                                  n_best=n_best), cost_comb=comb)
+    o = OracleState(gs)
+    o.init_planes()
+    rng = np.random.default_rng(box)
+    pts = [(0, 0), (gs.cols - 1, gs.rows - 1), (3, gs.rows - 2), (gs.cols - 4, 1), (5, 5)]
+    pts += [(int(rng.integers(0, gs.cols)), int(rng.integers(0, gs.rows))) for _ in range(7)]
+    L = lib()
+    n_side = (box + 1) // 2
+    checked = 0
+    for (nx, ny) in pts:
+        for plane in (np.ascontiguousarray(o.norm4[ny, nx]),                       # the pixel's own (random) plane
+                      np.array([0.0, 0.0, -1.0, 550.0], dtype=np.float32),          # fronto-parallel, mid range
+                      np.array([0.3, -0.2, -0.93, 0.0], dtype=np.float32)):         # degenerate: d = 0
+            out = (C.c_float * 8)()
+            valid = (C.c_int * 8)()
+            n_dis = L.gipuma_oracle_push_costs(C.byref(gs.desc), nx, ny, fptr(plane), out, valid)
+            assert n_dis == 2 * n_side * (n_side + 5)
+            for c in range(8):
+                dist = 1 if c < 4 else 5
+                dx, dy = [(0, dist), (0, -dist), (dist, 0), (-dist, 0)][c & 3]
+                px, py = nx + dx, ny + dy
+                inside = 0 <= px < gs.cols and 0 <= py < gs.rows
+                assert bool(valid[c]) == inside
+                if inside:
+                    want = L.gipuma_oracle_multiview_cost(C.byref(gs.desc), px, py, fptr(plane))
+                    got = np.float32(out[c])
+                    assert np.float32(want).view(np.uint32) == got.view(np.uint32), (box, nx, ny, c, want, got)
+                    checked += 1
+    assert checked > 200
