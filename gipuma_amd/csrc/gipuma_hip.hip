@@ -11,9 +11,7 @@
 //   * no per-pixel RNG state array (48 B/pixel, gipuma.cu:1840): the RNG is counter based.
 #include "../../include/gipuma_hip.h"
 #include "pm_device.h"
-#include "pm_prop_shared.h"
 #include "pm_push.h"
-#include "pm_refine_rows.h"
 
 #include <algorithm>
 #include <cmath>
@@ -69,12 +67,6 @@ struct gipuma_hip_session {
     bool own_stream = false;
     bool u8 = false;         // every image integer valued in [0,255] -> weight table + packed windows
     std::vector<uint32_t *> packed;  // window-packed copies of the selected views (U8 mode)
-    std::vector<uint32_t *> packed_t;  // ... and their column-major variants (row-per-lane refinement)
-    bool rows_kernel = false;  // pm::sweep_rows_kernel usable
-    int rows_from = 0;         // first half-sweep (2*iteration + colour) that uses it
-    bool shared_fused = false;  // ... with the refinement stage in the same launch (experiment)
-    int shared_from = 0;       // first half-sweep that uses the shared-sample propagation kernel (when enabled)
-    size_t lds_rows = 0;
     int *flag = nullptr;
     bool combine_reg = false;
     bool unfused = false;
@@ -107,7 +99,6 @@ struct gipuma_hip_session {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // experiment aid (GIPUMA_HIP_LAUNCH_TIMES=1): one event per half-sweep launch of gipuma_hip_solve,
     // durations printed to stderr
-    bool prop_attr_set = false;
     bool launch_times = false;
     std::vector<hipEvent_t> lev;
     std::vector<float> half_sweep_ms;  // of the last timed gipuma_hip_solve (gipuma_hip_launch_times)
@@ -256,7 +247,7 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
     // its own planes to the next one
     const int half_sweep = 2 * iteration + colour;
     const bool push_now = s->push_ok && qualifies && half_sweep < s->push_launches &&
-                          !(tune & (Tune::kNoSkip | Tune::kSharedProp | Tune::kRowsKernel));
+                          !(tune & Tune::kNoSkip);
     if (push_now) {
         const bool hist = (tune & Tune::kHistorySkip) != 0;
         if (s->push_valid != colour || s->push_hist != hist) {
@@ -268,7 +259,7 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
     }
     s->push_valid = -1;  // the planes of `colour` are about to change
     const bool push_next = s->push_ok && qualifies && half_sweep + 1 < s->push_launches &&
-                           !(tune & (Tune::kNoSkip | Tune::kSharedProp | Tune::kRowsKernel));
+                           !(tune & Tune::kNoSkip);
     // task order (performance only): planes are still incoherent in the first two iterations, where
     // grouping the evaluations of one plane saves cache-line fills; afterwards owner order is faster
     if (iteration >= 2 && !(tune & Tune::kSourceMajorTasks)) tune |= Tune::kOwnerMajorTasks;
@@ -290,34 +281,6 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
             k = s->combine_reg ? pm::sweep_cols_kernel<15, true> : pm::sweep_cols_kernel<15, false>;
         else
             k = s->combine_reg ? pm::sweep_cols_kernel<25, true> : pm::sweep_cols_kernel<25, false>;
-    } else if (s->rows_kernel && 2 * iteration + colour >= s->rows_from) {
-        // refinement by groups of 8 lanes (row per lane, column-major packed views, group-level early exit)
-        k = pm::sweep_rows_kernel<15>;
-        lds = s->lds_rows;
-    }
-    // propagation with shared patch samples (pm_prop_shared.h) where that instantiation exists; the
-    // refinement stage follows as its own launch of the kernel chosen above
-    const bool shared_ok = s->u8 && s->ch == 1 && s->hp.magic_addr && (s->box == 15 || s->box == 11) &&
-                           s->combine_reg && (stages & 3u) && (tune & Tune::kSharedProp) &&
-                           2 * iteration + colour >= s->shared_from &&
-                           !(tune & (Tune::kNoSkip | Tune::kNoInterior));
-    if (shared_ok) {
-        typedef void (*prop_fn)(const pm::Problem *, float4 *, float *, int, unsigned, unsigned, uint32_t);
-        const prop_fn pk = s->box == 15 ? pm::prop_shared_kernel<15> : pm::prop_shared_kernel<11>;
-        const size_t plds = sizeof(float) * (size_t)(s->box == 15 ? pm::PsLayout<15>::total : pm::PsLayout<11>::total);
-        if (!s->prop_attr_set) {
-            HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(pk), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)plds));
-            s->prop_attr_set = true;
-        }
-        // (GIPUMA_HIP_SHARED_FUSED: the refinement stage in the same launch)
-        const bool fused = s->shared_fused && (stages & 4u);
-        hipLaunchKernelGGL(pk, dim3(gx * gy), dim3(pm::kThreads), plds, s->stream, s->dp, s->norm4, s->cost, colour,
-                           fused ? stages : (stages & 3u), tune, phase);
-        HIP_OK(hipGetLastError());
-        if (fused || !(stages & 4u)) return 0;
-        stages = 4u;
-        tune |= Tune::kAccumChanged;
     }
     hipLaunchKernelGGL(k, dim3(gx * gy), dim3(pm::kThreads), lds, s->stream, s->dp, s->norm4,
                        s->cost, colour, phase, stages, tune);
@@ -599,32 +562,6 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         s->box = 0;  // the no-interior A/B arm only exists for these two variants
         s->combine_reg = false;
     }
-    // row-per-lane refinement (pm_refine_rows.h): box 15, register combiner, packed gray planes whose
-    // column-major copy also fits float-encoded offsets
-    hp.ph = d->rows + 8;
-    s->rows_kernel = s->u8 && s->ch == 1 && hp.magic_addr && s->box == 15 && s->combine_reg &&
-                     (s->tune & Tune::kRowsKernel) && !(s->tune & Tune::kNoInterior) &&
-                     (size_t)(d->cols + 3) * (size_t)hp.ph <= (size_t)pm::kMagicMaxWords;
-    if (const char *t = getenv("GIPUMA_HIP_ROWS_FROM")) s->rows_from = atoi(t);  // experiment
-    if (const char *t = getenv("GIPUMA_HIP_SHARED_FROM")) s->shared_from = atoi(t);  // experiment
-    if (const char *t = getenv("GIPUMA_HIP_SHARED_FUSED")) s->shared_fused = atoi(t) != 0;
-    if (s->rows_kernel) {
-        const size_t words = (size_t)(d->cols + 3) * (size_t)hp.ph;
-        const dim3 pgid((hp.ph + pm::kThreads - 1) / pm::kThreads, d->cols + 3);
-        for (int i = 0; i < d->n_selected; i++) {
-            uint32_t *pk = nullptr;
-            CREATE_OK(hipMalloc(&pk, words * sizeof(uint32_t)));
-            s->packed_t.push_back(pk);
-            hp.view[i].packed_t = pk;
-            hipLaunchKernelGGL(pm::pack_t_kernel, pgid, dim3(pm::kThreads), 0, s->stream, hp.view[i].img, hp.rows,
-                               hp.cols, hp.pitch, hp.ph, pk);
-        }
-        CREATE_OK(hipGetLastError());
-        const int hw = (hp.box_h + 1) / 2;
-        const int texels = (pm::kTileW + 2 * hw + pm::kRowsTilePad) * (pm::kSweepTileH + 2 * hw);
-        s->lds_rows = sizeof(float) * ((size_t)pm::lut_size<1>() + (size_t)4 * texels +
-                                       (size_t)pm::work_floats<1>(texels, true));
-    }
     // early termination of refinement evaluations (pm::multiview_cost): only where every view cost is
     // provably finite and below MAXCOST for every plane, so that numValid == n_sel always
     // (gipuma.cu:771-775): weights exp(-k/gamma) <= 1 from the table, dis <= (1-alpha)*tau_c + alpha*tau_g
@@ -649,7 +586,7 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         hp.et_theta[1] = 1.0f;
         // the two-phase refinement (compile-time box) redoes open candidates item by item, which
         // is cheap; the per-wavefront bound repeats the whole wavefront and wants a looser third bound
-        const bool two_phase = s->box > 0 && !(s->tune & (Tune::kNoTwoPhase | Tune::kRegroup));
+        const bool two_phase = s->box > 0 && !(s->tune & Tune::kNoTwoPhase);
         hp.et_theta[2] = two_phase ? 1.0f : 1.5f;
         if (const char *g = getenv("GIPUMA_HIP_TP_G0")) hp.tp_g0 = atoi(g);  // experiment: phase-1 columns
         if (const char *t = getenv("GIPUMA_HIP_ET_THETA")) {  // experiment: "t0,t1,t2" (any value is exact)
@@ -684,10 +621,6 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         g_err = keep;
         return GIPUMA_HIP_ERR_UNSUPPORTED;
     }
-#ifdef PM_PS_PROFILE
-    CREATE_OK(hipMalloc(&hp.prof, 16 * sizeof(unsigned long long)));
-    CREATE_OK(hipMemsetAsync(hp.prof, 0, 16 * sizeof(unsigned long long), s->stream));
-#endif
     CREATE_OK(hipMalloc(&s->dp, sizeof(pm::Problem)));
     CREATE_OK(hipMemcpyAsync(s->dp, &hp, sizeof(pm::Problem), hipMemcpyHostToDevice, s->stream));
     CREATE_OK(hipStreamSynchronize(s->stream));  // host image buffers may be released by the caller
@@ -701,20 +634,8 @@ int gipuma_hip_destroy(gipuma_hip_session *s)
     if (!s) return 0;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-#ifdef PM_PS_PROFILE
-    if (s->hp.prof) {
-        unsigned long long h[16];
-        if (hipMemcpy(h, s->hp.prof, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
-            fprintf(stderr, "prop_shared profile (100 MHz ticks along wavefront 0, summed over workgroups):");
-            for (int i = 0; i < 12; i++) fprintf(stderr, " %llu", h[i]);
-            fprintf(stderr, "\n");
-        }
-        (void)hipFree(s->hp.prof);
-    }
-#endif
     for (float *p : s->owned) (void)hipFree(p);
     for (uint32_t *p : s->packed) (void)hipFree(p);
-    for (uint32_t *p : s->packed_t) (void)hipFree(p);
     if (s->flag) (void)hipFree(s->flag);
     if (s->dp) (void)hipFree(s->dp);
     if (s->changed) (void)hipFree(s->changed);

@@ -32,7 +32,6 @@ struct ViewCam {  // Camera_cu of a selected source view + its image plane
     int pad;
     const float *img;        // float plane (row-major, Problem::pitch)
     const uint32_t *packed;  // window-packed u8 copy (see pack_kernel), or nullptr
-    const uint32_t *packed_t;  // column-major variant (see pack_t_kernel), or nullptr
 };
 struct Problem {  // lives in device memory, read through scalar loads (wave-uniform)
     int rows, cols, pitch, n_sel;
@@ -43,7 +42,6 @@ struct Problem {  // lives in device memory, read through scalar loads (wave-uni
     const float *ref;
     int pw, channels;  // packed layout: texels per row of V (cols + 8); 1 = gray, 4 = colour
     int magic_addr;    // gray packed planes small enough (< 2^21 words) for float-encoded offsets
-    int ph;            // column-major packed layout: words per column of VT (rows + 8)
     unsigned char *changed;  // per pixel: did its plane change in its colour's last half-sweep (history rule)
     // early termination of refinement evaluations (see multiview_cost): enabled by the host when every
     // view cost is provably finite and below MAXCOST; theta of refinement step 0, 1, 2+
@@ -64,9 +62,6 @@ struct Problem {  // lives in device memory, read through scalar loads (wave-uni
     // after the previous half-sweep for the pixels of the other colour; read instead of evaluated
     // when the host sets Tune::kPushConsume
     float *push_cost;
-#ifdef PM_PS_PROFILE
-    unsigned long long *prof;  // experiment builds only
-#endif
     RefCam rc;
     ViewCam view[kMaxViews];
 };
@@ -288,9 +283,6 @@ struct Tune {  // experiment switches (GIPUMA_HIP_TUNE), all default off
                               kUntrustedCosts = 128,  // set by the host after gipuma_hip_set_state
                               kPushConsume = 1u << 18,   // host-internal: propagation costs come from Problem::push_cost
                               kNoTwoPhase = 1u << 19,    // refinement bounded per wavefront (v11) instead of two-phase (refine_two_phase)
-                              kRegroup = 1u << 22,       // opt-in: lanes swap pixels before refinement (see regroup_for_refinement; measured: no gain)
-                              kRowsKernel = 1u << 21,    // refinement by the row-per-lane kernel (pm_refine_rows.h); opt-in: not faster when fused
-                              kSharedProp = 1u << 20,    // propagation by the shared-sample kernel (pm_prop_shared.h); opt-in while it is slower
                               kNoMagicAddr = 1u << 30,  // integer window addressing (bits 8..17: band height)
                               kOwnerMajorTasks = 1u << 29,   // always owner-major task lists
                               kSourceMajorTasks = 1u << 28,  // always source-major (default: by iteration)
@@ -1861,88 +1853,6 @@ __device__ __forceinline__ void owner_pixel(const SweepLane &L, int owner, int c
     olx = 2 * (owner & 15) + ((oly + colour) & 1);
 }
 
-// Regrouping before the refinement rounds (performance only; OPT-IN, Tune::kRegroup: on config C the
-// sort + exchange costs what the tighter wavefronts save, 115.2 vs 114.7 ms same box).  The bounded evaluation of
-// multiview_cost leaves a view when the SLOWEST lane of the wavefront has reached its bound, and how
-// soon a lane gets there is predictable: the first refinement candidates are far-off planes whose
-// dis is close to saturation, so their partial sums grow like the running sum of the pixel's
-// support weights, and the bound is the pixel's own cost.  Lanes are therefore re-dealt: every
-// lane computes the window column at which 0.6 * dis_max * (weights so far) reaches its cost, the
-// 256 pixels of the tile are sorted by that key (counting sort in LDS) and each lane adopts the
-// pixel of its rank -- plane, cost, change flag, position -- for the whole refinement stage and
-// writes that pixel back.  Wavefronts then hold pixels that stop at similar columns
-// (scripts/exp/et_stats.py: 51 / 61 % of the samples of steps 0 / 1 -> 39 / 53 %).  Results cannot
-// depend on which lane refines a pixel: the draws are keyed by the pixel (M4).
-template <int BOX>
-__device__ __forceinline__ void regroup_for_refinement(SweepLane &L, const Problem *__restrict__ P,
-                                                       const float *__restrict__ lut, int colour)
-{
-    constexpr int R = (BOX - 1) / 2, N = R + 1;
-    constexpr int kBins = 4 * N + 1;
-    static_assert(kBins <= 64, "one wavefront scans the histogram");
-    float *xpl = L.bres;                                   // [256] float4
-    float *xcst = L.bres + 4 * kThreads;                   // [256]
-    int *xinfo = reinterpret_cast<int *>(L.bres + 5 * kThreads);  // [256] lx | ly << 8 | chg << 16 | active << 17
-    int *hist = reinterpret_cast<int *>(L.btask);          // [64] + [64] (the task list is dead)
-    // key of this lane's pixel
-    int key = kBins - 1;
-    if (L.active) {
-        const float dis_max = (1.f - P->alpha) * P->tau_color + P->alpha * P->tau_gradient;
-        const float K = 0.6f * dis_max;
-        const float *tp0 = L.tile + ((L.ly + L.hh) * L.tw + (L.lx + L.hw)) * 4;
-        const float centre = tp0[0];
-        const char *lut_magic = (const char *)lut - kMagicBits;
-        float wsum = 0.0f;
-        bool found = false;
-#pragma unroll
-        for (int i = 0; i < N; i++) {
-#pragma unroll
-            for (int j = 0; j < N; j++) {
-                const float colorDis = __builtin_fabsf(tp0[4 * ((2 * j - R) * L.tw + (2 * i - R))] - centre);
-                wsum += *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
-            }
-            const float reach = K * wsum;
-            if (!found && reach >= L.cst) {
-                found = true;
-                const int q = min(3, max(0, (int)(L.cst / reach * 4.0f)));
-                key = 4 * i + q;
-            }
-        }
-    }
-    if (threadIdx.x < 128) hist[threadIdx.x] = 0;
-    __syncthreads();
-    const int rank_in_bin = atomicAdd(&hist[key], 1);
-    __syncthreads();
-    if (threadIdx.x < 64) {  // exclusive scan of the bins by the first wavefront
-        const int v = (int)threadIdx.x < kBins ? hist[threadIdx.x] : 0;
-        int incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int up = __shfl_up(incl, d);
-            if ((int)threadIdx.x >= d) incl += up;
-        }
-        hist[64 + threadIdx.x] = incl - v;
-    }
-    __syncthreads();
-    const int rank = hist[64 + key] + rank_in_bin;
-    *reinterpret_cast<float4 *>(xpl + 4 * rank) = L.pl;
-    xcst[rank] = L.cst;
-    xinfo[rank] = L.lx | (L.ly << 8) | ((int)L.chg << 16) | ((int)L.active << 17);
-    __syncthreads();
-    L.pl = *reinterpret_cast<const float4 *>(xpl + 4 * threadIdx.x);
-    L.cst = xcst[threadIdx.x];
-    const int info = xinfo[threadIdx.x];
-    L.lx = info & 255;
-    L.ly = (info >> 8) & 255;
-    L.chg = (unsigned)(info >> 16) & 1u;
-    L.active = ((info >> 17) & 1) != 0;
-    L.px = L.x0 + L.lx;
-    L.py = L.y0 + L.ly;
-    L.center = L.py * P->cols + L.px;
-    (void)colour;
-    __syncthreads();  // bres / btask may be reused
-}
-
 // Two-phase evaluation of one refinement step of a workgroup (performance only; packed 8-bit planes
 // -- gray with float-encoded offsets or colour --, compile-time box, register combiner).
 //
@@ -2165,8 +2075,6 @@ __global__ __launch_bounds__(kThreads, U8 ? 4 : 1) void sweep_kernel(const Probl
         if (r == prop_rounds) {
             __syncthreads();  // every wavefront runs the same number of rounds, so this is uniform
             sweep_replay(L, P, norm4, (tune & Tune::kPushConsume) != 0);
-            if constexpr (ET && CH == 1 && BOX > 0)
-                if (et_on && R.nref > 0 && (tune & Tune::kRegroup)) regroup_for_refinement<BOX>(L, P, lds, colour);
             refine_begin(R, L, P, phase);
             if constexpr (ET && BOX > 0)
                 if (et_on) __syncthreads();  // refine_two_phase reuses the candidate costs the replay has just read
@@ -2198,7 +2106,7 @@ __global__ __launch_bounds__(kThreads, U8 ? 4 : 1) void sweep_kernel(const Probl
             refine_next_step(R);
         }
         if constexpr (ET && BOX > 0) {
-            if (et_on && r >= prop_rounds && r - prop_rounds < 3 && !(tune & (Tune::kNoTwoPhase | Tune::kRegroup)) &&
+            if (et_on && r >= prop_rounds && r - prop_rounds < 3 && !(tune & Tune::kNoTwoPhase) &&
                 refine_step_items<BOX, CH>(P, L, lds, colour, phase, r - prop_rounds, do_eval, cand, d_new, tp_seq))
                 continue;
         }

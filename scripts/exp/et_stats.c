@@ -19,8 +19,11 @@
 #endif /* window columns (box <= 31) */
 
 /* per-view prefix: pre[c] = cost after window column c, reference order (go_view_cost) */
+static float *g_terms = NULL, *g_wts = NULL; /* optional per-sample outputs of view_prefix: w*dis, w */
+#pragma omp threadprivate(g_terms, g_wts)
 static int view_prefix(const gipuma_hip_desc *d, int view, int px, int py, const float pl[4], float *pre)
 {
+    int ns = 0;
     const gipuma_hip_params *ap = &d->params;
     const int rows = d->rows, cols = d->cols, pitch = d->pitch;
     const float *ref = d->images[0];
@@ -66,6 +69,8 @@ static int view_prefix(const gipuma_hip_desc *d, int view, int px, int py, const
             const float colDis = fminf(colDiff, tau_color);
             const float dis = fmaf(alpha, gradDis, oma * colDis);
             cost = fmaf(w, dis, cost);
+            if (g_terms) { g_terms[ns] = w * dis; g_wts[ns] = w; }
+            ns++;
         }
         pre[nc++] = cost;
     }
@@ -179,6 +184,13 @@ typedef struct {
      * [0] thr only, open tasks (F' < B0 with a truncated view) completed in full; [1] the same with
      * min(k-th smallest, thr) (sequential views); [2] fraction of tasks left open under [0]; [3] under [1] */
     double prop_item[4];
+    /* refinement lower-bound prefilter: items (candidate, view) whose sum over the K highest-weight samples
+     * (K = 4, 8, 12, 16, 24, 32) already reaches thr = B; [step][K index]; lb_fixed: the 16 samples of the
+     * centre 4x4 / the 4 of the centre 2x2; lb_items: all items; lb_cand_dead[step][K]: candidates whose
+     * F' (mean of m smallest bounds) >= B from the prefilter alone */
+    double lb_dead[4][6], lb_fixed[4][2], lb_items[4], lb_cand_dead[4][6], lb_cands[4];
+    /* samples an item needs in weight order until its partial sum reaches thr (64 if never): sum, [step] */
+    double lb_need[4];
 } launch_stats;
 
 static int ratio_bin(float F, float B)
@@ -424,6 +436,67 @@ int et_stats_run(const gipuma_hip_desc *d, int x0, int y0, int x1, int y1, int n
                                 task_eval te;
                                 eval_task(d, x, y, cand, &te);
                                 const int sidx = step < 3 ? step : 3;
+                                if (step < 3 && te.nc * te.nc <= 64) {
+                                    static const int KS[6] = {4, 8, 12, 16, 24, 32};
+                                    float terms[64], wts[64];
+                                    int ord[64];
+                                    const int ns = te.nc * te.nc;
+                                    float lbv[6][GIPUMA_HIP_MAX_VIEWS];
+                                    for (int v = 0; v < nv; v++) {
+                                        float dummy[MAXC];
+                                        g_terms = terms;
+                                        g_wts = wts;
+                                        view_prefix(d, d->selected[v], x, y, cand, dummy);
+                                        g_terms = NULL;
+                                        if (v == 0) {
+                                            for (int a = 0; a < ns; a++) ord[a] = a;
+                                            for (int a = 1; a < ns; a++) {
+                                                const int o = ord[a];
+                                                int b = a;
+                                                for (; b >= 1 && wts[o] > wts[ord[b - 1]]; b--) ord[b] = ord[b - 1];
+                                                ord[b] = o;
+                                            }
+                                        }
+                                        const float thrv = st.cost;
+                                        float acc = 0.f;
+                                        int need = 64, ki = 0;
+                                        for (int a = 0; a < ns; a++) {
+                                            acc += terms[ord[a]];
+                                            if (need == 64 && acc * 0.99998f >= thrv) need = a + 1;
+                                            while (ki < 6 && KS[ki] == a + 1) {
+                                                lbv[ki][v] = acc * 0.99998f;
+                                                if (acc * 0.99998f >= thrv) loc.lb_dead[step][ki] += 1;
+                                                ki++;
+                                            }
+                                        }
+                                        loc.lb_need[step] += need;
+                                        loc.lb_items[step] += 1;
+                                        /* fixed patterns: sample index = col * nc + row; centre 4x4 = cols/rows nc/2-2 .. nc/2+1 */
+                                        float f16 = 0.f, f4 = 0.f;
+                                        for (int ci = te.nc / 2 - 2; ci < te.nc / 2 + 2; ci++)
+                                            for (int ri = te.nc / 2 - 2; ri < te.nc / 2 + 2; ri++) {
+                                                f16 += terms[ci * te.nc + ri];
+                                                if (ci >= te.nc / 2 - 1 && ci <= te.nc / 2 && ri >= te.nc / 2 - 1 && ri <= te.nc / 2) f4 += terms[ci * te.nc + ri];
+                                            }
+                                        if (f16 * 0.99998f >= thrv) loc.lb_fixed[step][0] += 1;
+                                        if (f4 * 0.99998f >= thrv) loc.lb_fixed[step][1] += 1;
+                                    }
+                                    loc.lb_cands[step] += 1;
+                                    for (int ki = 0; ki < 6; ki++) {
+                                        /* mean of the m smallest bounds */
+                                        float b[GIPUMA_HIP_MAX_VIEWS];
+                                        for (int v = 0; v < nv; v++) b[v] = lbv[ki][v];
+                                        for (int a = 1; a < nv; a++) {
+                                            const float o = b[a];
+                                            int q = a;
+                                            for (; q >= 1 && o < b[q - 1]; q--) b[q] = b[q - 1];
+                                            b[q] = o;
+                                        }
+                                        float sm = 0.f;
+                                        for (int a = 0; a < m; a++) sm += b[a];
+                                        if (sm / (float)m >= st.cost) loc.lb_cand_dead[step][ki] += 1;
+                                    }
+                                }
                                 if (step < 3) {
                                     /* predicted stop: saturated dis times the running sum of support weights */
                                     const float dismax = (1.f - ap->alpha) * ap->tau_color + ap->alpha * ap->tau_gradient;

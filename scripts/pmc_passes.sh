@@ -30,6 +30,5 @@ python $R/scripts/rocprof_summary.py pmc $OUT sweep_kernel > $OUT/pmc_summary_pi
 python $R/scripts/rocprof_summary.py pmc $OUT sweep_cols_kernel > $OUT/pmc_summary_column_per_lane.json
 python $R/scripts/rocprof_summary.py pmc $OUT init_kernel > $OUT/pmc_summary_init.json
 python $R/scripts/rocprof_summary.py pmc $OUT prop_shared_kernel > $OUT/pmc_summary_prop_shared.json
-python $R/scripts/rocprof_summary.py pmc $OUT sweep_rows_kernel > $OUT/pmc_summary_rows.json
 rm -f $OUT/*.db
 ls -la $OUT | head -30

@@ -212,19 +212,14 @@ def test_device_resident_images_with_pitch(hip):
 
 
 @pytest.mark.parametrize("tune", [1 << 30, 1 << 29, 1 << 28, (1 << 30) | (1 << 28), 1 << 27, 1 << 26,
-                                  (1 << 26) | (1 << 29), 1 << 23, 1 << 25, (1 << 25) | (1 << 27), 1 << 20,
-                                  (1 << 20) | (1 << 27), (1 << 20) | (1 << 25) | (1 << 23), 1 << 21,
-                                  (1 << 21) | (1 << 20), (1 << 27) | (1 << 25), 1 << 22, (1 << 22) | (1 << 27), 1 << 19,
-                                  (1 << 19) | (1 << 27)])
+                                  (1 << 26) | (1 << 29), 1 << 23, 1 << 25, (1 << 25) | (1 << 27),
+                                  (1 << 27) | (1 << 25), 1 << 19, (1 << 19) | (1 << 27)])
 def test_kernel_variants_are_bit_identical(hip, tune):
     """the performance-only choices of the sweep kernels -- float-encoded window offsets + the
     hand-pipelined loop (off: bit 30), task order owner-major (bit 29) / source-major (bit 28) in
     every iteration instead of switching after iteration 1, the column-per-lane kernel never (bit
     27) / in every half-sweep (bit 26) instead of the first four, the history skip rule off (bit
-    23), early termination of view costs off (bit 25), propagation by the shared-sample kernel
-    (bit 20: pm_prop_shared.h, followed by a refinement-only launch), refinement by the row-per-lane
-    kernel (bit 21: pm_refine_rows.h, groups of 8 lanes on column-major packed views), the lanes of
-    a workgroup regrouped by predicted stopping column before refinement (bit 22, opt-in), refinement
+    23), early termination of view costs off (bit 25), refinement
     bounded per wavefront instead of per (candidate, view) item (bit 19: pm::refine_two_phase off) -- must
     not change a single bit.
     Box 15 (the pipelined and column-per-lane instantiations), 4 iterations so that the default run
@@ -262,9 +257,8 @@ def test_early_termination_is_exact_for_any_bound(hip, theta, cfg):
     os.environ["GIPUMA_HIP_ET_THETA"] = theta
     os.environ["GIPUMA_HIP_ET_FORCE"] = "1"  # (the library bounds evaluations only on frames of >= 1024 tiles)
     try:
-        # one lane per pixel with the two-phase refinement (default) / bounded per wavefront /
-        # row-per-lane refinement kernel
-        for tune in (1 << 27, (1 << 27) | (1 << 19), (1 << 27) | (1 << 21)):
+        # one lane per pixel with the two-phase refinement (default) / bounded per wavefront
+        for tune in (1 << 27, (1 << 27) | (1 << 19)):
             os.environ["GIPUMA_HIP_TUNE"] = str(tune)
             a = runcuda(gs)
             assert_same(a[0], o[0], "theta %s tune %d norm4" % (theta, tune))
@@ -273,23 +267,6 @@ def test_early_termination_is_exact_for_any_bound(hip, theta, cfg):
         del os.environ["GIPUMA_HIP_ET_THETA"]
         del os.environ["GIPUMA_HIP_ET_FORCE"]
         os.environ.pop("GIPUMA_HIP_TUNE", None)
-
-
-def test_shared_sample_kernel_with_fused_refinement(hip):
-    """experiment switch GIPUMA_HIP_SHARED_FUSED: the shared-sample propagation kernel (bit 20) runs the
-    refinement stage -- by (candidate, view) items -- in the same launch"""
-    gs, _ = synth.build_problem(synth.tiny_config(cols=160, rows=112, n_src=4, blocksize=15, iterations=3, n_best=3))
-    o = OracleState(gs).run()
-    os.environ["GIPUMA_HIP_ET_FORCE"] = "2"
-    os.environ["GIPUMA_HIP_SHARED_FUSED"] = "1"
-    os.environ["GIPUMA_HIP_TUNE"] = str(1 << 20)
-    try:
-        a = runcuda(gs)
-    finally:
-        for k in ("GIPUMA_HIP_ET_FORCE", "GIPUMA_HIP_SHARED_FUSED", "GIPUMA_HIP_TUNE"):
-            del os.environ[k]
-    assert_same(a[0], o[0], "shared+fused norm4")
-    assert_same(a[1], o[1], "shared+fused cost")
 
 
 def test_two_phase_refinement_ragged_frame_many_views(hip):
