@@ -82,6 +82,11 @@ struct gipuma_hip_session {
     unsigned char *changed = nullptr;  // device, one byte per pixel
     unsigned *et_stat = nullptr;       // device, Problem::et_stat
     unsigned char *et_hint = nullptr;  // device, 12 bytes per sweep tile (Problem::et_hint)
+    // lower-bound prefilter of refinement candidates (pm::lb_item): the heaviest window samples of every
+    // pixel, listed by pm::weight_order_kernel at the start of every solve (init_planes) or before the
+    // first sweep that needs them
+    uint32_t *worder = nullptr;  // device, Problem::worder
+    bool worder_valid = false;
     size_t et_hint_bytes = 0;
     // push propagation (pm_push.h): after a half-sweep the planes of its colour are evaluated once for
     // all their consumers; the next half-sweep reads those costs instead of evaluating them
@@ -281,6 +286,17 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
             k = s->combine_reg ? pm::sweep_cols_kernel<15, true> : pm::sweep_cols_kernel<15, false>;
         else
             k = s->combine_reg ? pm::sweep_cols_kernel<25, true> : pm::sweep_cols_kernel<25, false>;
+    }
+    if (s->worder && !s->worder_valid) {
+        typedef void (*order_fn)(const pm::Problem *, uint32_t *);
+        const order_fn ok = s->box == 15 ? pm::weight_order_kernel<15>
+                            : s->box == 25 ? pm::weight_order_kernel<25>
+                                           : pm::weight_order_kernel<11>;
+        const int n = s->rows * s->cols;
+        hipLaunchKernelGGL(ok, dim3((n + pm::kThreads - 1) / pm::kThreads), dim3(pm::kThreads), 0, s->stream, s->dp,
+                           s->worder);
+        HIP_OK(hipGetLastError());
+        s->worder_valid = true;
     }
     hipLaunchKernelGGL(k, dim3(gx * gy), dim3(pm::kThreads), lds, s->stream, s->dp, s->norm4,
                        s->cost, colour, phase, stages, tune);
@@ -598,6 +614,15 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
             }
         }
     }
+    // lower-bound prefilter of refinement candidates: where the two-phase refinement runs on gray planes
+    hp.lb_k = 0;  // chosen by the probe workgroups
+    if (const char *t = getenv("GIPUMA_HIP_LB_K")) hp.lb_k = atoi(t);  // experiment: fixed length, < 0 = off
+    if (hp.et_enable && s->ch == 1 && s->box > 0 && hp.lb_k >= 0 && !(s->tune & (Tune::kNoTwoPhase | Tune::kNoEarlyExit))) {
+        CREATE_OK(hipMalloc(&s->worder, (size_t)pm::kLbDwords * np * sizeof(uint32_t)));
+        hp.worder = s->worder;
+    } else {
+        hp.lb_k = -1;
+    }
     // push propagation (pm_push.h): box 11 / 15 / 25, register combiner, packed gray planes with float-encoded offsets
     // ... or colour (three words per texel, integer addressing), box 15
     s->push_ok = s->u8 && s->combine_reg && s->n_sel > 0 && !(s->tune & (Tune::kNoInterior | Tune::kNoSkip)) &&
@@ -641,6 +666,7 @@ int gipuma_hip_destroy(gipuma_hip_session *s)
     if (s->changed) (void)hipFree(s->changed);
     if (s->push_cost) (void)hipFree(s->push_cost);
     if (s->et_hint) (void)hipFree(s->et_hint);
+    if (s->worder) (void)hipFree(s->worder);
     if (s->et_stat) (void)hipFree(s->et_stat);
     if (s->norm4) (void)hipFree(s->norm4);
     if (s->cost) (void)hipFree(s->cost);
@@ -659,6 +685,7 @@ int gipuma_hip_init_planes(gipuma_hip_session *s)
     // (a fresh solve starts with fresh hints, so that repeated solves of a session do the same work)
     HIP_OK(hipMemsetAsync(s->et_hint, 0, s->et_hint_bytes, s->stream));
     HIP_OK(hipMemsetAsync(s->et_stat, 0, 3 * pm::kEtSlot * sizeof(unsigned), s->stream));
+    s->worder_valid = false;  // (listed again by the first sweep: part of every solve)
     const int rc = launch_dense(s, true, s->norm4, s->cost);
     if (!rc) s->costs_trusted = true;
     s->finalized = false;

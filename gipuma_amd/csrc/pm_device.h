@@ -62,6 +62,12 @@ struct Problem {  // lives in device memory, read through scalar loads (wave-uni
     // after the previous half-sweep for the pixels of the other colour; read instead of evaluated
     // when the host sets Tune::kPushConsume
     float *push_cost;
+    // lower-bound prefilter of refinement candidates (lb_item): per pixel the kLbMax window samples with the
+    // largest support weights, two bytes each (window column, window row), as kLbDwords planes of
+    // rows*cols words (weight_order_kernel); lb_k > 0: samples to use (even), 0: chosen from the probes'
+    // statistics, < 0: prefilter off.  Performance only: ANY list gives the same results.
+    const uint32_t *worder;
+    int lb_k;
     RefCam rc;
     ViewCam view[kMaxViews];
 };
@@ -235,7 +241,8 @@ constexpr int kTpViews = 5;
 // Problem::et_stat: per rotating slot, [4 * step + {0: columns of full evaluations, 1: columns evaluated,
 // 2: items left after phase 1, 3: items}] for the three bounded steps, then [12 + step] = the phase-1
 // length the probes used
-constexpr unsigned kEtSlot = 16;
+constexpr unsigned kEtSlot = 24;  // ... and [16 + step] = the prefilter length (lb_item) they used
+constexpr int kLbMax = 16, kLbDwords = kLbMax / 2;
 struct TpLayout {  // offsets in floats into the scratch region
     static constexpr int acc = 0;                             // [kTpViews][256] partial / final view costs
     static constexpr int plane = acc + kTpViews * kThreads;   // [256] float4 candidate planes
@@ -793,6 +800,160 @@ __device__ __forceinline__ float view_cost_pipe_range(const Problem *__restrict_
     }
     if (cols_run) *cols_run += c - c0;
     return cost;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lower-bound prefilter of refinement candidates (performance only).
+//
+// The support weight w(p, q) = exp(-|I(q) - I(p)| / gamma) of a window sample depends on the reference
+// image alone (weight_cu, gipuma.cu:186-193) -- not on the plane, the view or the iteration --, and a
+// view cost is a sum of terms w * dis >= 0 (pmCost_shared, :633-676).  So the sum over ANY subset of a
+// pixel's window samples is a lower bound of the view cost, and the subset that bounds best is the same
+// for every evaluation at that pixel: the samples with the largest weights.  weight_order_kernel lists
+// them once per solve (kLbMax per pixel); lb_item sums the first K of them for one (candidate, view)
+// item, each term by the instruction sequence of view_cost_pipe (same bits per term).
+//
+// Rigour against rounding.  Let C be the reference's chain value (64 fmaf's in window order), T the exact
+// real sum of its terms, l the value lb_item accumulates over S of the terms (|S| <= 16, any order) and
+// T_S <= T their exact sum, u = 2^-24.  Every fmaf rounds a non-negative exact value to nearest, so
+// C >= T (1-u)^64 - 64 * 2^-150 and l <= T_S (1+u)^16 + 16 * 2^-150 (the absolute terms cover subnormal
+// partial sums).  Hence C >= l (1 - 81u) - 2^-143, and for l >= 2^-60
+//     L' = l * (1 - 2^-16)   (one more rounding, 2^-16 = 256 u)
+// satisfies L' <= C.  An item with L' >= thr is decided: its view cost is at least L', which is what
+// the ViewCombiner gets -- "a lower bound >= thr", the case multiview_cost's proof calls an abandoned
+// view.  Everything else about refine_two_phase is unchanged.
+// ---------------------------------------------------------------------------------------------
+constexpr float kLbShrink = 0.9999847412109375f;  // 1 - 2^-16
+constexpr float kLbFloor = 0x1p-60f;
+
+// one lane per pixel; order[d * np + pixel] = {col, row} of samples 2d and 2d+1 (bytes 0..3), heaviest first
+template <int BOX>
+__global__ __launch_bounds__(kThreads) void weight_order_kernel(const Problem *__restrict__ P,
+                                                                uint32_t *__restrict__ order)
+{
+    static_assert(BOX > 0, "compile-time window only");
+    constexpr int R = (BOX - 1) / 2, N = R + 1;
+    const int rows = P->rows, cols = P->cols, pitch = P->pitch;
+    const int np = rows * cols;
+    const int center = blockIdx.x * kThreads + threadIdx.x;
+    if (center >= np) return;
+    const int py = center / cols, px = center - py * cols;
+    const gptr_f32 ref = (gptr_f32)P->ref;
+    const float centre = ref[py * pitch + px];
+    uint32_t best[kLbMax];  // ascending keys: |dI| << 16 | row << 8 | col
+#pragma unroll
+    for (int k = 0; k < kLbMax; k++) best[k] = 0xffffffffu;
+    for (int ci = 0; ci < N; ci++) {
+        const int x = clampi(px - R + 2 * ci, 0, cols - 1);
+        for (int ri = 0; ri < N; ri++) {
+            const int y = clampi(py - R + 2 * ri, 0, rows - 1);
+            const float dI = __builtin_fabsf(ref[y * pitch + x] - centre);
+            uint32_t key = (min(cvt_u32_sat(dI), 0xfffeu) << 16) | (uint32_t)(ri << 8) | (uint32_t)ci;
+#pragma unroll
+            for (int k = 0; k < kLbMax; k++) {
+                const uint32_t lo = min(best[k], key);
+                key = max(best[k], key);
+                best[k] = lo;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < kLbDwords; d++) {
+        // (a window of fewer than kLbMax samples leaves 0xffff entries: lb_item's caller caps K)
+        order[(size_t)d * np + center] = (best[2 * d] & 0xffffu) | (best[2 * d + 1] << 16);
+    }
+}
+
+struct LbReq {
+    float a, b;
+    u32x4_a4 w;
+    uint32_t taddr;  // float-encoded LDS offset of the sample's reference texel
+};
+// the sum of w * dis over the first 2 * kd listed samples of the pixel's window, for one view
+template <int BOX, bool FAST>
+__device__ __forceinline__ float lb_item(const Problem *__restrict__ P, gptr_bytes magic_base,
+                                         const float *__restrict__ H, const float *__restrict__ tp0, int tw,
+                                         const float *__restrict__ lut, int px, int py,
+                                         const uint32_t (&ord)[kLbDwords], int kd, float *lb_short)
+{
+    // (*lb_short: the sum two samples short of the end -- what the probe workgroups use to judge the length)
+    static_assert(BOX > 0, "compile-time window only");
+    constexpr int R = (BOX - 1) / 2;
+    const float colsf = (float)P->cols, rowsf = (float)P->rows;
+    const float alpha = P->alpha, oma = 1.f - P->alpha;
+    const float tau_color = P->tau_color, tau_gradient = P->tau_gradient;
+    const float centre = tp0[0];
+    const float pwf = (float)P->pw;
+    const float magic_c = kMagicF + (float)(2 * P->pw + 2);
+    const char *lut_magic = (const char *)lut - kMagicBits;
+    const float H1 = H[1], H4 = H[4], H7 = H[7];
+    const float pxR = (float)(px - R), pyR = (float)(py - R);
+    // byte offset of texel (col, row) of the window from tp0: 16 * ((2 row - R) * tw + 2 col - R), as the
+    // low bits of the float 2^23 + 2^15 + offset (|offset| < 2^15: ulp 1, bits = 0x4b008000 + offset)
+    constexpr uint32_t kTileMagic = 0x4b008000u;
+    const float trow = (float)(32 * tw);
+    const float tbias = 8421376.0f - (float)(16 * R * (tw + 1));  // 2^23 + 2^15 - 16 R (tw + 1)
+    const char *tile_magic = (const char *)tp0 - kTileMagic;
+
+    auto request = [&](float cif, float rif) -> LbReq {
+        // window coordinates as view_cost_pipe forms them (exact small integers)
+        const float qx = __builtin_fmaf(cif, 2.0f, pxR), qy = __builtin_fmaf(rif, 2.0f, pyR);
+        const float X0 = __builtin_fmaf(H[0], qx, H[2]);
+        const float Y0 = __builtin_fmaf(H[3], qx, H[5]);
+        const float Z0 = __builtin_fmaf(H[6], qx, H[8]);
+        const float X = __builtin_fmaf(H1, qy, X0);
+        const float Y = __builtin_fmaf(H4, qy, Y0);
+        const float Z = __builtin_fmaf(H7, qy, Z0);
+        const float rz = recip<FAST>(Z);
+        const float sx = X * rz, sy = Y * rz;
+        const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
+        LbReq r;
+        r.a = sx - fx0;
+        r.b = sy - fy0;
+        const float Xc = __builtin_amdgcn_fmed3f(fx0, -2.0f, colsf);
+        const float Yc = __builtin_amdgcn_fmed3f(fy0, -2.0f, rowsf);
+        const uint32_t off = __float_as_uint(__builtin_fmaf(Yc, pwf, Xc + magic_c));
+        r.w = *(gptr_u32x4)(magic_base + off);
+        r.taddr = __float_as_uint(__builtin_fmaf(rif, trow, __builtin_fmaf(cif, 32.0f, tbias)));
+        return r;
+    };
+    auto reduce = [&](const LbReq &cur, float acc) -> float {
+        const float4 t4 = *reinterpret_cast<const float4 *>(tile_magic + cur.taddr);
+        const float colorDis = __builtin_fabsf(t4.x - centre);
+        const float w = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
+        const Taps tp5 = taps_u8(cur.a, cur.b, cur.w.x, cur.w.y, cur.w.z, cur.w.w);
+        const float colDiff = t4.w - tp5.sc;
+        const float gradX = t4.y - tp5.gx2;
+        const float gradY = t4.z - tp5.gy2;
+        const float gradDis = min_nc((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
+        const float colDis = min_abs_nc(colDiff, tau_color);
+        const float dis = __builtin_fmaf(alpha, gradDis, oma * colDis);
+        return __builtin_fmaf(w, dis, acc);
+    };
+
+    float lb = 0.0f, prev = 0.0f;
+    LbReq r0 = request(ub0(ord[0]), ub1(ord[0])), r1 = request(ub2(ord[0]), ub3(ord[0]));
+#pragma unroll
+    for (int d = 0; d < kLbDwords; d++) {
+        if (d >= kd) break;  // (wave-uniform)
+        prev = lb;
+        // (the two requests past the last sample fetch valid, clamped addresses and are dropped)
+        const uint32_t nxt = ord[d + 1 < kLbDwords ? d + 1 : d];
+        LbReq cur = r0;
+        r0 = r1;
+        r1 = request(ub0(nxt), ub1(nxt));
+        __builtin_amdgcn_sched_barrier(0);
+        lb = reduce(cur, lb);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = r0;
+        r0 = r1;
+        r1 = request(ub2(nxt), ub3(nxt));
+        __builtin_amdgcn_sched_barrier(0);
+        lb = reduce(cur, lb);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    *lb_short = prev;
+    return lb;
 }
 
 template <int BOX, bool U8, bool INTERIOR, bool ET = false>
@@ -1892,11 +2053,15 @@ __device__ __forceinline__ float tp_item(const Problem *__restrict__ P, const Vi
     }
 }
 
+// `lbk` > 0 (gray): phase 1 is the lower-bound prefilter instead -- the sum over the pixel's lbk heaviest
+// window samples (lb_item, list `ord`); an item it decides passes its bound on, the others run their
+// exact chain from column 0 in phase 2.
 template <int BOX, int CH>
 __device__ __forceinline__ float refine_two_phase(const Problem *__restrict__ P, const SweepLane &L, float *work,
                                                   const float *__restrict__ lut, int colour, bool valid, float4 cand,
                                                   float thr, int g0, float *kth_out, int &seq, int *cols_run,
-                                                  int *items_left = nullptr)
+                                                  int *items_left, int lbk, const uint32_t (&ord)[kLbDwords],
+                                                  int *items_short = nullptr)
 {
     constexpr int R = (BOX - 1) / 2, N = R + 1;
     float *accv = work + TpLayout::acc;
@@ -1918,7 +2083,27 @@ __device__ __forceinline__ float refine_two_phase(const Problem *__restrict__ P,
         for (int v = vb; v < ve; v++) {
             float a = 0.0f;
             bool alive = valid;
-            if (g0 > 0) {
+            if (CH == 1 && lbk > 0) {
+                if constexpr (CH == 1) {
+                    float H[9];
+                    homography(P->rc.K_inv, P->view[v], cand, H);
+                    const bool safe = window_z_safe(H, (float)(L.px - R), (float)(L.px + R), (float)(L.py - R), (float)(L.py + R));
+                    const float *tp0 = L.tile + ((L.ly + L.hh) * L.tw + (L.lx + L.hw)) * 4;
+                    const gptr_bytes base = (gptr_bytes)((uintptr_t)P->view[v].packed - (uintptr_t)kMagicBits);
+                    float lb, lbs;
+                    if (__all(safe))
+                        lb = lb_item<BOX, true>(P, base, H, tp0, L.tw, lut, L.px, L.py, ord, lbk >> 1, &lbs);
+                    else
+                        lb = lb_item<BOX, false>(P, base, H, tp0, L.tw, lut, L.px, L.py, ord, lbk >> 1, &lbs);
+                    if (cols_run) *cols_run += 1 + (lbk + N - 1) / N;
+                    const float bound = lb * kLbShrink;  // <= the reference's chain value (see lb_item)
+                    const bool dead = bound >= thr && lb >= kLbFloor;
+                    if (items_short)  // (probe workgroups: items that two samples fewer would have left open)
+                        *items_short += (int)__popcll(__ballot(valid && !(lbs * kLbShrink >= thr && lbs >= kLbFloor)));
+                    a = dead ? bound : 0.0f;
+                    alive = valid && !dead;
+                }
+            } else if (g0 > 0) {
                 float H[9];
                 homography(P->rc.K_inv, P->view[v], cand, H);
                 const bool safe = window_z_safe(H, (float)(L.px - R), (float)(L.px + R), (float)(L.py - R), (float)(L.py + R));
@@ -1962,10 +2147,11 @@ __device__ __forceinline__ float refine_two_phase(const Problem *__restrict__ P,
             float H[9];
             homography(P->rc.K_inv, P->view[v], pl, H);
             const bool safe = window_z_safe(H, (float)(epx - R), (float)(epx + R), (float)(epy - R), (float)(epy + R));
+            const int c_from = lbk > 0 ? 0 : g0;
             if (__all(safe))
-                a = tp_item<BOX, CH, true>(P, P->view[v], H, tp0, L.tw, lut, epx, epy, g0, N, a, tau_i, cols_run);
+                a = tp_item<BOX, CH, true>(P, P->view[v], H, tp0, L.tw, lut, epx, epy, c_from, N, a, tau_i, cols_run);
             else
-                a = tp_item<BOX, CH, false>(P, P->view[v], H, tp0, L.tw, lut, epx, epy, g0, N, a, tau_i, cols_run);
+                a = tp_item<BOX, CH, false>(P, P->view[v], H, tp0, L.tw, lut, epx, epy, c_from, N, a, tau_i, cols_run);
             if (cols_run) *cols_run += 1;
             if (have) accv[vl * kThreads + t] = a;
         }
@@ -2008,7 +2194,41 @@ __device__ __forceinline__ bool refine_step_items(const Problem *__restrict__ P,
         g0 = max(2, min(g0, (Nc + 1) / 2 + 1));
     }
     const int g0_used = g0;
-    int items_left = 0;
+    // lower-bound prefilter (gray): length from Problem::lb_k, or two samples more / fewer than the previous
+    // half-sweep's probes used if more than 12 % / fewer than 3 % of their items survived it
+    int lbk = 0;
+    uint32_t ord[kLbDwords] = {};
+    if constexpr (CH == 1) {
+        if (P->lb_k > 0) {
+            lbk = min(P->lb_k & ~1, kLbMax);
+        } else if (P->lb_k == 0) {
+            lbk = kLbMax;
+            if (seen[3] > 0u) {
+                // an open item costs about kLbOpen samples (homography again + its chain up to the bound);
+                // the last two samples of the previous probes' prefilter paid if they closed more than
+                // 2 / kLbOpen of the items; two more are tried while more than 8 % stay open
+                constexpr unsigned long long kLbOpen = 45;
+                const unsigned prev_k = P->et_stat[((phase + 2u) % 3u) * kEtSlot + 16 + step];
+                const unsigned long long open_k = seen[2], open_short = P->et_stat[((phase + 2u) % 3u) * kEtSlot + 20 + step];
+                lbk = (int)prev_k;
+                if (prev_k > 0u) {
+                    if (open_short >= open_k && (open_short - open_k) * kLbOpen < 2ull * seen[3])
+                        lbk -= 2;
+                    else if (open_k * 100ull > (unsigned long long)seen[3] * 8ull)
+                        lbk += 2;
+                }
+                lbk = max(4, min(lbk, kLbMax));
+            }
+        }
+        if (lbk > 0) {
+            const size_t np = (size_t)P->rows * (size_t)P->cols;
+            const size_t me = L.active ? (size_t)L.center : 0;
+#pragma unroll
+            for (int d = 0; d < kLbDwords; d++) ord[d] = P->worder[(size_t)d * np + me];
+        }
+    }
+    const int lbk_used = lbk;
+    int items_left = 0, items_short = 0;
     float thr = P->et_theta[step] * L.cst;
     bool need = do_eval;
     int cols_run = 0;
@@ -2016,12 +2236,14 @@ __device__ __forceinline__ bool refine_step_items(const Problem *__restrict__ P,
     for (int pass = 0; pass < 2; pass++) {
         float kth;
         const float cc = refine_two_phase<BOX, CH>(P, L, L.bres, lds, colour, need, cand, thr, g0, &kth, tp_seq,
-                                                   probe ? &cols_run : nullptr, pass == 0 ? &items_left : nullptr);
+                                                   probe ? &cols_run : nullptr, pass == 0 ? &items_left : nullptr,
+                                                   lbk, ord, probe && pass == 0 ? &items_short : nullptr);
         const bool open = need && kth >= thr && cc < L.cst;
         if (need && !open) c = cc;
         need = open;
         thr = __builtin_inff();
         g0 = 0;
+        lbk = 0;
         if (!__syncthreads_or(need)) break;
     }
     if (probe) {
@@ -2034,6 +2256,10 @@ __device__ __forceinline__ bool refine_step_items(const Problem *__restrict__ P,
             if (threadIdx.x == 0) {
                 atomicAdd(&mine[2], (unsigned)items_left);
                 P->et_stat[(phase % 3u) * kEtSlot + 12 + step] = (unsigned)g0_used;
+                P->et_stat[(phase % 3u) * kEtSlot + 16 + step] = (unsigned)lbk_used;
+            }
+            if ((threadIdx.x & 63u) == 0u && items_short > 0) {  // (per wavefront: ballots of its own lanes)
+                atomicAdd(&P->et_stat[(phase % 3u) * kEtSlot + 20 + step], (unsigned)items_short);
             }
         }
     }
@@ -2047,8 +2273,11 @@ __device__ __forceinline__ bool refine_step_items(const Problem *__restrict__ P,
 }
 
 // (the packed-gray instantiations are held at 128 VGPRs = 4 wavefronts per SIMD)
+#ifndef PM_SWEEP_WG
+#define PM_SWEEP_WG 3  // workgroups per CU the packed-gray sweep kernel is compiled for (3: 168 VGPRs, no spills; 4: 128 VGPRs, measured level)
+#endif
 template <int BOX, bool U8, bool COMBINE_REG, bool INTERIOR, int CH>
-__global__ __launch_bounds__(kThreads, U8 ? 4 : 1) void sweep_kernel(const Problem *__restrict__ P,
+__global__ __launch_bounds__(kThreads, U8 ? (CH == 4 ? 4 : PM_SWEEP_WG) : 1) void sweep_kernel(const Problem *__restrict__ P,
                                                          float4 *__restrict__ norm4, float *__restrict__ cost,
                                                          int colour, uint32_t phase, unsigned stages,
                                                          unsigned tune)

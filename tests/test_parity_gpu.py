@@ -294,14 +294,56 @@ def test_two_phase_refinement_is_exact_for_any_split(hip, g0, theta):
     os.environ["GIPUMA_HIP_ET_THETA"] = theta
     os.environ["GIPUMA_HIP_ET_FORCE"] = "2"  # small frame, and every workgroup bounds every step
     os.environ["GIPUMA_HIP_TP_G0"] = str(g0)
+    os.environ["GIPUMA_HIP_LB_K"] = "-1"  # (phase 1 = window columns, not the lower-bound prefilter)
     os.environ["GIPUMA_HIP_TUNE"] = str(1 << 27)
     try:
         a = runcuda(gs)
     finally:
-        for k in ("GIPUMA_HIP_ET_THETA", "GIPUMA_HIP_ET_FORCE", "GIPUMA_HIP_TP_G0", "GIPUMA_HIP_TUNE"):
+        for k in ("GIPUMA_HIP_ET_THETA", "GIPUMA_HIP_ET_FORCE", "GIPUMA_HIP_TP_G0", "GIPUMA_HIP_TUNE", "GIPUMA_HIP_LB_K"):
             del os.environ[k]
     assert_same(a[0], o[0], "g0 %d theta %s norm4" % (g0, theta))
     assert_same(a[1], o[1], "g0 %d theta %s cost" % (g0, theta))
+
+
+@pytest.mark.parametrize("lbk", [0, 2, 4, 8, 12, 16])
+@pytest.mark.parametrize("theta", ["0.05,0.05,0.05", "1,1,1", "3,2,1.5"])
+def test_lower_bound_prefilter_is_exact_for_any_length(hip, lbk, theta):
+    """pm::lb_item: a refinement candidate's view costs are first bounded from below by the sum over the
+    pixel's lbk heaviest window samples (pm::weight_order_kernel); an item whose bound reaches
+    theta * (cost to beat) is decided, the others run the exact chain.  Any length (0 = chosen by the
+    probe workgroups), any theta: the oracle's bits."""
+    gs, _ = synth.build_problem(synth.tiny_config(cols=160, rows=112, n_src=7, blocksize=15, iterations=3, n_best=3))
+    o = OracleState(gs).run()
+    os.environ["GIPUMA_HIP_ET_THETA"] = theta
+    os.environ["GIPUMA_HIP_ET_FORCE"] = "2"  # small frame, and every workgroup bounds every step
+    os.environ["GIPUMA_HIP_LB_K"] = str(lbk)
+    os.environ["GIPUMA_HIP_TUNE"] = str(1 << 27)
+    try:
+        a = runcuda(gs)
+    finally:
+        for k in ("GIPUMA_HIP_ET_THETA", "GIPUMA_HIP_ET_FORCE", "GIPUMA_HIP_LB_K", "GIPUMA_HIP_TUNE"):
+            del os.environ[k]
+    assert_same(a[0], o[0], "lbk %d theta %s norm4" % (lbk, theta))
+    assert_same(a[1], o[1], "lbk %d theta %s cost" % (lbk, theta))
+
+
+@pytest.mark.parametrize("cfg", [dict(cols=96, rows=80, n_src=5, blocksize=11, iterations=3, n_best=1),
+                                 dict(cols=96, rows=64, n_src=3, blocksize=25, iterations=2, n_best=2),
+                                 dict(cols=150, rows=100, n_src=12, blocksize=15, iterations=2, n_best=2)])
+def test_lower_bound_prefilter_other_boxes(hip, cfg):
+    """the prefilter with the default (probe-chosen) length on boxes 11 and 25 and on a ragged frame with
+    12 views (border tiles, three groups of views)"""
+    gs, _ = synth.build_problem(synth.tiny_config(**cfg))
+    o = OracleState(gs).run()
+    os.environ["GIPUMA_HIP_ET_FORCE"] = "2"
+    os.environ["GIPUMA_HIP_TUNE"] = str(1 << 27)
+    try:
+        a = runcuda(gs)
+    finally:
+        for k in ("GIPUMA_HIP_ET_FORCE", "GIPUMA_HIP_TUNE"):
+            del os.environ[k]
+    assert_same(a[0], o[0], "box %d norm4" % cfg["blocksize"])
+    assert_same(a[1], o[1], "box %d cost" % cfg["blocksize"])
 
 
 @pytest.mark.parametrize("theta", ["0.05,0.05,0.05", "1,1,1.5"])
