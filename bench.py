@@ -324,6 +324,7 @@ def main():
 
     # quality vs the analytic ground truth (sanity: the solver reconstructs the surface)
     quality = quality_of(sess, info)
+    final_default = sess.get_state()  # (finalized maps of the last timed solve: compared with the exhaustive schedule's below)
     sess.close()
 
     if rank == 0:
@@ -450,6 +451,14 @@ def main():
                 with Session(gs) as s2:
                     s2.solve(timing=True)
                     t2 = s2.solve(timing=True)
+                    final_ex = s2.get_state()
+                # full-frame parity statement of the shipped schedule: its final maps and costs equal the
+                # exhaustive schedule's bit for bit on every pixel (the exhaustive kernel is what the tests
+                # teacher-force against the oracle at this size; tests/test_parity_gpu.py)
+                out["quality"]["default_equals_exhaustive"] = bool(
+                    np.array_equal(final_default[0].view(np.uint32), final_ex[0].view(np.uint32)) and
+                    np.array_equal(final_default[1].view(np.uint32), final_ex[1].view(np.uint32)))
+                del final_ex
                 out["value_exhaustive"] = {"value": n_pix / (t2.ms_total * 1e-3) / 1e6, "unit": "Mpix/s",
                                            "ms_per_step": float(t2.ms_total),
                                            "what": "same frames, GIPUMA_HIP_TUNE=64|2^23|2^25: no skip rules, no early "

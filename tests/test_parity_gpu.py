@@ -650,11 +650,60 @@ def test_config_c_every_launch_at_full_size(hip):
     print("config C: %d pixel updates compared exactly" % n)
 
 
+EXHAUSTIVE_TUNE = 64 | (1 << 23) | (1 << 25)  # no skip rules (A)/(D), no history rule (H), no bounded evaluation
+
+
+def _default_equals_exhaustive(gs, what):
+    """the shipped schedule (push propagation, skip rules, prefilter + bounded refinement) against the
+    exhaustive one -- every candidate of every pixel evaluated in full by the plain kernel -- on the
+    WHOLE frame, final maps and costs bit for bit"""
+    a = runcuda(gs)
+    b = _with_env({"GIPUMA_HIP_TUNE": EXHAUSTIVE_TUNE}, lambda: runcuda(gs))
+    assert_same(a[0], b[0], what + ": default vs exhaustive schedule, norm4 (whole frame)")
+    assert_same(a[1], b[1], what + ": default vs exhaustive schedule, cost (whole frame)")
+    return a
+
+
+def test_config_c_whole_frame_against_the_oracle(hip):
+    """BASELINE config C, the headline (1600x1200, 10 source views, box 15, 8 iterations, best-3;
+    scripts/dtu_fast.sh:9-21): the WHOLE free-running solve -- the reference's loop gipuma.cu:1911-1941,
+    30.7 M pixel updates -- against the oracle's own free-running solve, every pixel of the final maps
+    and costs bit for bit; and the shipped schedule against the exhaustive one on the same frame."""
+    import time
+    gs, info = synth.build_problem("C")
+    a = _default_equals_exhaustive(gs, "config C")
+    t0 = time.time()
+    o_n4, o_c = OracleState(gs).run()
+    print("config C: oracle free-running solve %.1f s" % (time.time() - t0))
+    assert_same(a[0], o_n4, "config C whole frame norm4")
+    assert_same(a[1], o_c, "config C whole frame cost")
+
+
+def test_config_d_and_colour_default_equals_exhaustive(hip):
+    """config D (20 views, box 25) and the colour variant of config C's geometry: the shipped schedule
+    against the exhaustive one on the whole frame (the exhaustive kernel itself is teacher-forced against
+    the oracle in test_exhaustive_schedule_every_launch_at_full_size)"""
+    gs, info = synth.build_problem("D", iterations=3)
+    _default_equals_exhaustive(gs, "config D")
+    gs, info = synth.build_problem("C", colour=True, iterations=3)
+    _default_equals_exhaustive(gs, "colour config C")
+
+
+@pytest.mark.parametrize("cfg,kw,bands", [("C", {}, [(0, 6), (604, 612)]), ("D", dict(iterations=2), [(0, 3), (606, 610)]),
+                                          ("C", dict(colour=True, iterations=2), [(0, 3), (606, 610)])])
+def test_exhaustive_schedule_every_launch_at_full_size(hip, cfg, kw, bands):
+    """the exhaustive schedule (what the whole-frame comparisons above are made against) teacher-forced
+    against the oracle on bands of rows, every launch"""
+    gs, info = synth.build_problem(cfg, **kw)
+    n = _with_env({"GIPUMA_HIP_TUNE": EXHAUSTIVE_TUNE}, lambda: _teacher_forced_bands(gs, bands, "exhaustive " + cfg))
+    print("exhaustive %s %r: %d pixel updates compared exactly" % (cfg, kw, n))
+
+
 def test_config_d_every_launch_at_full_size(hip):
     """BASELINE config D (1600x1200, 20 source views, box 25, 8 iterations; scripts/dtu_accurate.sh):
     every launch checked exactly on two bands (the oracle costs 5x config C per pixel here)."""
     gs, info = synth.build_problem("D")
-    n = _teacher_forced_bands(gs, [(0, 6), (600, 610)], "config D")
+    n = _teacher_forced_bands(gs, [(0, 6), (154, 166), (600, 610), (1194, 1200)], "config D")
     print("config D: %d pixel updates compared exactly" % n)
 
 
