@@ -85,6 +85,9 @@ struct gipuma_hip_session {
     // lower-bound prefilter of refinement candidates (pm::lb_item): the heaviest window samples of every
     // pixel, listed by pm::weight_order_kernel at the start of every solve (init_planes) or before the
     // first sweep that needs them
+    unsigned long long *dbg = nullptr;  // device, Problem::dbg (GIPUMA_HIP_COUNTS=1)
+    float4 *seen_ring = nullptr;        // device, Problem::seen_ring (skip rule (S))
+    unsigned char *seen_pos = nullptr;  // device, Problem::seen_pos
     uint32_t *worder = nullptr;  // device, Problem::worder
     bool worder_valid = false;
     size_t et_hint_bytes = 0;
@@ -557,6 +560,18 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         CREATE_OK(hipMemsetAsync(s->et_stat, 0, 3 * pm::kEtSlot * sizeof(unsigned), s->stream));
         hp.et_stat = s->et_stat;
     }
+    if (!(s->tune & (Tune::kNoSeen | Tune::kNoSkip))) {
+        CREATE_OK(hipMalloc(&s->seen_ring, (size_t)pm::kSeenRing * np * sizeof(float4)));
+        CREATE_OK(hipMalloc(&s->seen_pos, np));
+        CREATE_OK(hipMemsetAsync(s->seen_pos, 0, np, s->stream));
+        hp.seen_ring = s->seen_ring;
+        hp.seen_pos = s->seen_pos;
+    }
+    if (getenv("GIPUMA_HIP_COUNTS") && atoi(getenv("GIPUMA_HIP_COUNTS"))) {  // experiment aid
+        CREATE_OK(hipMalloc(&s->dbg, 64 * pm::kDbgSlots * sizeof(unsigned long long)));
+        CREATE_OK(hipMemsetAsync(s->dbg, 0, 64 * pm::kDbgSlots * sizeof(unsigned long long), s->stream));
+        hp.dbg = s->dbg;
+    }
     CREATE_OK(hipMalloc(&s->changed, np));
     CREATE_OK(hipMemsetAsync(s->changed, 1, np, s->stream));
     hp.changed = s->changed;
@@ -667,6 +682,9 @@ int gipuma_hip_destroy(gipuma_hip_session *s)
     if (s->push_cost) (void)hipFree(s->push_cost);
     if (s->et_hint) (void)hipFree(s->et_hint);
     if (s->worder) (void)hipFree(s->worder);
+    if (s->dbg) (void)hipFree(s->dbg);
+    if (s->seen_ring) (void)hipFree(s->seen_ring);
+    if (s->seen_pos) (void)hipFree(s->seen_pos);
     if (s->et_stat) (void)hipFree(s->et_stat);
     if (s->norm4) (void)hipFree(s->norm4);
     if (s->cost) (void)hipFree(s->cost);
@@ -686,6 +704,7 @@ int gipuma_hip_init_planes(gipuma_hip_session *s)
     HIP_OK(hipMemsetAsync(s->et_hint, 0, s->et_hint_bytes, s->stream));
     HIP_OK(hipMemsetAsync(s->et_stat, 0, 3 * pm::kEtSlot * sizeof(unsigned), s->stream));
     s->worder_valid = false;  // (listed again by the first sweep: part of every solve)
+    if (s->seen_pos) HIP_OK(hipMemsetAsync(s->seen_pos, 0, (size_t)s->rows * s->cols, s->stream));  // rule (S): new planes
     const int rc = launch_dense(s, true, s->norm4, s->cost);
     if (!rc) s->costs_trusted = true;
     s->finalized = false;
@@ -777,6 +796,7 @@ int gipuma_hip_set_state(gipuma_hip_session *s, const float *norm4_host, const f
         HIP_OK(hipMemcpyAsync(s->norm4, norm4_host, np * sizeof(float4), hipMemcpyHostToDevice, s->stream));
     if (cost_host)
         HIP_OK(hipMemcpyAsync(s->cost, cost_host, np * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    if (s->seen_pos) HIP_OK(hipMemsetAsync(s->seen_pos, 0, np, s->stream));  // rule (S): a cost may have gone up
     HIP_OK(hipStreamSynchronize(s->stream));
     s->costs_trusted = false;
     s->prev1 = s->prev2 = -1;
@@ -838,6 +858,19 @@ int gipuma_hip_solve(gipuma_hip_session *s, gipuma_hip_timing *timing)
             fprintf(stderr, "gipuma_hip launch_ms:");
             for (float ms : s->half_sweep_ms) fprintf(stderr, " %.3f", ms);
             fprintf(stderr, "\n");
+        }
+        if (s->dbg) {  // per half-sweep: events per pixel of the colour
+            std::vector<unsigned long long> h(64 * pm::kDbgSlots);
+            HIP_OK(hipMemcpy(h.data(), s->dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            HIP_OK(hipMemset(s->dbg, 0, h.size() * sizeof(unsigned long long)));
+            const double px = 0.5 * (double)s->rows * (double)s->cols;
+            static const char *names[] = {"tasks/px", "seen/px", "items/px", "open items/px", "redone cands/px", "cands/px"};
+            for (int k = 0; k < 6; k++) {
+                fprintf(stderr, "gipuma_hip counts %s:", names[k]);
+                for (int ph = 1; ph <= 2 * s->iterations && ph < 64; ph++)
+                    fprintf(stderr, " %.3f", (double)h[(size_t)ph * pm::kDbgSlots + k] / px);
+                fprintf(stderr, "\n");
+            }
         }
     }
     return 0;

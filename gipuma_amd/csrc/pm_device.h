@@ -68,6 +68,13 @@ struct Problem {  // lives in device memory, read through scalar loads (wave-uni
     // statistics, < 0: prefilter off.  Performance only: ANY list gives the same results.
     const uint32_t *worder;
     int lb_k;
+    // rule (S) of the sweep kernels' exact skipping: per pixel a ring of the last kSeenRing planes its
+    // propagation evaluated ([kSeenRing][rows*cols] float4) and one byte of ring state (next slot | 8 once
+    // full); nullptr: rule off.  Cleared by the host whenever planes are (re-)installed.
+    float4 *seen_ring;
+    unsigned char *seen_pos;
+    // experiment aid (GIPUMA_HIP_COUNTS=1): [64 phases][kDbgSlots] event counters, or nullptr
+    unsigned long long *dbg;
     RefCam rc;
     ViewCam view[kMaxViews];
 };
@@ -243,6 +250,11 @@ constexpr int kTpViews = 5;
 // length the probes used
 constexpr unsigned kEtSlot = 24;  // ... and [16 + step] = the prefilter length (lb_item) they used
 constexpr int kLbMax = 16, kLbDwords = kLbMax / 2;
+constexpr int kSeenRing = 8;
+// Problem::dbg slots: propagation tasks, candidates removed by rule (S), refinement items, items the
+// prefilter / phase 1 left open, refinement candidates redone, refinement candidates
+constexpr int kDbgSlots = 8;
+enum { kDbgTasks = 0, kDbgSeen = 1, kDbgItems = 2, kDbgItemsOpen = 3, kDbgRedo = 4, kDbgCands = 5 };
 struct TpLayout {  // offsets in floats into the scratch region
     static constexpr int acc = 0;                             // [kTpViews][256] partial / final view costs
     static constexpr int plane = acc + kTpViews * kThreads;   // [256] float4 candidate planes
@@ -289,6 +301,7 @@ struct Tune {  // experiment switches (GIPUMA_HIP_TUNE), all default off
                               kGenericCombine = 16, kRowMajorTiles = 32, kNoSkip = 64,
                               kUntrustedCosts = 128,  // set by the host after gipuma_hip_set_state
                               kPushConsume = 1u << 18,   // host-internal: propagation costs come from Problem::push_cost
+                              kNoSeen = 1u << 22,        // no skip rule (S) (planes this pixel evaluated before)
                               kNoTwoPhase = 1u << 19,    // refinement bounded per wavefront (v11) instead of two-phase (refine_two_phase)
                               kNoMagicAddr = 1u << 30,  // integer window addressing (bits 8..17: band height)
                               kOwnerMajorTasks = 1u << 29,   // always owner-major task lists
@@ -826,13 +839,23 @@ __device__ __forceinline__ float view_cost_pipe_range(const Problem *__restrict_
 constexpr float kLbShrink = 0.9999847412109375f;  // 1 - 2^-16
 constexpr float kLbFloor = 0x1p-60f;
 
-// one lane per pixel; order[d * np + pixel] = {col, row} of samples 2d and 2d+1 (bytes 0..3), heaviest first
+// one lane per pixel; order[d * np + pixel] = {col, row} of samples 2d and 2d+1 (bytes 0..3), heaviest first.
+// The samples are listed in groups of PM_LB_GROUP horizontally adjacent ones (window columns G c .. G c + G - 1
+// of one window row, ranked by their summed weights): the windows of a group lie next to each other in the
+// source view, i.e. in one cache line, and a refinement candidate's window loads are bound by the vector
+// L1's line fills (every lane has its own random plane), not by their count.
+#ifndef PM_LB_GROUP
+#define PM_LB_GROUP 1  // (measured on config C: singles 89.5, pairs 91.2, quads 93.0 ms per view)
+#endif
 template <int BOX>
 __global__ __launch_bounds__(kThreads) void weight_order_kernel(const Problem *__restrict__ P,
                                                                 uint32_t *__restrict__ order)
 {
     static_assert(BOX > 0, "compile-time window only");
     constexpr int R = (BOX - 1) / 2, N = R + 1;
+    constexpr int G = PM_LB_GROUP, NG = N / G, KG = kLbMax / G;  // group size, groups per window row, groups listed
+    static_assert(G == 1 || G == 2 || G == 4, "group size");
+    static_assert(NG * N >= KG, "the window has enough groups");
     const int rows = P->rows, cols = P->cols, pitch = P->pitch;
     const int np = rows * cols;
     const int center = blockIdx.x * kThreads + threadIdx.x;
@@ -840,17 +863,21 @@ __global__ __launch_bounds__(kThreads) void weight_order_kernel(const Problem *_
     const int py = center / cols, px = center - py * cols;
     const gptr_f32 ref = (gptr_f32)P->ref;
     const float centre = ref[py * pitch + px];
-    uint32_t best[kLbMax];  // ascending keys: |dI| << 16 | row << 8 | col
+    uint32_t best[KG];  // ascending keys: sum of |dI| << 16 | row << 8 | first column
 #pragma unroll
-    for (int k = 0; k < kLbMax; k++) best[k] = 0xffffffffu;
-    for (int ci = 0; ci < N; ci++) {
-        const int x = clampi(px - R + 2 * ci, 0, cols - 1);
-        for (int ri = 0; ri < N; ri++) {
-            const int y = clampi(py - R + 2 * ri, 0, rows - 1);
-            const float dI = __builtin_fabsf(ref[y * pitch + x] - centre);
-            uint32_t key = (min(cvt_u32_sat(dI), 0xfffeu) << 16) | (uint32_t)(ri << 8) | (uint32_t)ci;
+    for (int k = 0; k < KG; k++) best[k] = 0xffffffffu;
+    for (int ri = 0; ri < N; ri++) {
+        const int y = clampi(py - R + 2 * ri, 0, rows - 1);
+        for (int c = 0; c < NG; c++) {
+            float dsum = 0.0f;
 #pragma unroll
-            for (int k = 0; k < kLbMax; k++) {
+            for (int e = 0; e < G; e++) {
+                const int x = clampi(px - R + 2 * (G * c + e), 0, cols - 1);
+                dsum += __builtin_fabsf(ref[y * pitch + x] - centre);
+            }
+            uint32_t key = (min(cvt_u32_sat(dsum), 0xfffeu) << 16) | (uint32_t)(ri << 8) | (uint32_t)(G * c);
+#pragma unroll
+            for (int k = 0; k < KG; k++) {
                 const uint32_t lo = min(best[k], key);
                 key = max(best[k], key);
                 best[k] = lo;
@@ -859,8 +886,10 @@ __global__ __launch_bounds__(kThreads) void weight_order_kernel(const Problem *_
     }
 #pragma unroll
     for (int d = 0; d < kLbDwords; d++) {
-        // (a window of fewer than kLbMax samples leaves 0xffff entries: lb_item's caller caps K)
-        order[(size_t)d * np + center] = (best[2 * d] & 0xffffu) | (best[2 * d + 1] << 16);
+        // samples 2d and 2d + 1: members (2d) % G and (2d + 1) % G of groups (2d) / G and (2d + 1) / G
+        const uint32_t s0 = (best[(2 * d) / G] & 0xffffu) + (uint32_t)((2 * d) % G);
+        const uint32_t s1 = (best[(2 * d + 1) / G] & 0xffffu) + (uint32_t)((2 * d + 1) % G);
+        order[(size_t)d * np + center] = s0 | (s1 << 16);
     }
 }
 
@@ -1686,6 +1715,14 @@ __global__ __launch_bounds__(kThreads) void init_cols_kernel(const Problem *__re
 //         (Problem::changed), then this pixel met exactly that plane one half-sweep ago and did
 //         not end up with it at a lower cost -- it was rejected against a cost that has only
 //         decreased since, or accepted and improved upon
+//     (S) a plane this pixel's propagation evaluated before (a ring of its last kSeenRing evaluated
+//         candidates, Problem::seen_ring): its cost F is a pure function of (pixel, plane); it was then
+//         rejected against a cost that has only decreased since (or for its depth, which is a pure
+//         function too), or accepted -- and the pixel's cost has been <= F ever since.  This does not
+//         need the state invariant, only that the pixel's cost never increases between the two
+//         half-sweeps: the host clears the rings whenever planes are (re-)installed.  A plane that
+//         spreads over a patch reaches a pixel that turned it down again and again, through every
+//         neighbour that adopts it: 8 % (fifth half-sweep) to 20 % (last) of the remaining candidates
 //   can never be accepted (strict <, gipuma.cu:868) and is not evaluated.  On config C the
 //   evaluated candidates drop from 8 to 2.7 per pixel by the last half-sweep.  Because the
 //   per-wavefront MAXIMUM stays near 8, the surviving (pixel, candidate) pairs of the whole
@@ -1728,6 +1765,7 @@ struct SweepLane {
     unsigned needmask;                // candidate slots that must be evaluated
     unsigned chg;                     // the plane changed in this half-sweep
     int n_tasks;                      // surviving (pixel, candidate) pairs of the workgroup
+    int n_seen;                       // (statistics) candidates of this pixel removed by rule (S)
 };
 
 // tile staging, lane -> pixel mapping, state read (gipuma.cu:1527-1530) and the exact skipping rules:
@@ -1774,6 +1812,7 @@ __device__ __forceinline__ void sweep_read_state(SweepLane &L, const Problem *__
     L.needmask = 0;
     L.chg = 0;
     L.n_tasks = 0;
+    L.n_seen = 0;
     const bool history = (tune & Tune::kHistorySkip) != 0;
     if (L.active) {
         const float4 pl = norm4[L.center];
@@ -1818,6 +1857,32 @@ __device__ __forceinline__ void sweep_read_state(SweepLane &L, const Problem *__
                 for (int j = 0; j < k; j++)
                     if (fresh && ((valid >> j) & 1u) && same_bits(cands[k], cands[j])) fresh = false;  // (D)
                 if (fresh) needmask |= 1u << k;
+            }
+            if (P->seen_ring != nullptr && !(tune & Tune::kNoSeen)) {  // (S)
+                const size_t np = (size_t)rows * (size_t)cols;
+                const unsigned st = P->seen_pos[L.center];
+                const unsigned before_seen = needmask;
+                const int cnt = (st & 8u) ? kSeenRing : (int)(st & 7u);
+#pragma unroll
+                for (int a = 0; a < kSeenRing; a++) {
+                    if (a < cnt && needmask != 0u) {
+                        const float4 e = P->seen_ring[(size_t)a * np + (size_t)L.center];
+#pragma unroll
+                        for (int k = 0; k < 8; k++)
+                            if (((needmask >> k) & 1u) && same_bits(cands[k], e)) needmask &= ~(1u << k);
+                    }
+                }
+                L.n_seen = __popc(before_seen) - __popc(needmask);
+                unsigned pos = st & 7u, full = st & 8u;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if ((needmask >> k) & 1u) {
+                        P->seen_ring[(size_t)pos * np + (size_t)L.center] = cands[k];
+                        pos = (pos + 1u) & 7u;
+                        if (pos == 0u) full = 8u;
+                    }
+                }
+                P->seen_pos[L.center] = (unsigned char)(pos | full);
             }
         }
         L.needmask = needmask;
@@ -2228,7 +2293,7 @@ __device__ __forceinline__ bool refine_step_items(const Problem *__restrict__ P,
         }
     }
     const int lbk_used = lbk;
-    int items_left = 0, items_short = 0;
+    int items_left = 0, items_short = 0, n_redo = 0;
     float thr = P->et_theta[step] * L.cst;
     bool need = do_eval;
     int cols_run = 0;
@@ -2244,7 +2309,21 @@ __device__ __forceinline__ bool refine_step_items(const Problem *__restrict__ P,
         thr = __builtin_inff();
         g0 = 0;
         lbk = 0;
+        if (P->dbg != nullptr) n_redo += __syncthreads_count(need);
         if (!__syncthreads_or(need)) break;
+    }
+    if (P->dbg != nullptr && threadIdx.x == 0) {
+        unsigned long long *d = P->dbg + (size_t)(phase & 63u) * kDbgSlots;
+        atomicAdd(&d[kDbgItemsOpen], (unsigned long long)items_left);
+        atomicAdd(&d[kDbgRedo], (unsigned long long)n_redo);
+    }
+    if (P->dbg != nullptr) {
+        const unsigned n_cand = (unsigned)__popcll(__ballot(do_eval));
+        if ((threadIdx.x & 63u) == 0u) {
+            unsigned long long *d = P->dbg + (size_t)(phase & 63u) * kDbgSlots;
+            atomicAdd(&d[kDbgCands], (unsigned long long)n_cand);
+            atomicAdd(&d[kDbgItems], (unsigned long long)n_cand * (unsigned)P->n_sel);
+        }
     }
     if (probe) {
         const unsigned n_cand = (unsigned)__popcll(__ballot(do_eval));
@@ -2288,6 +2367,11 @@ __global__ __launch_bounds__(kThreads, U8 ? (CH == 4 ? 4 : PM_SWEEP_WG) : 1) voi
     SweepLane L;
     sweep_setup<BOX, CH>(L, P, lds, norm4, cost, colour, stages, tune, U8);
     const int prop_rounds = (L.n_tasks + kThreads - 1) / kThreads;
+    if (P->dbg != nullptr) {
+        unsigned long long *d = P->dbg + (size_t)(phase & 63u) * kDbgSlots;
+        if (threadIdx.x == 0) atomicAdd(&d[kDbgTasks], (unsigned long long)L.n_tasks);
+        if (L.n_seen) atomicAdd(&d[kDbgSeen], (unsigned long long)L.n_seen);
+    }
     RefineDraws R;
     refine_init(R, P, stages);
     constexpr bool ET = U8 && COMBINE_REG && INTERIOR && (CH == 4 || BOX > 0);

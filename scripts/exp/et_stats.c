@@ -169,6 +169,11 @@ typedef struct {
     double plane_groups, plane_union_samples, plane_task_samples, plane_bbox_samples, plane_maxgroup;
     double cols_w8_ref[4][4]; /* like cols_wave_ref but a 'wave' of 8 tasks (8 lanes per task) */
     double seen4, seen8, seen32;  /* needed prop tasks whose plane this pixel evaluated before (ring of K) */
+    double seen_own8, seen_own16;
+    /* runs of tasks with the same plane on the same row, x stepping by 2 (xrun) / same column, y stepping by 2
+     * (yrun): window columns (rows) evaluated = 7 + length instead of 8 * length; [0] = sum of (7 + k),
+     * [1] = sum of 8 k, [2] = number of runs, [3] = runs of length 1 */
+    double xrun[4], yrun[4]; /* ... with the pixel's own refinement-accepted planes in a second ring of 8 / 16 as well */
     double cols_sorted_ref[4][4]; /* wave-level with lanes regrouped by a predicted stop column */
     /* workgroup pool: per view, rounds of G columns (G = 1, 2, 4); after a round the lanes that reached
      * their bound drop out and the survivors are compacted into ceil(alive/64) wavefronts; lanes left
@@ -191,6 +196,9 @@ typedef struct {
     double lb_dead[4][6], lb_fixed[4][2], lb_items[4], lb_cand_dead[4][6], lb_cands[4];
     /* samples an item needs in weight order until its partial sum reaches thr (64 if never): sum, [step] */
     double lb_need[4];
+    /* the same with the samples taken as horizontally adjacent PAIRS (window columns 2c, 2c+1 of a row; the two
+     * windows of a pair lie in one cache line) / as QUADS (columns 4c..4c+3), heaviest first: [step][K index] */
+    double lb_pair_dead[4][6], lb_quad_dead[4][6];
 } launch_stats;
 
 static int ratio_bin(float F, float B)
@@ -231,6 +239,8 @@ int et_stats_run(const gipuma_hip_desc *d, int x0, int y0, int x1, int y1, int n
     float *hist = (float *)calloc(np * 4 * 32, sizeof(float)); /* ring of 32 planes per pixel */
     unsigned char *hcount = (unsigned char *)calloc(np, 1);
     unsigned *hpos = (unsigned *)calloc(np, sizeof(unsigned));
+    float *hist2 = (float *)calloc(np * 4 * 16, sizeof(float)); /* ring of 16: propagation-evaluated + own refined planes */
+    unsigned *hpos2 = (unsigned *)calloc(np, sizeof(unsigned));
     unsigned char *changed = (unsigned char *)malloc(np);
     memset(changed, 1, np);
     const int m = d->params.n_best < d->n_selected ? d->params.n_best : d->n_selected;
@@ -353,6 +363,20 @@ int et_stats_run(const gipuma_hip_desc *d, int x0, int y0, int x1, int y1, int n
                                 }
                                 memcpy(hist + center * 128 + 4 * (hpos[center] & 31), cands[k], 16);
                                 hpos[center]++;
+                                {
+                                    const float *hp2 = hist2 + center * 64;
+                                    const unsigned n2 = hpos2[center];
+                                    for (unsigned a = 0; a < 16 && a < n2; a++) {
+                                        const unsigned idx = (n2 - 1 - a) & 15;
+                                        if (!memcmp(hp2 + 4 * idx, cands[k], 16)) {
+                                            if (a < 8) loc.seen_own8 += 1;
+                                            loc.seen_own16 += 1;
+                                            break;
+                                        }
+                                    }
+                                    memcpy(hist2 + center * 64 + 4 * (hpos2[center] & 15), cands[k], 16);
+                                    hpos2[center]++;
+                                }
                             }
                             task_eval te;
                             eval_task(d, x, y, cands[k], &te);
@@ -439,7 +463,7 @@ int et_stats_run(const gipuma_hip_desc *d, int x0, int y0, int x1, int y1, int n
                                 if (step < 3 && te.nc * te.nc <= 64) {
                                     static const int KS[6] = {4, 8, 12, 16, 24, 32};
                                     float terms[64], wts[64];
-                                    int ord[64];
+                                    int ord[64], pord[64], qord[64];
                                     const int ns = te.nc * te.nc;
                                     float lbv[6][GIPUMA_HIP_MAX_VIEWS];
                                     for (int v = 0; v < nv; v++) {
@@ -455,6 +479,42 @@ int et_stats_run(const gipuma_hip_desc *d, int x0, int y0, int x1, int y1, int n
                                                 int b = a;
                                                 for (; b >= 1 && wts[o] > wts[ord[b - 1]]; b--) ord[b] = ord[b - 1];
                                                 ord[b] = o;
+                                            }
+                                        }
+                                        if (v == 0) {
+                                            /* sample index = col * nc + row; pairs: cols (2c, 2c+1) of a row, by summed weight */
+                                            for (int grp = 2; grp <= 4; grp += 2) {
+                                                int *o = grp == 2 ? pord : qord;
+                                                const int ng = te.nc / grp;
+                                                int ids[64]; float gw[64]; int n = 0;
+                                                for (int ri = 0; ri < te.nc; ri++)
+                                                    for (int c = 0; c < ng; c++) {
+                                                        float wsum = 0.f;
+                                                        for (int e = 0; e < grp; e++) wsum += wts[(grp * c + e) * te.nc + ri];
+                                                        ids[n] = c * 64 + ri; gw[n] = wsum; n++;
+                                                    }
+                                                for (int a = 1; a < n; a++) {
+                                                    const int oi = ids[a]; const float ow = gw[a];
+                                                    int b = a;
+                                                    for (; b >= 1 && ow > gw[b - 1]; b--) { ids[b] = ids[b - 1]; gw[b] = gw[b - 1]; }
+                                                    ids[b] = oi; gw[b] = ow;
+                                                }
+                                                int k = 0;
+                                                for (int a = 0; a < n && k + grp <= 64; a++)
+                                                    for (int e = 0; e < grp; e++) o[k++] = (grp * (ids[a] / 64) + e) * te.nc + (ids[a] % 64);
+                                                for (; k < 64; k++) o[k] = 0;
+                                            }
+                                        }
+                                        for (int mode = 0; mode < 2; mode++) {
+                                            const int *o = mode == 0 ? pord : qord;
+                                            float acc2 = 0.f;
+                                            int ki2 = 0;
+                                            for (int a = 0; a < 32 && a < ns; a++) {
+                                                acc2 += terms[o[a]];
+                                                while (ki2 < 6 && KS[ki2] == a + 1) {
+                                                    if (acc2 * 0.99998f >= st.cost) (mode == 0 ? loc.lb_pair_dead : loc.lb_quad_dead)[step][ki2] += 1;
+                                                    ki2++;
+                                                }
                                             }
                                         }
                                         const float thrv = st.cost;
@@ -531,6 +591,8 @@ int et_stats_run(const gipuma_hip_desc *d, int x0, int y0, int x1, int y1, int n
                                 }
                                 refvalid[lane] = 1;
                                 if (te.F < st.cost) {
+                                    memcpy(hist2 + center * 64 + 4 * (hpos2[center] & 15), cand, 16);
+                                    hpos2[center]++;
                                     st.cost = te.F;
                                     st.depth = depthOut;
                                     memcpy(st.pl, cand, 16);
@@ -679,6 +741,40 @@ int et_stats_run(const gipuma_hip_desc *d, int x0, int y0, int x1, int y1, int n
                                 if (pstop[p][l][k] > mx) mx = pstop[p][l][k];
                             loc.cols_wave_prop[p] += 64.0 * mx;
                         }
+                /* runs along x / y */
+                for (int dir = 0; dir < 2; dir++) {
+                    static __thread unsigned char usedr[2048];
+                    memset(usedr, 0, (size_t)nptask);
+                    double *out4 = dir == 0 ? loc.xrun : loc.yrun;
+                    for (int a = 0; a < nptask; a++) {
+                        if (usedr[a]) continue;
+                        /* find the start of the run containing a, then walk it */
+                        int cx = ptask[a].lx, cy = ptask[a].ly;
+                        for (;;) {
+                            int found = -1;
+                            for (int b = 0; b < nptask; b++)
+                                if (!usedr[b] && b != a && !memcmp(ptask[a].pl, ptask[b].pl, 16) &&
+                                    ptask[b].lx == cx - (dir == 0 ? 2 : 0) && ptask[b].ly == cy - (dir == 0 ? 0 : 2)) { found = b; break; }
+                            if (found < 0) break;
+                            cx = ptask[found].lx; cy = ptask[found].ly;
+                        }
+                        int k = 0;
+                        for (;;) {
+                            int found = -1;
+                            for (int b = 0; b < nptask; b++)
+                                if (!usedr[b] && !memcmp(ptask[a].pl, ptask[b].pl, 16) && ptask[b].lx == cx && ptask[b].ly == cy) { found = b; break; }
+                            if (found < 0) break;
+                            usedr[found] = 1;
+                            k++;
+                            if (dir == 0) cx += 2; else cy += 2;
+                        }
+                        if (k == 0) { usedr[a] = 1; k = 1; }
+                        out4[0] += 7 + k;
+                        out4[1] += 8.0 * k;
+                        out4[2] += 1;
+                        if (k == 1) out4[3] += 1;
+                    }
+                }
                 /* plane-keyed sharing: group tasks by (plane bits, parity class), union of sample points */
                 {
                     static __thread unsigned char used[2048];

@@ -35,7 +35,7 @@ names = [("prop_tasks", 1), ("ref_tasks", 4), ("cols_full_prop", 1), ("cols_full
          ("cols_lane_prop", 4), ("cols_lane_ref", 16), ("cols_wave_ref", 16), ("cols_wave_prop", 4),
          ("ambiguous_prop", 4), ("ambiguous_ref", 16), ("wrong", 4),
          ("jobs", 1), ("job_union_cols", 1), ("job_target_cols", 1), ("job_hist", 5),
-         ("accepted_prop", 1), ("accepted_ref", 4), ("ratio_hist_ref", 32), ("ratio_hist_prop", 8), ("plane_groups", 1), ("plane_union_samples", 1), ("plane_task_samples", 1), ("plane_bbox_samples", 1), ("plane_maxgroup", 1), ("cols_w8_ref", 16), ("seen4", 1), ("seen8", 1), ("seen32", 1), ("cols_sorted_ref", 16), ("cols_pool_ref", 48), ("cols_wave_nr", 16), ("cols_two_phase", 32), ("items_alive", 16), ("prop_item", 4), ("lb_dead", 24), ("lb_fixed", 8), ("lb_items", 4), ("lb_cand_dead", 24), ("lb_cands", 4), ("lb_need", 4)]
+         ("accepted_prop", 1), ("accepted_ref", 4), ("ratio_hist_ref", 32), ("ratio_hist_prop", 8), ("plane_groups", 1), ("plane_union_samples", 1), ("plane_task_samples", 1), ("plane_bbox_samples", 1), ("plane_maxgroup", 1), ("cols_w8_ref", 16), ("seen4", 1), ("seen8", 1), ("seen32", 1), ("seen_own8", 1), ("seen_own16", 1), ("xrun", 4), ("yrun", 4), ("cols_sorted_ref", 16), ("cols_pool_ref", 48), ("cols_wave_nr", 16), ("cols_two_phase", 32), ("items_alive", 16), ("prop_item", 4), ("lb_dead", 24), ("lb_fixed", 8), ("lb_items", 4), ("lb_cand_dead", 24), ("lb_cands", 4), ("lb_need", 4), ("lb_pair_dead", 24), ("lb_quad_dead", 24)]
 off = {}
 o = 0
 for n, k in names:
@@ -94,11 +94,19 @@ for li in range(nl):
     print("    propagation bounded item-wise vs the cost at the start (open tasks in full): thr only %.3f (open %.3f), with k-th rule %.3f (open %.3f)" % (pi_[0] / max(cfp, 1), pi_[2] / max(pt, 1), pi_[1] / max(cfp, 1), pi_[3] / max(pt, 1)))
     print("    seen-before fraction of needed prop tasks: K=4 %.3f  K=8 %.3f  K=32 %.3f" %
           (f(r, "seen4")[0] / max(pt, 1), f(r, "seen8")[0] / max(pt, 1), f(r, "seen32")[0] / max(pt, 1)))
+    print("    ... with the pixel's own refinement-accepted planes in the ring too: K=8 %.3f  K=16 %.3f" %
+          (f(r, "seen_own8")[0] / max(pt, 1), f(r, "seen_own16")[0] / max(pt, 1)))
     lbd = f(r, "lb_dead").reshape(4, 6); lbi = np.maximum(f(r, "lb_items"), 1); lbf = f(r, "lb_fixed").reshape(4, 2)
     lcd = f(r, "lb_cand_dead").reshape(4, 6); lbc = np.maximum(f(r, "lb_cands"), 1)
     for st_ in range(3):
         print("    LB prefilter step %d: items dead after the K=4,8,12,16,24,32 heaviest samples %s | centre 4x4 %.3f 2x2 %.3f | candidates rejected outright %s | mean samples to reach thr %.1f" %
               (st_, np.round(lbd[st_] / lbi[st_], 3), lbf[st_][0] / lbi[st_], lbf[st_][1] / lbi[st_], np.round(lcd[st_] / lbc[st_], 3), f(r, "lb_need")[st_] / lbi[st_]))
+    xr, yr = f(r, "xrun"), f(r, "yrun")
+    print("    runs of equal planes: along x cols %.3f of the tasks' (%.2f tasks per run, %.2f of the runs single) | along y %.3f (%.2f, %.2f)" %
+          (xr[0] / max(xr[1], 1), xr[1] / 8 / max(xr[2], 1), xr[3] / max(xr[2], 1), yr[0] / max(yr[1], 1), yr[1] / 8 / max(yr[2], 1), yr[3] / max(yr[2], 1)))
+    lpd = f(r, "lb_pair_dead").reshape(4, 6); lqd = f(r, "lb_quad_dead").reshape(4, 6)
+    for st_ in range(3):
+        print("    LB prefilter step %d, K=4,8,12,16,24,32: singles %s | pairs %s | quads %s" % (st_, np.round(lbd[st_] / lbi[st_], 3), np.round(lpd[st_] / lbi[st_], 3), np.round(lqd[st_] / lbi[st_], 3)))
     jobs = f(r, "jobs")[0]
     print("    sharing: jobs %.2f/px, targets/job hist %s, union cols / target cols = %.3f" %
           (jobs / npx, np.round(f(r, "job_hist") / max(jobs, 1), 3),
