@@ -10,6 +10,7 @@ import os
 ABI_VERSION = 1
 MAX_VIEWS = 32
 MAXCOST = 1000.0
+ERR_ARG, ERR_DEVICE, ERR_NO_DEVICE, ERR_UNSUPPORTED = -1, -2, -3, -4  # gipuma_hip_status
 
 COMB_ALL, COMB_BEST_N, COMB_ANGLE, COMB_GOOD = 0, 1, 2, 3
 STAGE_CLOSE, STAGE_FAR, STAGE_REFINE, STAGE_ALL = 1, 2, 4, 7

@@ -184,8 +184,10 @@ def main(argv=None):
         for leftover in pending:
             leftover[0].close()
         pending.clear()
+        # ... nor the image cache: its entries are keyed by the device addresses of `dev`'s tensors, which
+        # torch hands out again once they are freed (the library refuses while a session still uses them)
+        abi.load_library().gipuma_hip_cache_clear()
     t_batch = time.perf_counter() - t_batch0
-    abi.load_library().gipuma_hip_cache_clear()
     with open(os.path.join(args.output_folder, "batch_rank%d.json" % rank), "w") as f:
         n_done = sum(1 for r in report if "skipped" not in r)
         json.dump({"rank": rank, "world": world, "device": dev_index, "load_seconds": t_load,

@@ -42,6 +42,7 @@ int fail(int code, const char *fmt, const char *a = "", const char *b = "")
 struct CachedImage {
     int not_u8 = -1;              // result of the 8-bit check (-1: not run yet)
     uint32_t *packed = nullptr;   // window-packed copy (pack_kernel / pack_kernel_c4)
+    int users = 0;                // live sessions whose Problem points at `packed`
 };
 typedef std::tuple<int, const void *, int, int, int, int> CacheKey;
 std::map<CacheKey, CachedImage> g_cache;
@@ -67,6 +68,7 @@ struct gipuma_hip_session {
     bool own_stream = false;
     bool u8 = false;         // every image integer valued in [0,255] -> weight table + packed windows
     std::vector<uint32_t *> packed;  // window-packed copies of the selected views (U8 mode)
+    std::vector<CacheKey> cache_refs;  // ... or shared ones it holds a use count on (GIPUMA_HIP_FLAG_CACHE_IMAGES)
     int *flag = nullptr;
     bool combine_reg = false;
     bool unfused = false;
@@ -347,6 +349,10 @@ int gipuma_hip_device_count(void)
 int gipuma_hip_cache_clear(void)
 {
     std::lock_guard<std::mutex> lock(g_cache_mutex);
+    for (auto &kv : g_cache)
+        if (kv.second.users > 0)
+            return fail(GIPUMA_HIP_ERR_ARG, "gipuma_hip_cache_clear: a live session still reads a cached packed image; "
+                                            "destroy the sessions first");
     for (auto &kv : g_cache) {
         if (kv.second.packed) {
             (void)hipSetDevice(std::get<0>(kv.first));
@@ -509,6 +515,10 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
             const dim3 pgid((hp.pw + pm::kThreads - 1) / pm::kThreads, d->rows + 3);
             for (int i = 0; i < d->n_selected; i++) {
                 CachedImage *e = entry(hp.view[i].img);
+                if (e) {  // (counted once per use: destroy gives every one back)
+                    e->users++;
+                    s->cache_refs.push_back(CacheKey(s->device, hp.view[i].img, d->rows, d->cols, hp.pitch, d->channels));
+                }
                 if (e && e->packed) {  // packed for an earlier session: shared, owned by the cache
                     hp.view[i].packed = e->packed;
                     continue;
@@ -674,6 +684,14 @@ int gipuma_hip_destroy(gipuma_hip_session *s)
     if (!s) return 0;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (!s->cache_refs.empty()) {
+        std::lock_guard<std::mutex> lock(g_cache_mutex);
+        for (const CacheKey &k : s->cache_refs) {
+            auto it = g_cache.find(k);
+            if (it != g_cache.end() && it->second.users > 0) it->second.users--;
+        }
+        s->cache_refs.clear();
+    }
     for (float *p : s->owned) (void)hipFree(p);
     for (uint32_t *p : s->packed) (void)hipFree(p);
     if (s->flag) (void)hipFree(s->flag);

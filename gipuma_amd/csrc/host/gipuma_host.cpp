@@ -114,20 +114,27 @@ int parse_command_line(int argc, char **argv, InputFiles &in, OutputFiles &out, 
         else printf("Command-line parameter warning: unknown option %s\n", a);  // e.g. -no_display
     }
 #undef NEXT_INTO
-    // --pmvs_folder: images under <pmvs>/visualize/, projection matrices under <pmvs>/txt/ (main.cpp:409-417)
-    // The reference then takes its depth range from <pmvs>/bundle.rd.out (main.cpp:873-875); here it comes
-    // from --depth_min/--depth_max or from the view geometry like in the other modes.
+    // --pmvs_folder: images under <pmvs>/visualize/, projection matrices under <pmvs>/txt/ (main.cpp:409-417);
+    // the depth range, unless given, comes from <pmvs>/bundle.rd.out (bundler_depth_range below)
     if (!in.pmvs_folder.empty()) {
         std::cout << "Using pmvs information inside directory " << in.pmvs_folder << std::endl;
         in.images_folder = in.pmvs_folder + "/visualize/";
         in.p_folder = in.pmvs_folder + "/txt/";
         in.img_filenames.clear();
         if (DIR *dir = opendir(in.images_folder.c_str())) {
-            while (dirent *ent = readdir(dir))
-                if (strcmp(ent->d_name, ".") && strcmp(ent->d_name, "..")) in.img_filenames.push_back(ent->d_name);
+            while (dirent *ent = readdir(dir)) {
+                if (!strcmp(ent->d_name, ".") || !strcmp(ent->d_name, "..")) continue;
+                // (the reference takes every directory entry, main.cpp:131-141; entries that are not images
+                //  in a format this front-end reads could only fail later, so they are left out here)
+                const std::string nm(ent->d_name);
+                const size_t dot = nm.find_last_of('.');
+                std::string ext = dot == std::string::npos ? "" : nm.substr(dot + 1);
+                for (char &ch : ext) ch = (char)tolower((unsigned char)ch);
+                if (ext == "pgm" || ext == "ppm" || ext == "pnm" || ext == "pfm") in.img_filenames.push_back(nm);
+            }
             closedir(dir);
         }
-        std::sort(in.img_filenames.begin(), in.img_filenames.end());  // (readdir order in the reference)
+        std::sort(in.img_filenames.begin(), in.img_filenames.end());  // sorted like the reference's list (main.cpp:153)
         if (camera_idx < 0 || camera_idx >= (int)in.img_filenames.size()) {
             printf("Command-line parameter error: --camera_idx out of range\n");
             return -1;
@@ -366,6 +373,49 @@ std::vector<int> select_views(const CameraSet &cs, int cols, int rows, Algorithm
     return subset;
 }
 
+// parse_bundler_3d_points + from_bundler_get_range, main.cpp:45-118: the 3d points of a Bundler v0.3 file
+// (https://www.cs.cornell.edu/~snavely/bundler/bundler-v0.4-manual.html#S6), the distance of each to the
+// centre of every source camera, and depthMin = 0.6 * the smallest / depthMax = 1.2 * the largest -- each only
+// if still -1.  As in the reference, this runs AFTER selectViews (main.cpp:870-875), which has already
+// replaced every -1 (main.cpp:481-484): the file is read and its range never takes effect.  Kept literal --
+// including the centres of the RE-CENTRED cameras measured against world-frame points.
+bool bundler_depth_range(const std::string &path, const CameraSet &cs, AlgorithmParameters &ap)
+{
+    FILE *fp = fopen(path.c_str(), "r");
+    if (!fp) return false;
+    char line[512];
+    unsigned num_cameras = 0, num_points = 0;
+    int c = fgetc(fp);
+    if (c == '#') {
+        if (!fgets(line, sizeof line, fp)) { fclose(fp); return false; }
+    } else if (c != EOF) {
+        ungetc(c, fp);
+    }
+    if (!fgets(line, sizeof line, fp) || sscanf(line, "%u %u", &num_cameras, &num_points) != 2) { fclose(fp); return false; }
+    for (unsigned i = 0; i < 5 * num_cameras; i++)  // <f k1 k2>, three rows of R, t
+        if (!fgets(line, sizeof line, fp)) { fclose(fp); return false; }
+    float min_depth = 9999, max_depth = 0;
+    unsigned got = 0;
+    for (unsigned i = 0; i < num_points; i++) {
+        float X[3] = {0, 0, 0};
+        if (!fgets(line, sizeof line, fp)) break;
+        sscanf(line, "%f %f %f", &X[0], &X[1], &X[2]);
+        if (!fgets(line, sizeof line, fp)) break;  // colour
+        if (!fgets(line, sizeof line, fp)) break;  // view list
+        got++;
+        for (size_t v = 1; v < cs.cams.size(); v++) {
+            const float dx = X[0] - (float)cs.C[3 * v], dy = X[1] - (float)cs.C[3 * v + 1], dz = X[2] - (float)cs.C[3 * v + 2];
+            const float depth = std::sqrt(dx * dx + dy * dy + dz * dz);
+            min_depth = std::min(depth, min_depth);
+            max_depth = std::max(depth, max_depth);
+        }
+    }
+    fclose(fp);
+    if (ap.depthMin == -1) ap.depthMin = min_depth - min_depth * 0.4f;
+    if (ap.depthMax == -1) ap.depthMax = max_depth + max_depth * 0.2f;
+    return got > 0;
+}
+
 // ------------------------------------------------------------------------------------------ images, dmb
 bool read_pnm_gray(const std::string &path, std::vector<float> &img, int &rows, int &cols)
 {
@@ -551,7 +601,9 @@ bool read_gt_map(const std::string &path, std::vector<float> &img, int &rows, in
                 fclose(fp);
                 return false;
             }
-            for (int x = 0; x < cols; x++) img[(size_t)y * cols + x] = line[(size_t)x * ch];
+            // ('PF': the reference reads all three floats of a pixel into one variable and keeps the last,
+            //  fileIoUtils.h:439-445)
+            for (int x = 0; x < cols; x++) img[(size_t)y * cols + x] = line[(size_t)x * ch + (ch - 1)];
         }
         fclose(fp);
         return true;
@@ -724,6 +776,11 @@ int run_gipuma(const InputFiles &in, const OutputFiles &out, AlgorithmParameters
     CameraSet cs;
     get_camera_parameters(P, n, ap.cam_scale, cs);
     std::vector<int> subset = select_views(cs, cols, rows, ap);
+    if (!in.pmvs_folder.empty()) {  // main.cpp:873-875
+        const std::string bf = in.pmvs_folder + "/bundle.rd.out";
+        std::cout << "Using bundler file " << bf << " to obtain depth range" << std::endl;
+        if (!bundler_depth_range(bf, cs, ap)) printf("Warning: no 3d points read from %s\n", bf.c_str());
+    }
     std::cout << "Total number of images used: " << subset.size() << std::endl;
     std::cout << "Selected views: ";
     for (int v : subset) std::cout << v << ", ";
@@ -838,6 +895,31 @@ int gipuma_host_select_views(const double *P_list, int n, float cam_scale, int c
     for (size_t k = 0; k < s.size(); k++) subset[k] = s[k];
     *depth_min = ap.depthMin; *depth_max = ap.depthMax;
     return (int)s.size();
+}
+
+int gipuma_host_bundler_depth_range(const char *path, const double *P_list, int n, float cam_scale, float *depth_min,
+                                    float *depth_max)
+{  // depth_min / depth_max: in = current values (-1 = unset), out = after from_bundler_get_range
+    gipuma_host::CameraSet cs;
+    gipuma_host::get_camera_parameters(std::vector<double>(P_list, P_list + 12 * (size_t)n), n, cam_scale, cs);
+    gipuma_host::AlgorithmParameters ap;
+    ap.depthMin = *depth_min;
+    ap.depthMax = *depth_max;
+    const bool ok = gipuma_host::bundler_depth_range(path, cs, ap);
+    *depth_min = ap.depthMin;
+    *depth_max = ap.depthMax;
+    return ok ? 0 : -1;
+}
+
+int gipuma_host_read_gt_map(const char *path, float *out, int *rows, int *cols)
+{
+    std::vector<float> img;
+    int r = 0, c = 0;
+    if (!gipuma_host::read_gt_map(path, img, r, c)) return -1;
+    *rows = r;
+    *cols = c;
+    if (out) memcpy(out, img.data(), img.size() * sizeof(float));
+    return 0;
 }
 
 int gipuma_host_compute_error(const float *gt, const float *gt_nocc, const float *disp, const unsigned char *valid,

@@ -92,6 +92,8 @@ struct CameraSet {
 // transformP = false keeps the cameras in the world frame (getCameraParameters(..., false), used for the PLY)
 void get_camera_parameters(const std::vector<double> &P_list, int n, float cam_scale, CameraSet &cs,
                            bool transformP = true);
+// from_bundler_get_range (main.cpp:89-118); false if the file holds no readable 3d point
+bool bundler_depth_range(const std::string &path, const CameraSet &cs, AlgorithmParameters &ap);
 // returns the selected subset; fills depthMin/depthMax when they are -1
 std::vector<int> select_views(const CameraSet &cs, int cols, int rows, AlgorithmParameters &ap);
 
@@ -123,6 +125,12 @@ int gipuma_host_camera_parameters_world(const double *P_list, int n, float cam_s
 int gipuma_host_main(int argc, char **argv);
 // computeError / computeNormalError on caller data (tests): out = error, error2, error_nocc, error_valid,
 // error_valid_all, valid_ratio, num_gt;  out2 = normal error, normal error2
+// from_bundler_get_range on caller data (tests): *depth_min / *depth_max in = current values (-1 = unset)
+int gipuma_host_bundler_depth_range(const char *path, const double *P_list, int n, float cam_scale, float *depth_min,
+                                    float *depth_max);
+// the ground-truth map reader of the CLI (.dmb / .pfm / .pgm): rows * cols floats to `out` (may be NULL to query
+// the size)
+int gipuma_host_read_gt_map(const char *path, float *out, int *rows, int *cols);
 int gipuma_host_compute_error(const float *gt, const float *gt_nocc, const float *disp, const unsigned char *valid,
                               int rows, int cols, float div_factor, float tol, float tol2, float *out);
 int gipuma_host_compute_normal_error(const float *normals3, const float *gt3, int rows, int cols, float tol,

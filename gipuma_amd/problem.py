@@ -126,7 +126,36 @@ def save_problem(path, gs, P_matrices, cam_scale=1.0):
     np.save(path + ".images.npy", np.stack(imgs))
     np.savez(path, P=np.stack([np.asarray(p, dtype=np.float64) for p in P_matrices]),
              cam_scale=float(cam_scale), selected=np.asarray(gs.selected, dtype=np.int32),
-             seed=int(gs.desc.seed), params=np.array([repr(sorted(gs.params.__dict__.items()))]))
+             seed=int(gs.desc.seed), params=np.array([_params_to_json(gs.params)]))
+
+
+def _params_to_json(ap):
+    """AlgorithmParameters as JSON text; non-finite floats as the strings "inf" / "-inf" / "nan" (plain JSON has
+    no spelling for them)"""
+    import json
+    import math
+    out = {}
+    for k, v in sorted(ap.__dict__.items()):
+        if isinstance(v, (bool, np.bool_)):
+            out[k] = bool(v)
+        elif isinstance(v, (int, np.integer)):
+            out[k] = int(v)
+        elif isinstance(v, (float, np.floating)):
+            v = float(v)
+            out[k] = v if math.isfinite(v) else repr(v)
+        else:
+            out[k] = v
+    return json.dumps(out)
+
+
+def _params_from_json(text):
+    import json
+    out = {}
+    for k, v in json.loads(text).items():
+        if isinstance(v, str) and v in ("inf", "-inf", "nan"):
+            v = float(v)
+        out[k] = v
+    return out
 
 
 def load_problem(path):
@@ -134,7 +163,7 @@ def load_problem(path):
     z = np.load(path, allow_pickle=False)
     cs = get_camera_parameters([p for p in z["P"]], cam_scale=float(z["cam_scale"]))
     ap = AlgorithmParameters()
-    for k, v in eval(str(z["params"][0])):  # written by save_problem above
+    for k, v in _params_from_json(str(z["params"][0])).items():
         setattr(ap, k, v)
     stack = np.load(path + ".images.npy", mmap_mode="r")
     gs = GlobalState([stack[i] for i in range(stack.shape[0])], cs, [int(v) for v in z["selected"]], ap,

@@ -134,7 +134,8 @@ typedef struct gipuma_hip_session gipuma_hip_session;
 int gipuma_hip_version(void);                 /* GIPUMA_HIP_ABI_VERSION of the built library */
 const char *gipuma_hip_last_error(void);      /* thread-local text of the last failure */
 int gipuma_hip_device_count(void);            /* usable HIP devices (0 if none) */
-/* frees everything kept for GIPUMA_HIP_FLAG_CACHE_IMAGES (sessions using it must be destroyed first) */
+/* frees everything kept for GIPUMA_HIP_FLAG_CACHE_IMAGES.  Sessions that use a cached packed image hold a use
+ * count on it: while one of them is alive the call frees nothing and returns GIPUMA_HIP_ERR_ARG. */
 int gipuma_hip_cache_clear(void);
 
 /* Device self-test of an arithmetic shortcut the kernels rely on: v_rcp_f32 + one Newton step must

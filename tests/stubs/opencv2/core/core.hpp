@@ -1,0 +1,2 @@
+// test infrastructure: see ../opencv_stub.hpp
+#include "../opencv_stub.hpp"

@@ -45,3 +45,29 @@ def test_runcuda_through_the_reference_structs_matches_the_oracle(hip, colour):
     o_n4, o_c = OracleState(gs).run()
     assert np.array_equal(n4.view(np.uint32), o_n4.view(np.uint32))
     assert np.array_equal(c.view(np.uint32), o_c.view(np.uint32))
+
+
+REF_MAIN = "/root/reference/main.cpp"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_MAIN), reason="the reference tree is only present in the build container")
+def test_reference_main_cpp_compiles_unchanged_against_the_compat_layer():
+    """north_star: "drops into main.cpp unchanged".  The reference's OWN main.cpp -- its includes
+    (main.cpp:16-23: cuda_runtime.h, cuda.h, cuda_runtime_api.h, cuda_texture_types.h, vector_types.h,
+    helper_cuda.h), its texture upload (:501-690: cudaMallocArray / cudaMemcpyToArray / cudaCreateTextureObject
+    on cudaResourceDesc / cudaTextureDesc), cudaSetDevice / cudaMemGetInfo / cudaDeviceReset, the managed
+    GlobalState and the call runcuda(*gs) at :973 -- goes through the compiler's front end with only
+    adapter/cuda_compat/ in place of the CUDA toolkit.  OpenCV, which the image does not have, is stood in for
+    by declarations under tests/stubs/ (test infrastructure, never linked); every other header is the
+    reference's.  Any CUDA identifier the compat layer failed to provide would be an error here."""
+    here = os.path.join(ROOT, "gipuma_amd", "csrc", "adapter", "cuda_compat")
+    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-fsyntax-only", "-std=c++17", "-w", "-ferror-limit=50",
+           "-D__HIP_PLATFORM_AMD__", "-x", "hip", "--offload-arch=gfx950", "--cuda-host-only",
+           "-include", os.path.join(here, "gipuma_cuda_compat.h"), "-I" + here,
+           "-I" + os.path.join(ROOT, "tests", "stubs"), "-I/root/reference", REF_MAIN]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # the stub really is declarations only, and the adapter does not see it
+    stub = open(os.path.join(ROOT, "tests", "stubs", "opencv2", "opencv_stub.hpp")).read()
+    assert "TEST INFRASTRUCTURE" in stub
+    assert "stubs" not in open(os.path.join(ROOT, "gipuma_amd", "csrc", "adapter", "build_adapter.sh")).read()

@@ -390,3 +390,67 @@ def test_cli_middlebury_par_file(hip, tmp_path):
     n4, c = OracleState(gs2).run()
     assert np.array_equal(disp.view(np.uint32), n4[..., 3].view(np.uint32))
     assert np.array_equal(cost.view(np.uint32), c.view(np.uint32))
+
+
+def _write_bundle(path, points, n_cams=2, comment=True):
+    """a Bundler v0.3 file (main.cpp:45-87): [comment], '<cams> <points>', 5 lines per camera, 3 per point"""
+    with open(path, "w") as f:
+        if comment:
+            f.write("# Bundle file v0.3\n")
+        f.write("%d %d\n" % (n_cams, len(points)))
+        for _ in range(n_cams):
+            f.write("1000 0 0\n1 0 0\n0 1 0\n0 0 1\n0 0 0\n")
+        for X in points:
+            f.write("%r %r %r\n255 255 255\n2 0 1 10.0 20.0 1 2 11.0 21.0\n" % tuple(float(v) for v in X))
+
+
+@pytest.mark.parametrize("comment", [True, False])
+def test_bundler_depth_range_restates_from_bundler_get_range(tmp_path, comment):
+    """--pmvs_folder: from_bundler_get_range (main.cpp:89-118) on a hand-made bundle.rd.out -- the distance of
+    every 3d point to the centre of every SOURCE camera (as getCameraParameters left it: re-centred on the
+    reference), depthMin = 0.6 x the smallest, depthMax = 1.2 x the largest, each only where still -1"""
+    P = synth.dtu_projection_matrices()
+    ids = [15, 2, 9]
+    Pl = [P[k] for k in ids]
+    pts = np.array([[10.0, -20.0, 600.0], [55.5, 12.25, 480.0], [-80.0, 40.0, 720.0]], np.float32)
+    bf = str(tmp_path / "bundle.rd.out")
+    _write_bundle(bf, pts, comment=comment)
+    cs = get_camera_parameters(Pl, cam_scale=1.0)
+    centres = [np.asarray(cs.C[i], np.float32) for i in range(1, 3)]  # centres of the re-centred P (the python restatement)
+    d = np.array([[np.sqrt(((X - c) ** 2).sum(dtype=np.float32)) for X in pts] for c in centres], np.float32)
+    want_min = np.float32(d.min()) - np.float32(d.min()) * np.float32(0.4)
+    want_max = np.float32(d.max()) + np.float32(d.max()) * np.float32(0.2)
+    L = host_lib()
+    L.gipuma_host_bundler_depth_range.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.c_int, C.c_float,
+                                                  C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    flat = np.ascontiguousarray(np.stack(Pl).reshape(-1), dtype=np.float64)
+    fp = flat.ctypes.data_as(C.POINTER(C.c_double))
+    dmin, dmax = C.c_float(-1), C.c_float(-1)
+    assert L.gipuma_host_bundler_depth_range(bf.encode(), fp, 3, 1.0, C.byref(dmin), C.byref(dmax)) == 0
+    assert dmin.value == pytest.approx(float(want_min), rel=2e-5)
+    assert dmax.value == pytest.approx(float(want_max), rel=2e-5)
+    # values that are already set stay (after selectViews, main.cpp:481-484, that is always the case)
+    dmin, dmax = C.c_float(300.0), C.c_float(-1)
+    assert L.gipuma_host_bundler_depth_range(bf.encode(), fp, 3, 1.0, C.byref(dmin), C.byref(dmax)) == 0
+    assert dmin.value == 300.0 and dmax.value == pytest.approx(float(want_max), rel=2e-5)
+    # a file without points
+    _write_bundle(bf, [], comment=comment)
+    dmin, dmax = C.c_float(1.0), C.c_float(2.0)
+    assert L.gipuma_host_bundler_depth_range(bf.encode(), fp, 3, 1.0, C.byref(dmin), C.byref(dmax)) != 0
+
+
+def test_pfm_ground_truth_keeps_the_last_channel(tmp_path):
+    """readPfm (fileIoUtils.h:430-446): rows bottom-up; a 3-channel 'PF' file leaves the LAST float of a pixel"""
+    rows, cols = 3, 4
+    a = np.arange(rows * cols * 3, dtype=np.float32).reshape(rows, cols, 3)
+    for name, magic, data, want in [("c3.pfm", b"PF", a, a[..., 2]), ("c1.pfm", b"Pf", a[..., 0], a[..., 0])]:
+        path = str(tmp_path / name)
+        with open(path, "wb") as f:
+            f.write(magic + b"\n%d %d\n-1.0\n" % (cols, rows) + np.ascontiguousarray(data[::-1]).tobytes())
+        L = host_lib()
+        L.gipuma_host_read_gt_map.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        r, c = C.c_int(), C.c_int()
+        out = np.zeros((rows, cols), np.float32)
+        assert L.gipuma_host_read_gt_map(path.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(r), C.byref(c)) == 0
+        assert (r.value, c.value) == (rows, cols)
+        assert np.array_equal(out, want)

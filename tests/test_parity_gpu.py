@@ -211,6 +211,33 @@ def test_device_resident_images_with_pitch(hip):
     assert_same(c, o_c, "device images cost")
 
 
+def test_image_cache_is_pinned_by_live_sessions(hip):
+    """GIPUMA_HIP_FLAG_CACHE_IMAGES: sessions share the packed copies of resident images; the cache refuses
+    to free them while a session that samples them is alive, frees them afterwards, and a session created
+    after the clear packs again and still gives the oracle's bits"""
+    import torch
+    gs, _ = synth.build_problem(synth.tiny_config(n_src=3, iterations=2))
+    dev = [torch.from_numpy(np.ascontiguousarray(im)).to("cuda:0") for im in gs.images]
+    torch.cuda.synchronize()
+    from gipuma_amd.problem import GlobalState
+    gsd = GlobalState(dev, gs.cameras, gs.selected, gs.params, seed=1, device_ptrs=[t.data_ptr() for t in dev],
+                      rows=gs.rows, cols=gs.cols, flags=abi.FLAG_CACHE_IMAGES)
+    lib = abi.load_library()
+    o = OracleState(gs).run()
+    with Session(gsd) as s1:
+        with Session(gsd) as s2:
+            assert lib.gipuma_hip_cache_clear() == abi.ERR_ARG  # two users
+            s2.solve()
+        assert lib.gipuma_hip_cache_clear() == abi.ERR_ARG      # one user left
+        s1.solve()
+        n4, c = s1.get_state()
+    assert_same(n4, o[0], "cached images norm4")
+    assert lib.gipuma_hip_cache_clear() == 0
+    a = runcuda(gsd)
+    assert_same(a[0], o[0], "after the clear norm4")
+    assert lib.gipuma_hip_cache_clear() == 0
+
+
 @pytest.mark.parametrize("tune", [1 << 30, 1 << 29, 1 << 28, (1 << 30) | (1 << 28), 1 << 27, 1 << 26,
                                   (1 << 26) | (1 << 29), 1 << 23, 1 << 25, (1 << 25) | (1 << 27),
                                   (1 << 27) | (1 << 25), 1 << 19, (1 << 19) | (1 << 27), 1 << 22,
