@@ -45,10 +45,38 @@ def algorithmic_bytes_per_sweep_launch(n_pixels, n_views):
 # ------------------------------------------------------------------------------------------------
 # CPU baselines (reported, never optimised against): bounded samples of the SAME workload
 # ------------------------------------------------------------------------------------------------
-def _ref_worker(problem_file, bx0, bx1, by0, by1):
+def effective_cores():
+    """(cores this process may really use, how that was found): the affinity mask, cut down by the cgroup's CPU
+    quota where one is set -- a container that SEES 256 hardware threads may be allowed the time of 8"""
+    n_aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:  # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:  # noqa: BLE001
+        try:  # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:  # noqa: BLE001
+            quota = None
+    n = n_aff if quota is None else max(1, min(n_aff, int(quota + 0.5)))
+    return n, {"affinity": n_aff, "cgroup_cpu_quota": quota}
+
+
+def _ref_worker(problem_file, bx0, bx1, by0, by1, cpu):
     """one process = one core: the reference's OWN device code (oracle/_ref/libgipuma_ref.so =
     /root/reference/gipuma.cu lines 1..1824 compiled for the CPU, oracle/ref_shim/build_ref.sh)
-    on a window of 32x32-pixel blocks of the frame: its init kernel + one iteration (6 launches)"""
+    on a window of 32x32-pixel blocks of the frame: its init kernel + one iteration (6 launches).
+    The worker pins itself to one CPU, maps the shared frames, runs the same launches once untimed (first
+    touch of its state planes) and then measured."""
+    if cpu >= 0 and hasattr(os, "sched_setaffinity"):
+        try:
+            os.sched_setaffinity(0, {cpu})
+        except OSError:
+            pass
     from gipuma_amd.problem import load_problem
     from tests import ref_lib
     gs = load_problem(problem_file)
@@ -56,6 +84,9 @@ def _ref_worker(problem_file, bx0, bx1, by0, by1):
     L.ref_time_window.argtypes = [C.POINTER(type(gs.desc)), C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.POINTER(C.c_double), C.POINTER(C.c_double)]
     ti, ts = C.c_double(), C.c_double()
+    L.ref_time_window_warm.argtypes = [C.c_int]
+    L.ref_time_window_warm(0)
+    L.ref_time_window(C.byref(gs.desc), bx0, bx0 + 1, by0, by1, C.byref(ti), C.byref(ts))  # untimed: pages, caches
     print("READY", flush=True)
     sys.stdin.readline()  # start together with the other workers
     rc = L.ref_time_window(C.byref(gs.desc), bx0, bx1, by0, by1, C.byref(ti), C.byref(ts))
@@ -63,25 +94,28 @@ def _ref_worker(problem_file, bx0, bx1, by0, by1):
                       "pixels": (bx1 - bx0) * (by1 - by0) * 1024}), flush=True)
 
 
-def _ref_baseline(problem_file, rows, cols, iterations, n_proc, blocks_each=1):
-    """the reference's own code on `n_proc` cores at once: one single-threaded process per core
-    (its device code keeps block state in globals), each on its own window of interior blocks of
+def _ref_baseline(problem_file, rows, cols, iterations, n_proc, blocks_each=4):
+    """the reference's own code on `n_proc` cores at once: one single-threaded, pinned process per core
+    (its device code keeps block state in globals), each on its own run of interior blocks of
     the same frame; throughput = pixels of all windows / slowest process, scaled by iterations
     (work per pixel and per iteration is constant)."""
     from tests import ref_lib
     if not ref_lib.available():
         return None
     gx, gy = cols // 32, rows // 32  # interior, fully covered blocks only
+    cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
+    span = max(1, gx - 2 - blocks_each)
     procs = []
     for i in range(n_proc):
-        b = (i * 7919) % ((gx - 2) * (gy - 2))
-        bx0, by0 = 1 + b % (gx - 2), 1 + b // (gx - 2)
-        code = ("import sys; sys.path.insert(0, %r); import bench; bench._ref_worker(%r, %d, %d, %d, %d)"
-                % (ROOT, problem_file, bx0, min(bx0 + blocks_each, gx - 1), by0, by0 + 1))
+        b = (i * 7919) % (span * (gy - 2))
+        bx0, by0 = 1 + b % span, 1 + b // span
+        cpu = cpus[(i * max(1, len(cpus) // max(n_proc, 1))) % len(cpus)] if cpus else -1
+        code = ("import sys; sys.path.insert(0, %r); import bench; bench._ref_worker(%r, %d, %d, %d, %d, %d)"
+                % (ROOT, problem_file, bx0, min(bx0 + blocks_each, gx - 1), by0, by0 + 1, cpu))
         procs.append(subprocess.Popen([sys.executable, "-c", code], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
                                       stderr=subprocess.DEVNULL, text=True,
                                       env=dict(os.environ, OMP_NUM_THREADS="1")))
-    for p in procs:  # every worker has rendered its frames
+    for p in procs:  # every worker has mapped the frames and touched its pages
         while True:
             line = p.stdout.readline()
             if not line or line.startswith("READY"):
@@ -106,8 +140,9 @@ def _ref_baseline(problem_file, rows, cols, iterations, n_proc, blocks_each=1):
     full = (t_init + iterations * t_iter) * rows * cols / px
     return {"value": rows * cols / full / 1e6, "unit": "Mpix/s", "cores": n_proc, "kind": "reference",
             "sample": "the reference's own kernels (gipuma.cu compiled for the CPU, oracle/_ref), %d single-threaded "
-                      "processes at once, each on %d interior 32x32 block(s) of the same frame: init %.2fs + 1 "
-                      "iteration (6 launches) %.2fs (slowest), scaled by pixels and x%d iterations; sample wall %.1fs"
+                      "pinned processes at once, each on %d interior 32x32 blocks of the same frame after an untimed "
+                      "pass over one block: init %.2fs + 1 iteration (6 launches) %.2fs (slowest), scaled by pixels "
+                      "and x%d iterations; sample wall %.1fs"
                       % (n_proc, blocks_each, t_init, t_iter, iterations, wall),
             "est_full_frame_seconds": full}
 
@@ -123,7 +158,10 @@ def _port_worker(problem_file, seconds):
     y0 = rows // 2
     L.gipuma_oracle_time_band(C.byref(gs.desc), y0, y0 + band, C.byref(ti), C.byref(ts))
     per_row = (ti.value + ts.value) / band
-    band = int(max(band, min(rows - y0, seconds / max(per_row, 1e-9))))
+    # (rows are the unit of the oracle's OpenMP loops: at least four per thread, so that the slowest thread does
+    #  not decide the figure)
+    band = int(max(band, 4 * L.gipuma_oracle_num_threads(), seconds / max(per_row, 1e-9)))
+    band = min(band, rows - y0)
     L.gipuma_oracle_time_band(C.byref(gs.desc), y0, y0 + band, C.byref(ti), C.byref(ts))
     it = gs.params.iterations
     full = (ti.value + it * ts.value) * rows / band
@@ -151,7 +189,7 @@ def cpu_baseline(problem_file, rows, cols, iterations):
     """`cpu_baseline` object of the bench line: the reference's own code on all cores of this host
     (kind "reference") when oracle/_ref exists, else the oracle port; the other figures (one core,
     the port) ride along under "all"."""
-    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ncpu, how = effective_cores()
     allv = {
         "reference_all_cores": _ref_baseline(problem_file, rows, cols, iterations, ncpu),
         "reference_1_core": _ref_baseline(problem_file, rows, cols, iterations, 1),
@@ -160,6 +198,10 @@ def cpu_baseline(problem_file, rows, cols, iterations):
     }
     head = allv["reference_all_cores"] or allv["port_all_cores"] or {"value": None, "kind": "port", "cores": ncpu}
     out = dict(head)
+    out["cores_available"] = how  # (`cores` = the workers actually run: the affinity mask cut down by the cgroup quota)
+    a, b = allv.get("reference_all_cores"), allv.get("reference_1_core")
+    if a and b and a.get("value") and b.get("value"):
+        out["speedup_all_cores_over_1"] = a["value"] / b["value"]
     out["all"] = allv
     return out
 
@@ -363,14 +405,27 @@ def main():
                 pd = json.load(open(pmc_dom))
             except Exception:  # noqa: BLE001
                 pd = None
+        # imported counters are flagged when they were not collected with the library this run loads
+        try:
+            import hashlib
+            lib_now = hashlib.sha256(open(os.environ.get("GIPUMA_HIP_LIB") or abi.LIB_PATH, "rb").read()).hexdigest()[:16]
+        except Exception:  # noqa: BLE001
+            lib_now = None
+
+        def stale(j):
+            return None if not j else (j.get("_lib_sha16") != lib_now)
         traffic = None
         if pd and "hbm_read_bytes_per_launch_x2corr" in pd:
             traffic = (pd["hbm_read_bytes_per_launch_x2corr"] + pd["hbm_write_bytes_per_launch"]) / 1e9
         imported_dom = {"measured_in_this_run": False, "file": "profiles/pmc_latest_sweep_kernel.json",
                         "collected_at_kernel_ms": pd.get("_kernel_ms_profiled_mean") if pd else None,
+                        "collected_with_lib_sha16": pd.get("_lib_sha16") if pd else None, "commit": pd.get("_commit") if pd else None,
+                        "lib_sha16_of_this_run": lib_now, "stale": stale(pd),
                         "note": pd.get("_note") if pd else None}
         imported = {"measured_in_this_run": False, "file": "profiles/pmc_latest.json",
                     "collected_at_kernel_ms": pj.get("_kernel_ms_profiled_mean") if pj else None,
+                    "collected_with_lib_sha16": pj.get("_lib_sha16") if pj else None, "commit": pj.get("_commit") if pj else None,
+                    "lib_sha16_of_this_run": lib_now, "stale": stale(pj),
                     "note": pj.get("_note") if pj else None}
         box = gs.params.box_hsize
         S = ((box - 1) // 2 + 1) ** 2
@@ -442,6 +497,15 @@ def main():
                 "per": "half-sweep of a view (all its kernels: sums over the dispatches / %d)" % n_launch,
                 "valu_instr_per_window_load": pj["SQ_INSTS_VALU"] / max(1.0, pj.get("SQ_INSTS_VMEM_RD", 0.0)),
                 "source": dict(imported, counter="rocprofv3 --pmc SQ_INSTS_VALU")}
+        # ... and for the dominant kernel alone (its own summary of the same passes, this run's launch time)
+        if pd and "SQ_INSTS_VALU" in pd:
+            lane_ops = pd["SQ_INSTS_VALU"] * 64.0
+            peak = 256 * 4 * 32 * 2.4e9
+            out["roofline_valu_kernel"] = {
+                "bound": "valu", "kernel": "pm::sweep_kernel", "achieved": lane_ops / (ms_launch * 1e-3) / 1e12,
+                "peak": peak / 1e12, "unit": "T lane-instr/s", "frac": lane_ops / (ms_launch * 1e-3) / peak,
+                "valu_wave_instr_per_launch": pd["SQ_INSTS_VALU"], "kernel_ms": ms_launch,
+                "source": dict(imported_dom, counter="rocprofv3 --pmc SQ_INSTS_VALU")}
         if world == 1 and not args.no_extras:
             from gipuma_amd.problem import GlobalState, runcuda
             # (a) the same workload with every exact work-reduction switched off (skip rules A/D/H, early

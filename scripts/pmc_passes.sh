@@ -29,6 +29,22 @@ python $R/scripts/rocprof_summary.py pmc $OUT push_kernel > $OUT/pmc_summary_pus
 python $R/scripts/rocprof_summary.py pmc $OUT sweep_kernel > $OUT/pmc_summary_pixel_per_lane.json
 python $R/scripts/rocprof_summary.py pmc $OUT sweep_cols_kernel > $OUT/pmc_summary_column_per_lane.json
 python $R/scripts/rocprof_summary.py pmc $OUT init_kernel > $OUT/pmc_summary_init.json
-python $R/scripts/rocprof_summary.py pmc $OUT prop_shared_kernel > $OUT/pmc_summary_prop_shared.json
+# which binary and which source these counters belong to: bench.py flags imported figures as stale when the
+# library it runs is not this one
+python - $OUT $R <<'PY'
+import glob, hashlib, json, os, sys
+out, root = sys.argv[1:3]
+lib = os.environ.get("GIPUMA_HIP_LIB") or os.path.join(root, "gipuma_amd", "csrc", "libgipuma_hip.so")
+sha = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
+src = hashlib.sha256(b"".join(open(f, "rb").read() for f in sorted(glob.glob(os.path.join(root, "gipuma_amd", "csrc", "*.h*"))))).hexdigest()[:16]
+commit = os.environ.get("GIPUMA_COMMIT", "")
+for f in glob.glob(os.path.join(out, "pmc_summary*.json")):
+    try:
+        d = json.load(open(f))
+    except Exception:
+        continue
+    d["_lib_sha16"], d["_src_sha16"], d["_commit"] = sha, src, commit
+    json.dump(d, open(f, "w"), indent=1, sort_keys=True)
+PY
 rm -f $OUT/*.db
 ls -la $OUT | head -30

@@ -19,9 +19,16 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "A"
 over = {}
 if len(sys.argv) > 3:
     over = dict(cols=int(sys.argv[2]), rows=int(sys.argv[3]))
+# optional 4th argument: the texture-filter model the reference's code runs with -- 0: fp32 lerp weights (M1, the
+# model the oracle and the kernels use); 1: weights rounded to 8 fractional bits, the 1.8 fixed-point weights the
+# CUDA programming guide documents for cudaFilterModeLinear (main.cpp:644-648)
+tex_mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 gs, info = synth.build_problem(cfg, **over)
+ref_lib.lib().ref_set_tex_mode(tex_mode)
+print("reference texture filter model: %s" % ("8-bit fixed-point weights (CUDA's documented filter)" if tex_mode else "fp32 weights (M1)"))
 t0 = time.time()
 rn, rc = ref_lib.RefState(gs).run()
+ref_lib.lib().ref_set_tex_mode(0)
 t1 = time.time()
 on, oc = OracleState(gs).run()
 t2 = time.time()

@@ -100,3 +100,62 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"],
                        capture_output=True, text=True, timeout=120, env=env)
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+# ---- on hardware (the driver's GPU box has one MI355X; an 8-GPU node runs the same code with 8 devices) ----
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_sessions_on_two_devices_from_one_process(hip):
+    """config E in miniature: two DIFFERENT reference views solved concurrently by two sessions -- on devices
+    0 and min(1, count - 1), i.e. two GPUs where there are two, the same GPU twice on the one-GPU box -- each
+    with its own stream, enqueued asynchronously; each result equals the same view solved alone on device 0
+    (the path has no cross-device state: the shard is the whole view)."""
+    import numpy as np
+    from gipuma_amd import abi
+    from gipuma_amd.problem import Session, runcuda
+    lib = abi.load_library()
+    n_dev = lib.gipuma_hip_device_count()
+    assert n_dev >= 1
+    views = synth.DTU_REF_VIEWS[:2]
+    cfg = synth.tiny_config(cols=160, rows=112, n_src=4, blocksize=15, iterations=3, n_best=3)
+    problems = [synth.build_problem(cfg, ref_view=v)[0] for v in views]
+    alone = [runcuda(g) for g in problems]
+    for k, g in enumerate(problems):
+        g.desc.device_id = min(k, n_dev - 1)
+    sessions = [Session(g) for g in problems]
+    try:
+        for s in sessions:
+            s.solve(timing=False)  # asynchronous: both solves are in flight before either is waited for
+        got = [s.get_state() for s in sessions]
+    finally:
+        for s in sessions:
+            s.close()
+    for k in range(2):
+        assert np.array_equal(got[k][0].view(np.uint32), alone[k][0].view(np.uint32)), "view %d norm4" % views[k]
+        assert np.array_equal(got[k][1].view(np.uint32), alone[k][1].view(np.uint32)), "view %d cost" % views[k]
+    assert not np.array_equal(got[0][0], got[1][0])  # (two different problems)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_hardware(hip):
+    """the real rank path of `bench.py --gpus 2` on the GPU box: two processes, gloo rendezvous on 127.0.0.1,
+    device binding by LOCAL_RANK, one problem per rank from its own reference view, barrier + MAX over ranks,
+    ONE JSON line with the whole-job value.  --oversubscribe lets both ranks share the box's single GPU (on an
+    8-GPU node the driver runs it without: N ranks on N distinct devices, asserted by bench.py itself)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--steps", "1",
+                        "--warmup", "0", "--config", "B", "--no-extras", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert [r["rank"] for r in d["ranks"]] == [0, 1]
+    assert len({r["ref_view"] for r in d["ranks"]}) == 2
+    # whole-job value = both ranks' pixels over the slower rank's time
+    assert d["value"] <= sum(r["value"] for r in d["ranks"]) * 1.0001
+    assert d["quality"]["frac_within_1pct_of_gt"] > 0.5
