@@ -294,7 +294,10 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
     }
     if (s->worder && !s->worder_valid) {
         typedef void (*order_fn)(const pm::Problem *, uint32_t *);
-        const order_fn ok = s->box == 15 ? pm::weight_order_kernel<15>
+        const order_fn ok = s->ch == 4    ? (s->box == 15   ? pm::weight_order_kernel<15, 4>
+                                             : s->box == 25 ? pm::weight_order_kernel<25, 4>
+                                                            : pm::weight_order_kernel<11, 4>)
+                            : s->box == 15 ? pm::weight_order_kernel<15>
                             : s->box == 25 ? pm::weight_order_kernel<25>
                                            : pm::weight_order_kernel<11>;
         const int n = s->rows * s->cols;
@@ -642,7 +645,7 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     // lower-bound prefilter of refinement candidates: where the two-phase refinement runs on gray planes
     hp.lb_k = 0;  // chosen by the probe workgroups
     if (const char *t = getenv("GIPUMA_HIP_LB_K")) hp.lb_k = atoi(t);  // experiment: fixed length, < 0 = off
-    if (hp.et_enable && s->ch == 1 && s->box > 0 && hp.lb_k >= 0 && !(s->tune & (Tune::kNoTwoPhase | Tune::kNoEarlyExit))) {
+    if (hp.et_enable && s->box > 0 && hp.lb_k >= 0 && !(s->tune & (Tune::kNoTwoPhase | Tune::kNoEarlyExit))) {
         CREATE_OK(hipMalloc(&s->worder, (size_t)pm::kLbDwords * np * sizeof(uint32_t)));
         hp.worder = s->worder;
     } else {

@@ -249,7 +249,7 @@ constexpr int kTpViews = 5;
 // 2: items left after phase 1, 3: items}] for the three bounded steps, then [12 + step] = the phase-1
 // length the probes used
 constexpr unsigned kEtSlot = 24;  // ... and [16 + step] = the prefilter length (lb_item) they used
-constexpr int kLbMax = 16, kLbDwords = kLbMax / 2;
+constexpr int kLbMax = 32, kLbDwords = kLbMax / 2;
 constexpr int kSeenRing = 8;
 // Problem::dbg slots: propagation tasks, candidates removed by rule (S), refinement items, items the
 // prefilter / phase 1 left open, refinement candidates redone, refinement candidates
@@ -847,7 +847,7 @@ constexpr float kLbFloor = 0x1p-60f;
 #ifndef PM_LB_GROUP
 #define PM_LB_GROUP 1  // (measured on config C: singles 89.5, pairs 91.2, quads 93.0 ms per view)
 #endif
-template <int BOX>
+template <int BOX, int CH = 1>
 __global__ __launch_bounds__(kThreads) void weight_order_kernel(const Problem *__restrict__ P,
                                                                 uint32_t *__restrict__ order)
 {
@@ -862,7 +862,14 @@ __global__ __launch_bounds__(kThreads) void weight_order_kernel(const Problem *_
     if (center >= np) return;
     const int py = center / cols, px = center - py * cols;
     const gptr_f32 ref = (gptr_f32)P->ref;
-    const float centre = ref[py * pitch + px];
+    // (colour: |dB| + |dG| + |dR|, the index of the colour weight table)
+    auto texel_dist = [&](int x, int y) -> float {
+        if (CH == 4) {
+            const gptr_f32 a = ref + (y * pitch + 4 * x), c = ref + (py * pitch + 4 * px);
+            return __builtin_fabsf(a[0] - c[0]) + __builtin_fabsf(a[1] - c[1]) + __builtin_fabsf(a[2] - c[2]);
+        }
+        return __builtin_fabsf(ref[y * pitch + x] - ref[py * pitch + px]);
+    };
     uint32_t best[KG];  // ascending keys: sum of |dI| << 16 | row << 8 | first column
 #pragma unroll
     for (int k = 0; k < KG; k++) best[k] = 0xffffffffu;
@@ -873,7 +880,7 @@ __global__ __launch_bounds__(kThreads) void weight_order_kernel(const Problem *_
 #pragma unroll
             for (int e = 0; e < G; e++) {
                 const int x = clampi(px - R + 2 * (G * c + e), 0, cols - 1);
-                dsum += __builtin_fabsf(ref[y * pitch + x] - centre);
+                dsum += texel_dist(x, y);
             }
             uint32_t key = (min(cvt_u32_sat(dsum), 0xfffeu) << 16) | (uint32_t)(ri << 8) | (uint32_t)(G * c);
 #pragma unroll
@@ -898,12 +905,13 @@ struct LbReq {
     u32x4_a4 w;
     uint32_t taddr;  // float-encoded LDS offset of the sample's reference texel
 };
-// the sum of w * dis over the first 2 * kd listed samples of the pixel's window, for one view
+// the sum of w * dis over the first 2 * kd listed samples of the pixel's window, for one view; `ordp` points at
+// the pixel's entry of the first list plane (plane d is np words further: streamed, one word ahead)
 template <int BOX, bool FAST>
 __device__ __forceinline__ float lb_item(const Problem *__restrict__ P, gptr_bytes magic_base,
                                          const float *__restrict__ H, const float *__restrict__ tp0, int tw,
                                          const float *__restrict__ lut, int px, int py,
-                                         const uint32_t (&ord)[kLbDwords], int kd, float *lb_short)
+                                         const uint32_t *__restrict__ ordp, size_t np, int kd, float *lb_short)
 {
     // (*lb_short: the sum two samples short of the end -- what the probe workgroups use to judge the length)
     static_assert(BOX > 0, "compile-time window only");
@@ -920,6 +928,7 @@ __device__ __forceinline__ float lb_item(const Problem *__restrict__ P, gptr_byt
     // byte offset of texel (col, row) of the window from tp0: 16 * ((2 row - R) * tw + 2 col - R), as the
     // low bits of the float 2^23 + 2^15 + offset (|offset| < 2^15: ulp 1, bits = 0x4b008000 + offset)
     constexpr uint32_t kTileMagic = 0x4b008000u;
+    static_assert(16 * R * (kTileW + 2 * (R + 1) + 1) < 32768, "tile offsets fit the float encoding");
     const float trow = (float)(32 * tw);
     const float tbias = 8421376.0f - (float)(16 * R * (tw + 1));  // 2^23 + 2^15 - 16 R (tw + 1)
     const char *tile_magic = (const char *)tp0 - kTileMagic;
@@ -960,26 +969,101 @@ __device__ __forceinline__ float lb_item(const Problem *__restrict__ P, gptr_byt
         return __builtin_fmaf(w, dis, acc);
     };
 
+    typedef const __attribute__((address_space(1))) uint32_t *gptr_u32;
+    const gptr_u32 op = (gptr_u32)ordp;
     float lb = 0.0f, prev = 0.0f;
-    LbReq r0 = request(ub0(ord[0]), ub1(ord[0])), r1 = request(ub2(ord[0]), ub3(ord[0]));
-#pragma unroll
-    for (int d = 0; d < kLbDwords; d++) {
-        if (d >= kd) break;  // (wave-uniform)
+    const uint32_t w0 = op[0];
+    uint32_t nxt = op[kd > 1 ? np : 0];
+    LbReq r0 = request(ub0(w0), ub1(w0)), r1 = request(ub2(w0), ub3(w0));
+    for (int d = 0; d < kd; d++) {
         prev = lb;
-        // (the two requests past the last sample fetch valid, clamped addresses and are dropped)
-        const uint32_t nxt = ord[d + 1 < kLbDwords ? d + 1 : d];
+        // samples 2d + 2 and 2d + 3 are requested while 2d and 2d + 1 are reduced; the list word after them is
+        // on its way (the two requests past the last sample fetch valid, clamped addresses and are dropped)
+        const uint32_t cw = nxt;
+        nxt = op[(size_t)min(d + 2, kLbDwords - 1) * np];
         LbReq cur = r0;
         r0 = r1;
-        r1 = request(ub0(nxt), ub1(nxt));
+        r1 = request(ub0(cw), ub1(cw));
         __builtin_amdgcn_sched_barrier(0);
         lb = reduce(cur, lb);
         __builtin_amdgcn_sched_barrier(0);
         cur = r0;
         r0 = r1;
-        r1 = request(ub2(nxt), ub3(nxt));
+        r1 = request(ub2(cw), ub3(cw));
         __builtin_amdgcn_sched_barrier(0);
         lb = reduce(cur, lb);
         __builtin_amdgcn_sched_barrier(0);
+    }
+    *lb_short = prev;
+    return lb;
+}
+
+__device__ __forceinline__ float l1_3(float x, float y, float z);
+// lb_item for T = float4 (-color_processing): the per-sample arithmetic of view_cost_c4_loop (three window
+// loads and tap sets, l1_norm(float4) reductions, weight table indexed by |dB|+|dG|+|dR|, integer window
+// addressing) on the listed samples; `tp0` points at the pixel's own texel in the float4 {B, G, R, 0} tile
+template <int BOX, bool FAST>
+__device__ __forceinline__ float lb_item_c4(const Problem *__restrict__ P, const ViewCam &vc,
+                                            const float *__restrict__ H, const float *__restrict__ tp0, int tw,
+                                            const float *__restrict__ lut, int px, int py,
+                                            const uint32_t *__restrict__ ordp, size_t np, int kd, float *lb_short)
+{
+    static_assert(BOX > 0, "compile-time window only");
+    constexpr int R = (BOX - 1) / 2;
+    const gptr_bytes packed = (gptr_bytes)vc.packed;
+    const uint32_t pw = (uint32_t)P->pw;
+    const uint32_t xmax = (uint32_t)(P->cols + 2), ymax = (uint32_t)(P->rows + 2);
+    const float alpha = P->alpha, oma = 1.f - P->alpha;
+    const float tau_color = P->tau_color, tau_gradient = P->tau_gradient;
+    const float4 centre = *reinterpret_cast<const float4 *>(tp0);
+    typedef const __attribute__((address_space(1))) uint32_t *gptr_u32;
+    const gptr_u32 op = (gptr_u32)ordp;
+    float lb = 0.0f, prev = 0.0f;
+    for (int d = 0; d < kd; d++) {
+        prev = lb;
+        const uint32_t cw = op[(size_t)d * np];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int ci = (int)((cw >> (16 * e)) & 255u), ri = (int)((cw >> (16 * e + 8)) & 255u);
+            const int i = 2 * ci - R, j = 2 * ri - R;
+            const float qx = (float)(px + i), qy = (float)(py + j);
+            const float X0 = __builtin_fmaf(H[0], qx, H[2]);
+            const float Y0 = __builtin_fmaf(H[3], qx, H[5]);
+            const float Z0 = __builtin_fmaf(H[6], qx, H[8]);
+            const float *tp = tp0 + 4 * (j * tw + i);
+            const float4 lv = *reinterpret_cast<const float4 *>(tp);
+            const float S = __builtin_fabsf(lv.x - centre.x) + __builtin_fabsf(lv.y - centre.y) +
+                            __builtin_fabsf(lv.z - centre.z);  // exact integer 0..765
+            const float w = lut[(int)S];
+            const float X = __builtin_fmaf(H[1], qy, X0);
+            const float Y = __builtin_fmaf(H[4], qy, Y0);
+            const float Z = __builtin_fmaf(H[7], qy, Z0);
+            const float rz = recip<FAST>(Z);
+            const float sx = X * rz, sy = Y * rz;
+            const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
+            const float a = sx - fx0, b = sy - fy0;
+            const uint32_t Xw = min(cvt_u32_sat(fx0 + 2.0f), xmax);
+            const uint32_t Yw = min(cvt_u32_sat(fy0 + 2.0f), ymax);
+            const gptr_bytes base = packed + (Yw * pw + Xw) * 12u;
+            const u32x4_a4 q0 = *(gptr_u32x4)(base), q1 = *(gptr_u32x4)(base + 16), q2 = *(gptr_u32x4)(base + 32);
+            Taps t[3];  // word 3k+c = column k, channel c
+            t[0] = taps_u8(a, b, q0.x, q0.w, q1.z, q2.y);
+            t[1] = taps_u8(a, b, q0.y, q1.x, q1.w, q2.z);
+            t[2] = taps_u8(a, b, q0.z, q1.y, q2.x, q2.w);
+            const float4 up = *reinterpret_cast<const float4 *>(tp - 4 * tw);
+            const float4 down = *reinterpret_cast<const float4 *>(tp + 4 * tw);
+            const float4 left = *reinterpret_cast<const float4 *>(tp - 4);
+            const float4 right = *reinterpret_cast<const float4 *>(tp + 4);
+            const float colDiff = l1_3(lv.x - t[0].sc, lv.y - t[1].sc, lv.z - t[2].sc);
+            const float gX = l1_3((right.x - left.x) - t[0].gx2, (right.y - left.y) - t[1].gx2,
+                                  (right.z - left.z) - t[2].gx2);
+            const float gY = l1_3((down.x - up.x) - t[0].gy2, (down.y - up.y) - t[1].gy2,
+                                  (down.z - up.z) - t[2].gy2);
+            const float gradDis = min_nc((gX + gY) * 0.0625f, tau_gradient);
+            const float colDis = min_nc(colDiff, tau_color);
+            const float dis = __builtin_fmaf(alpha, gradDis, oma * colDis);
+            lb = __builtin_fmaf(w, dis, lb);
+        }
     }
     *lb_short = prev;
     return lb;
@@ -2125,7 +2209,7 @@ template <int BOX, int CH>
 __device__ __forceinline__ float refine_two_phase(const Problem *__restrict__ P, const SweepLane &L, float *work,
                                                   const float *__restrict__ lut, int colour, bool valid, float4 cand,
                                                   float thr, int g0, float *kth_out, int &seq, int *cols_run,
-                                                  int *items_left, int lbk, const uint32_t (&ord)[kLbDwords],
+                                                  int *items_left, int lbk, const uint32_t *ordp,
                                                   int *items_short = nullptr)
 {
     constexpr int R = (BOX - 1) / 2, N = R + 1;
@@ -2148,26 +2232,32 @@ __device__ __forceinline__ float refine_two_phase(const Problem *__restrict__ P,
         for (int v = vb; v < ve; v++) {
             float a = 0.0f;
             bool alive = valid;
-            if (CH == 1 && lbk > 0) {
-                if constexpr (CH == 1) {
-                    float H[9];
-                    homography(P->rc.K_inv, P->view[v], cand, H);
-                    const bool safe = window_z_safe(H, (float)(L.px - R), (float)(L.px + R), (float)(L.py - R), (float)(L.py + R));
-                    const float *tp0 = L.tile + ((L.ly + L.hh) * L.tw + (L.lx + L.hw)) * 4;
-                    const gptr_bytes base = (gptr_bytes)((uintptr_t)P->view[v].packed - (uintptr_t)kMagicBits);
-                    float lb, lbs;
+            if (lbk > 0) {
+                float H[9];
+                homography(P->rc.K_inv, P->view[v], cand, H);
+                const bool safe = window_z_safe(H, (float)(L.px - R), (float)(L.px + R), (float)(L.py - R), (float)(L.py + R));
+                const float *tp0 = L.tile + ((L.ly + L.hh) * L.tw + (L.lx + L.hw)) * 4;
+                const size_t np = (size_t)P->rows * (size_t)P->cols;
+                float lb, lbs;
+                if constexpr (CH == 4) {
                     if (__all(safe))
-                        lb = lb_item<BOX, true>(P, base, H, tp0, L.tw, lut, L.px, L.py, ord, lbk >> 1, &lbs);
+                        lb = lb_item_c4<BOX, true>(P, P->view[v], H, tp0, L.tw, lut, L.px, L.py, ordp, np, lbk >> 1, &lbs);
                     else
-                        lb = lb_item<BOX, false>(P, base, H, tp0, L.tw, lut, L.px, L.py, ord, lbk >> 1, &lbs);
-                    if (cols_run) *cols_run += 1 + (lbk + N - 1) / N;
-                    const float bound = lb * kLbShrink;  // <= the reference's chain value (see lb_item)
-                    const bool dead = bound >= thr && lb >= kLbFloor;
-                    if (items_short)  // (probe workgroups: items that two samples fewer would have left open)
-                        *items_short += (int)__popcll(__ballot(valid && !(lbs * kLbShrink >= thr && lbs >= kLbFloor)));
-                    a = dead ? bound : 0.0f;
-                    alive = valid && !dead;
+                        lb = lb_item_c4<BOX, false>(P, P->view[v], H, tp0, L.tw, lut, L.px, L.py, ordp, np, lbk >> 1, &lbs);
+                } else {
+                    const gptr_bytes base = (gptr_bytes)((uintptr_t)P->view[v].packed - (uintptr_t)kMagicBits);
+                    if (__all(safe))
+                        lb = lb_item<BOX, true>(P, base, H, tp0, L.tw, lut, L.px, L.py, ordp, np, lbk >> 1, &lbs);
+                    else
+                        lb = lb_item<BOX, false>(P, base, H, tp0, L.tw, lut, L.px, L.py, ordp, np, lbk >> 1, &lbs);
                 }
+                if (cols_run) *cols_run += 1 + (lbk + N - 1) / N;
+                const float bound = lb * kLbShrink;  // <= the reference's chain value (see lb_item)
+                const bool dead = bound >= thr && lb >= kLbFloor;
+                if (items_short)  // (probe workgroups: items that two samples fewer would have left open)
+                    *items_short += (int)__popcll(__ballot(valid && !(lbs * kLbShrink >= thr && lbs >= kLbFloor)));
+                a = dead ? bound : 0.0f;
+                alive = valid && !dead;
             } else if (g0 > 0) {
                 float H[9];
                 homography(P->rc.K_inv, P->view[v], cand, H);
@@ -2262,12 +2352,13 @@ __device__ __forceinline__ bool refine_step_items(const Problem *__restrict__ P,
     // lower-bound prefilter (gray): length from Problem::lb_k, or two samples more / fewer than the previous
     // half-sweep's probes used if more than 12 % / fewer than 3 % of their items survived it
     int lbk = 0;
-    uint32_t ord[kLbDwords] = {};
-    if constexpr (CH == 1) {
+    const uint32_t *ordp = P->worder;
+    if (ordp != nullptr) {
+        constexpr int kLbFirst = Nc * Nc / 4 < kLbMax ? (Nc * Nc / 4) & ~1 : kLbMax;  // no measurement yet: a quarter of the window
         if (P->lb_k > 0) {
             lbk = min(P->lb_k & ~1, kLbMax);
         } else if (P->lb_k == 0) {
-            lbk = kLbMax;
+            lbk = kLbFirst;
             if (seen[3] > 0u) {
                 // an open item costs about kLbOpen samples (homography again + its chain up to the bound);
                 // the last two samples of the previous probes' prefilter paid if they closed more than
@@ -2285,12 +2376,7 @@ __device__ __forceinline__ bool refine_step_items(const Problem *__restrict__ P,
                 lbk = max(4, min(lbk, kLbMax));
             }
         }
-        if (lbk > 0) {
-            const size_t np = (size_t)P->rows * (size_t)P->cols;
-            const size_t me = L.active ? (size_t)L.center : 0;
-#pragma unroll
-            for (int d = 0; d < kLbDwords; d++) ord[d] = P->worder[(size_t)d * np + me];
-        }
+        ordp += L.active ? (size_t)L.center : 0;
     }
     const int lbk_used = lbk;
     int items_left = 0, items_short = 0, n_redo = 0;
@@ -2302,7 +2388,7 @@ __device__ __forceinline__ bool refine_step_items(const Problem *__restrict__ P,
         float kth;
         const float cc = refine_two_phase<BOX, CH>(P, L, L.bres, lds, colour, need, cand, thr, g0, &kth, tp_seq,
                                                    probe ? &cols_run : nullptr, pass == 0 ? &items_left : nullptr,
-                                                   lbk, ord, probe && pass == 0 ? &items_short : nullptr);
+                                                   lbk, ordp, probe && pass == 0 ? &items_short : nullptr);
         const bool open = need && kth >= thr && cc < L.cst;
         if (need && !open) c = cc;
         need = open;
@@ -2370,7 +2456,10 @@ __global__ __launch_bounds__(kThreads, U8 ? (CH == 4 ? 4 : PM_SWEEP_WG) : 1) voi
     if (P->dbg != nullptr) {
         unsigned long long *d = P->dbg + (size_t)(phase & 63u) * kDbgSlots;
         if (threadIdx.x == 0) atomicAdd(&d[kDbgTasks], (unsigned long long)L.n_tasks);
-        if (L.n_seen) atomicAdd(&d[kDbgSeen], (unsigned long long)L.n_seen);
+        int ns = L.n_seen;  // (one atomic per wavefront: per-lane atomics on one address would distort the timing)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ns += __shfl_xor(ns, o);
+        if ((threadIdx.x & 63u) == 0u && ns) atomicAdd(&d[kDbgSeen], (unsigned long long)ns);
     }
     RefineDraws R;
     refine_init(R, P, stages);

@@ -24,10 +24,9 @@ if len(sys.argv) > 3:
 # CUDA programming guide documents for cudaFilterModeLinear (main.cpp:644-648)
 tex_mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 gs, info = synth.build_problem(cfg, **over)
-ref_lib.lib().ref_set_tex_mode(tex_mode)
 print("reference texture filter model: %s" % ("8-bit fixed-point weights (CUDA's documented filter)" if tex_mode else "fp32 weights (M1)"))
 t0 = time.time()
-rn, rc = ref_lib.RefState(gs).run()
+rn, rc = ref_lib.RefState(gs, tex_mode=tex_mode).run()
 ref_lib.lib().ref_set_tex_mode(0)
 t1 = time.time()
 on, oc = OracleState(gs).run()

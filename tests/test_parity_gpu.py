@@ -333,7 +333,7 @@ def test_two_phase_refinement_is_exact_for_any_split(hip, g0, theta):
     assert_same(a[1], o[1], "g0 %d theta %s cost" % (g0, theta))
 
 
-@pytest.mark.parametrize("lbk", [0, 2, 4, 8, 12, 16])
+@pytest.mark.parametrize("lbk", [0, 2, 8, 12, 16, 32])
 @pytest.mark.parametrize("theta", ["0.05,0.05,0.05", "1,1,1", "3,2,1.5"])
 def test_lower_bound_prefilter_is_exact_for_any_length(hip, lbk, theta):
     """pm::lb_item: a refinement candidate's view costs are first bounded from below by the sum over the
@@ -353,6 +353,18 @@ def test_lower_bound_prefilter_is_exact_for_any_length(hip, lbk, theta):
             del os.environ[k]
     assert_same(a[0], o[0], "lbk %d theta %s norm4" % (lbk, theta))
     assert_same(a[1], o[1], "lbk %d theta %s cost" % (lbk, theta))
+
+
+@pytest.mark.parametrize("lbk", [0, 6, 32])
+@pytest.mark.parametrize("theta", ["0.05,0.05,0.05", "1,1,1.5"])
+def test_lower_bound_prefilter_colour(hip, lbk, theta):
+    """the same in the colour kernels (pm::lb_item_c4: three window loads per sample, |dB|+|dG|+|dR| weights)"""
+    gs, _ = synth.build_problem(synth.tiny_config(cols=96, rows=80, n_src=6, blocksize=15, iterations=3, n_best=3),
+                                colour=True)
+    o = OracleState(gs).run()
+    a = _with_env({"GIPUMA_HIP_ET_THETA": theta, "GIPUMA_HIP_ET_FORCE": 2, "GIPUMA_HIP_LB_K": lbk}, lambda: runcuda(gs))
+    assert_same(a[0], o[0], "colour lbk %d theta %s norm4" % (lbk, theta))
+    assert_same(a[1], o[1], "colour lbk %d theta %s cost" % (lbk, theta))
 
 
 @pytest.mark.parametrize("cfg", [dict(cols=96, rows=80, n_src=5, blocksize=11, iterations=3, n_best=1),
