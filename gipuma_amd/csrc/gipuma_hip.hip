@@ -12,6 +12,7 @@
 #include "../../include/gipuma_hip.h"
 #include "pm_device.h"
 #include "pm_push.h"
+#include "pm_group.h"
 
 #include <algorithm>
 #include <cmath>
@@ -101,6 +102,11 @@ struct gipuma_hip_session {
     int push_valid = -1;       // colour whose pixels find valid costs in push_cost (-1: nobody)
     bool push_hist = false;    // ... offered under rule (H) (only the planes that changed)
     bool push_attr_set = false;
+    // plane-keyed propagation (pm_group.h): from half-sweep `group_from` on the propagation costs of a half-sweep
+    // come from pm::group_kernel, launched right before it
+    bool group_ok = false;
+    int group_from = 0;
+    bool group_attr_set = false;
     int box = 0;             // specialised window size, 0 = runtime
     int ch = 1;              // 1 = gray (T=float), 4 = colour (T=float4)
     unsigned tune = 0;
@@ -235,6 +241,26 @@ int launch_push(gipuma_hip_session *s, int colour, bool hist)
     return 0;
 }
 
+// pm::group_kernel: the propagation costs of the half-sweep of `colour` that follows, one evaluation per plane
+int launch_group(gipuma_hip_session *s, int colour, bool hist, unsigned tune)
+{
+    const int gx = (s->cols + pm::kTileW - 1) / pm::kTileW;
+    const int gy = (s->rows + pm::kSweepTileH - 1) / pm::kSweepTileH;
+    typedef void (*group_fn)(const pm::Problem *, const float4 *, const float *, int, int, unsigned);
+    const group_fn k = s->box == 15 ? pm::group_kernel<15> : pm::group_kernel<11>;
+    const size_t lds = sizeof(float) * (size_t)(s->box == 15 ? pm::GroupLayout<15>::total : pm::GroupLayout<11>::total);
+    if (!s->group_attr_set) {
+        HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        s->group_attr_set = true;
+    }
+    hipLaunchKernelGGL(k, dim3(gx * gy), dim3(pm::kThreads), lds, s->stream, s->dp, s->norm4, s->cost, colour,
+                       hist ? 1 : 0, tune & ~(Tune::kPushConsume | Tune::kHistorySkip));
+    HIP_OK(hipGetLastError());
+    s->push_valid = colour;
+    s->push_hist = hist;
+    return 0;
+}
+
 int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stages)
 {
     const int gx = (s->cols + pm::kTileW - 1) / pm::kTileW;
@@ -266,6 +292,12 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
         }
         tune |= Tune::kPushConsume;
         s->n_push_consumed++;
+    }
+    // plane-keyed propagation for the later half-sweeps (any skip rule the sweep would apply is applied there)
+    if (!push_now && s->group_ok && qualifies && half_sweep >= s->group_from && !(tune & Tune::kNoSkip)) {
+        const int rc = launch_group(s, colour, (tune & Tune::kHistorySkip) != 0, tune);
+        if (rc) return rc;
+        tune |= Tune::kPushConsume;
     }
     s->push_valid = -1;  // the planes of `colour` are about to change
     const bool push_next = s->push_ok && qualifies && half_sweep + 1 < s->push_launches &&
@@ -660,8 +692,16 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     // colour (config C geometry): 6 (4: -1.3 %, 8: -0.7 %, 16: -7 %)
     s->push_launches = s->ch == 4 ? 6 : s->box == 15 ? 4 : s->box == 25 ? 3 : 2;
     if (const char *t = getenv("GIPUMA_HIP_PUSH_LAUNCHES")) s->push_launches = atoi(t);  // A/B runs: 0 = never
+    // plane-keyed propagation (pm_group.h) after the pushed half-sweeps: box 11 / 15, gray
+    s->group_ok = s->push_ok && s->ch == 1 && (s->box == 11 || s->box == 15);
     if (s->push_launches <= 0) s->push_ok = false;
-    if (s->push_ok) {
+    // OPT-IN (GIPUMA_HIP_GROUP_FROM=<first half-sweep>): measured on config C it halves the propagation stage's
+    // instructions (6.4e8 instead of 13.5e8 per late half-sweep) but runs them at a third of the fused kernel's issue
+    // rate -- short phases between ~100 barriers per workgroup --: 4.07 ms against 3.31 ms per late half-sweep
+    s->group_from = -1;
+    if (const char *t = getenv("GIPUMA_HIP_GROUP_FROM")) s->group_from = atoi(t);  // < 0 = never
+    if (s->group_from < 0) s->group_ok = false;
+    if (s->push_ok || s->group_ok) {
         CREATE_OK(hipMalloc(&s->push_cost, 8 * np * sizeof(float)));
         hp.push_cost = s->push_cost;
     }
