@@ -406,26 +406,32 @@ def main():
             except Exception:  # noqa: BLE001
                 pd = None
         # imported counters are flagged when they were not collected with the library this run loads
+        # (by the hash of the kernel sources, which survives a rebuild; the binary's hash rides along)
         try:
+            import glob
             import hashlib
             lib_now = hashlib.sha256(open(os.environ.get("GIPUMA_HIP_LIB") or abi.LIB_PATH, "rb").read()).hexdigest()[:16]
+            src_now = hashlib.sha256(b"".join(open(f, "rb").read() for f in sorted(
+                glob.glob(os.path.join(ROOT, "gipuma_amd", "csrc", "*.h*"))))).hexdigest()[:16]
         except Exception:  # noqa: BLE001
-            lib_now = None
+            lib_now = src_now = None
 
         def stale(j):
-            return None if not j else (j.get("_lib_sha16") != lib_now)
+            return None if not j else (j.get("_src_sha16") != src_now)
         traffic = None
         if pd and "hbm_read_bytes_per_launch_x2corr" in pd:
             traffic = (pd["hbm_read_bytes_per_launch_x2corr"] + pd["hbm_write_bytes_per_launch"]) / 1e9
         imported_dom = {"measured_in_this_run": False, "file": "profiles/pmc_latest_sweep_kernel.json",
                         "collected_at_kernel_ms": pd.get("_kernel_ms_profiled_mean") if pd else None,
                         "collected_with_lib_sha16": pd.get("_lib_sha16") if pd else None, "commit": pd.get("_commit") if pd else None,
-                        "lib_sha16_of_this_run": lib_now, "stale": stale(pd),
+                        "collected_with_src_sha16": pd.get("_src_sha16") if pd else None,
+                        "lib_sha16_of_this_run": lib_now, "src_sha16_of_this_run": src_now, "stale": stale(pd),
                         "note": pd.get("_note") if pd else None}
         imported = {"measured_in_this_run": False, "file": "profiles/pmc_latest.json",
                     "collected_at_kernel_ms": pj.get("_kernel_ms_profiled_mean") if pj else None,
                     "collected_with_lib_sha16": pj.get("_lib_sha16") if pj else None, "commit": pj.get("_commit") if pj else None,
-                    "lib_sha16_of_this_run": lib_now, "stale": stale(pj),
+                    "collected_with_src_sha16": pj.get("_src_sha16") if pj else None,
+                    "lib_sha16_of_this_run": lib_now, "src_sha16_of_this_run": src_now, "stale": stale(pj),
                     "note": pj.get("_note") if pj else None}
         box = gs.params.box_hsize
         S = ((box - 1) // 2 + 1) ** 2
