@@ -1121,5 +1121,5 @@ def test_hip_against_reference_golden_fixture(hip, fixture):
     d_rel = rel(g["final_norm4"][..., 3], f4[..., 3])
     n_err = np.abs(g["final_norm4"][..., :3] - f4[..., :3]).max(-1)
     ok = (d_rel < 1e-4) & (n_err < 1e-3)
-    assert ok.mean() > 0.995
+    assert ok.mean() >= 0.9995  # measured: 1.0 on both fixtures (every pixel inside the tolerance)
     assert costs_close(g["final_cost"][ok], fc[ok])
