@@ -933,3 +933,13 @@ int gipuma_oracle_num_threads(void)
     return 1;
 #endif
 }
+
+/* threads of the OpenMP loops from now on (the test harness passes the cores the cgroup grants) */
+void gipuma_oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

@@ -44,6 +44,7 @@ int gipuma_oracle_time(const gipuma_hip_desc *d, int n_iter_timed, double *sec_i
 int gipuma_oracle_time_band(const gipuma_hip_desc *d, int y0, int y1, double *sec_init_band,
                             double *sec_iter_band);
 int gipuma_oracle_num_threads(void);
+void gipuma_oracle_set_threads(int n);
 
 /* ---- unit pieces, exported for the known-answer tests ---- */
 float gipuma_oracle_exp(float x);

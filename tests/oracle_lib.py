@@ -20,12 +20,28 @@ def build():
                           stdout=subprocess.DEVNULL)
 
 
+def _granted_cores():
+    """cores this process may really use: the affinity mask cut down by the cgroup's CPU quota (the GPU box shows
+    256 hardware threads and grants the time of 16; 256 OpenMP threads on that quota spend it being throttled)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per) + 0.5)))
+    except Exception:  # noqa: BLE001
+        pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(ORACLE_SO):
             build()
         L = C.CDLL(ORACLE_SO)
+        if "OMP_NUM_THREADS" not in os.environ:  # (libgomp may be loaded already: set it through the library)
+            L.gipuma_oracle_set_threads.argtypes = [C.c_int]
+            L.gipuma_oracle_set_threads(_granted_cores())
         D = C.POINTER(abi.Desc)
         L.gipuma_oracle_run.argtypes = [D, _FP, _FP, C.c_int]
         L.gipuma_oracle_init_planes.argtypes = [D, _FP, _FP]

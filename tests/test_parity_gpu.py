@@ -620,7 +620,7 @@ def test_properties_at_full_size(hip):
     """config C size (1600x1200, 10 views), where the oracle is too slow: size-independent
     properties instead -- determinism, plane/depth consistency, hemisphere, cost bounds, and the
     cost plane equals a fresh evaluation of the final planes."""
-    gs, info = synth.build_problem("C", iterations=1)
+    gs, info = full_problem("C", iterations=1)
     with Session(gs) as s:
         s.init_planes()
         s.sweep(0, abi.BLACK)
@@ -644,6 +644,24 @@ def test_properties_at_full_size(hip):
         pl = np.ascontiguousarray(n4[y, x])
         want = lib().gipuma_oracle_multiview_cost(C.byref(gs.desc), x, y, fptr(pl))
         assert np.float32(want).view(np.uint32) == c[y, x].view(np.uint32), (x, y, want, c[y, x])
+
+
+_FULL = {}
+
+
+def full_problem(cfg, colour=False, iterations=None):
+    """the BASELINE-size synthetic problems are rendered once per test session (7-25 s each) and shared; a test that
+    wants fewer iterations gets a GlobalState over the same frames and cameras with its own parameter block"""
+    key = (cfg, colour)
+    if key not in _FULL:
+        _FULL[key] = synth.build_problem(cfg, colour=colour)
+    gs, info = _FULL[key]
+    if iterations is None or iterations == gs.params.iterations:
+        return gs, info
+    from gipuma_amd.problem import AlgorithmParameters, GlobalState
+    ap = AlgorithmParameters(**{k: getattr(gs.params, k) for k in vars(gs.params)})
+    ap.iterations = iterations
+    return GlobalState(gs.images, gs.cameras, gs.selected, ap, seed=gs.desc.seed), info
 
 
 def _teacher_forced_bands(gs, bands, what):
@@ -701,7 +719,7 @@ def test_config_c_every_launch_at_full_size(hip):
     all 16 half-sweep launches of the shipped schedule (column-per-lane kernel, fused kernel with
     early termination, history rule) checked exactly on three bands of rows -- top border, interior
     across a tile-band boundary, bottom border (scripts/dtu_fast.sh:9-21)."""
-    gs, info = synth.build_problem("C")
+    gs, info = full_problem("C")
     n = _teacher_forced_bands(gs, [(0, 12), (592, 612), (1190, 1200)], "config C")
     print("config C: %d pixel updates compared exactly" % n)
 
@@ -726,7 +744,7 @@ def test_config_c_whole_frame_against_the_oracle(hip):
     30.7 M pixel updates -- against the oracle's own free-running solve, every pixel of the final maps
     and costs bit for bit; and the shipped schedule against the exhaustive one on the same frame."""
     import time
-    gs, info = synth.build_problem("C")
+    gs, info = full_problem("C")
     a = _default_equals_exhaustive(gs, "config C")
     t0 = time.time()
     o_n4, o_c = OracleState(gs).run()
@@ -739,9 +757,9 @@ def test_config_d_and_colour_default_equals_exhaustive(hip):
     """config D (20 views, box 25) and the colour variant of config C's geometry: the shipped schedule
     against the exhaustive one on the whole frame (the exhaustive kernel itself is teacher-forced against
     the oracle in test_exhaustive_schedule_every_launch_at_full_size)"""
-    gs, info = synth.build_problem("D", iterations=3)
+    gs, info = full_problem("D", iterations=3)
     _default_equals_exhaustive(gs, "config D")
-    gs, info = synth.build_problem("C", colour=True, iterations=3)
+    gs, info = full_problem("C", colour=True, iterations=3)
     _default_equals_exhaustive(gs, "colour config C")
 
 
@@ -750,7 +768,7 @@ def test_config_d_and_colour_default_equals_exhaustive(hip):
 def test_exhaustive_schedule_every_launch_at_full_size(hip, cfg, kw, bands):
     """the exhaustive schedule (what the whole-frame comparisons above are made against) teacher-forced
     against the oracle on bands of rows, every launch"""
-    gs, info = synth.build_problem(cfg, **kw)
+    gs, info = full_problem(cfg, **kw)
     n = _with_env({"GIPUMA_HIP_TUNE": EXHAUSTIVE_TUNE}, lambda: _teacher_forced_bands(gs, bands, "exhaustive " + cfg))
     print("exhaustive %s %r: %d pixel updates compared exactly" % (cfg, kw, n))
 
@@ -758,8 +776,8 @@ def test_exhaustive_schedule_every_launch_at_full_size(hip, cfg, kw, bands):
 def test_config_d_every_launch_at_full_size(hip):
     """BASELINE config D (1600x1200, 20 source views, box 25, 8 iterations; scripts/dtu_accurate.sh):
     every launch checked exactly on two bands (the oracle costs 5x config C per pixel here)."""
-    gs, info = synth.build_problem("D")
-    n = _teacher_forced_bands(gs, [(0, 6), (154, 166), (600, 610), (1194, 1200)], "config D")
+    gs, info = full_problem("D")
+    n = _teacher_forced_bands(gs, [(0, 6), (156, 164), (602, 610), (1194, 1200)], "config D")
     print("config D: %d pixel updates compared exactly" % n)
 
 
@@ -791,8 +809,8 @@ def test_colour_every_launch_at_full_size(hip):
     --colour runs it, four iterations: every one of the 8 half-sweep launches -- six of them fed by
     pm::push_kernel_c4, then the plain colour sweep kernel with the history rule -- checked exactly on
     two bands of rows (top border, interior across a tile boundary)"""
-    gs, info = synth.build_problem("C", colour=True, iterations=4)
-    n = _teacher_forced_bands(gs, [(0, 5), (604, 612)], "colour config C")
+    gs, info = full_problem("C", colour=True, iterations=4)
+    n = _teacher_forced_bands(gs, [(0, 4), (606, 612)], "colour config C")
     print("colour config C: %d pixel updates compared exactly" % n)
 
 
