@@ -57,6 +57,12 @@ def rq3(M):
 def decompose_projection(P):
     """K, R, C (camera centre, 3-vector) of P = K [R | -R C]."""
     P = np.asarray(P, dtype=np.float64)
+    # a projection matrix is defined up to scale, including its sign: with det(M) < 0 the RQ step would have to
+    # return a reflection or a negative K[2][2] (what OpenCV's decomposeProjectionMatrix does,
+    # cameraGeometryUtils.h:252: it fixes two diagonal signs only); both front-ends decompose -P instead and
+    # get the camera of +P (the same deliberate deviation as gipuma_host.cpp decompose(), DESIGN.md 8)
+    if np.linalg.det(P[:, :3]) < 0:
+        P = -P
     K, R = rq3(P[:, :3])
     # centre: right null vector of P (cameraGeometryUtils.h:259-261 divides T by T[3])
     _, _, vt = np.linalg.svd(P)

@@ -1,0 +1,828 @@
+// pm_cost.h -- patch costs: pmCost_shared / pmCostComputation_shared (gipuma.cu:585-680, 223-277) as the generic
+// loop, the hand-pipelined loop for packed gray planes and its column range variant, the colour loop, the
+// column-per-lane evaluation; pmCostMultiview_cu (:720-806) with the register combiner and the exact early
+// termination.  Part of the device code of the PatchMatch path (pm_device.h).
+#pragma once
+#include "pm_core.h"
+
+namespace pm {
+
+// Patch cost of one source view: pmCost_shared + pmCostComputation_shared,
+// gipuma.cu:585-680 and :223-277.  `tp0` points at the pixel's own texel inside the LDS tile.
+// Is every warped-point denominator of the window safely inside the range where rcp_newton is
+// exact?  Z(i,j) = fmaf(H7, qy, fmaf(H6, qx, H8)) is monotone in qx and in qy (one rounding each),
+// so all window values lie between the four corner values.
+__device__ __forceinline__ bool window_z_safe(const float *H, float qx0, float qx1, float qy0, float qy1)
+{
+    const float z00 = __builtin_fmaf(H[7], qy0, __builtin_fmaf(H[6], qx0, H[8]));
+    const float z01 = __builtin_fmaf(H[7], qy1, __builtin_fmaf(H[6], qx0, H[8]));
+    const float z10 = __builtin_fmaf(H[7], qy0, __builtin_fmaf(H[6], qx1, H[8]));
+    const float z11 = __builtin_fmaf(H[7], qy1, __builtin_fmaf(H[6], qx1, H[8]));
+    const float lo = __builtin_fminf(__builtin_fminf(z00, z01), __builtin_fminf(z10, z11));
+    const float hi = __builtin_fmaxf(__builtin_fmaxf(z00, z01), __builtin_fmaxf(z10, z11));
+    // same sign, and magnitudes in [2^-100, 2^100] (NaN fails every comparison)
+    return (lo >= 0x1p-100f && hi <= 0x1p100f) || (hi <= -0x1p-100f && lo >= -0x1p100f);
+}
+
+// Exponent trick used by the U8 loop: for an integer n in [0, 2^21), the float 2^21 + n has ulp 1/4,
+// so its bit pattern is 0x4a000000 + 4n -- a byte offset of 4-byte entry n, produced by a full-rate
+// fp32 add instead of cvt + shift (conversions, integer min/max and shifts issue at ~60 % of the
+// fp32 rate on gfx950, scripts/ubench/valu_rates.hip).  The constant part moves into the base.
+constexpr uint32_t kMagicBits = 0x4a000000u;  // bits of 2^21
+constexpr float kMagicF = 0x1p21f;
+constexpr int kMagicMaxWords = (1 << 21) - 8;
+
+template <int BOX, bool U8, bool INTERIOR, bool FAST, bool MAGIC>
+__device__ __forceinline__ float view_cost_loop(const Problem *__restrict__ P, const ViewCam &vc,
+                                                const float *__restrict__ H, const float *__restrict__ tp0,
+                                                int tw, const float *__restrict__ lut, int px, int py,
+                                                const Win<BOX> &win)
+{
+    const gptr_f32 img = (gptr_f32)vc.img;
+    const uint32_t *__restrict__ packed = vc.packed;
+    const uint32_t pw = (uint32_t)P->pw;
+    const uint32_t xmax = (uint32_t)(P->cols + 2), ymax = (uint32_t)(P->rows + 2);
+    const int rows = P->rows, cols = P->cols, pitch = P->pitch;
+    const float colsf = (float)cols, rowsf = (float)rows;
+    const float alpha = P->alpha, oma = 1.f - P->alpha;
+    const float tau_color = P->tau_color, tau_gradient = P->tau_gradient, gamma = P->gamma;
+    const float centre = tp0[0];
+    const int hr = win.hrad(), vr = win.vrad();
+    // MAGIC: offset of window (Xc, Yc), Xc in [-2, cols], Yc in [-2, rows] (clamped floor
+    // coordinates; entry (Yc+2)*pw + Xc+2 of V), as the bits of fma(Yc, pw, Xc + magic_c)
+    const float pwf = (float)P->pw;
+    const float magic_c = kMagicF + (float)(2 * P->pw + 2);
+    const gptr_bytes magic_base = (gptr_bytes)((uintptr_t)packed - (uintptr_t)kMagicBits);
+    const char *lut_magic = (const char *)lut - kMagicBits;
+    float cost = 0.0f;
+    // (float)(px + i) == (float)px + (float)i exactly (small integers): full-rate adds, no cvt
+    float qx = (float)(px - hr);
+    for (int i = -hr; i <= hr; i += 2, qx += 2.0f) {
+        const float X0 = __builtin_fmaf(H[0], qx, H[2]);
+        const float Y0 = __builtin_fmaf(H[3], qx, H[5]);
+        const float Z0 = __builtin_fmaf(H[6], qx, H[8]);
+        float qy = (float)(py - vr);
+#pragma unroll unroll_j<BOX>()
+        for (int j = -vr; j <= vr; j += 2, qy += 2.0f) {
+            // one ds_read_b128: {I(q), gx1(q), gy1(q)} of the reference tile
+            const float4 t4 = *reinterpret_cast<const float4 *>(tp0 + 4 * (j * tw + i));
+            // weight_cu, gipuma.cu:186-193
+            const float leftValue = t4.x;
+            const float colorDis = __builtin_fabsf(leftValue - centre);
+            float w;
+            if (U8)  // images are integer valued in [0,255]: 256 possible weights
+                w = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
+            else
+                w = exp_model(-colorDis / gamma);
+            // getCorrespondingPoint_cu, gipuma.cu:207-217
+            const float X = __builtin_fmaf(H[1], qy, X0);
+            const float Y = __builtin_fmaf(H[4], qy, Y0);
+            const float Z = __builtin_fmaf(H[7], qy, Z0);
+            const float rz = recip<FAST>(Z);
+            const float sx = X * rz, sy = Y * rz;
+            // M1: five bilinear taps sharing one 4x4 texel window (gipuma.cu:251-253)
+            const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
+            const float a = sx - fx0, b = sy - fy0;
+            Taps tp5;
+            if (U8 && MAGIC) {  // U8 mode: the whole window is one 16-byte load
+                // v_med3_f32 returns min3 when an input is NaN: NaN -> -2, like the saturating cvt
+                const float Xc = __builtin_amdgcn_fmed3f(fx0, -2.0f, colsf);
+                const float Yc = __builtin_amdgcn_fmed3f(fy0, -2.0f, rowsf);
+                const uint32_t off = __float_as_uint(__builtin_fmaf(Yc, pwf, Xc + magic_c));
+                const u32x4_a4 wv = *(gptr_u32x4)(magic_base + off);
+                tp5 = taps_u8(a, b, wv.x, wv.y, wv.z, wv.w);
+            } else if (U8) {
+                // X = clamp(floor(sx), -2, cols) + 2, same for Y: the +2 is exact wherever the
+                // clamp does not saturate
+                const uint32_t X = min(cvt_u32_sat(fx0 + 2.0f), xmax);
+                const uint32_t Y = min(cvt_u32_sat(fy0 + 2.0f), ymax);
+                const uint32_t off = (Y * pw + X) << 2;
+                const u32x4_a4 wv = *(gptr_u32x4)((gptr_bytes)packed + off);
+                tp5 = taps_u8(a, b, wv.x, wv.y, wv.z, wv.w);
+            } else {
+                // float planes: keep the float->int conversion defined for huge / NaN coordinates
+                const int ix = (int)__builtin_fminf(__builtin_fmaxf(fx0, -2.0f), colsf);
+                const int iy = (int)__builtin_fminf(__builtin_fmaxf(fy0, -2.0f), rowsf);
+                const bool inside = ix >= 1 && ix <= cols - 3 && iy >= 1 && iy <= rows - 3;
+                if (INTERIOR && __all(inside)) {
+                    const gptr_f32 s = img + (iy * pitch + ix);
+                    tp5 = taps12(a, b, s[-pitch], s[-pitch + 1], s[-1], s[0], s[1], s[2], s[pitch - 1], s[pitch],
+                                 s[pitch + 1], s[pitch + 2], s[2 * pitch], s[2 * pitch + 1]);
+                } else {
+                    const int c0 = clampi(ix - 1, 0, cols - 1), c1 = clampi(ix, 0, cols - 1);
+                    const int c2 = clampi(ix + 1, 0, cols - 1), c3 = clampi(ix + 2, 0, cols - 1);
+                    const int r0 = clampi(iy - 1, 0, rows - 1) * pitch, r1 = clampi(iy, 0, rows - 1) * pitch;
+                    const int r2 = clampi(iy + 1, 0, rows - 1) * pitch, r3 = clampi(iy + 2, 0, rows - 1) * pitch;
+                    tp5 = taps12(a, b, img[r0 + c1], img[r0 + c2], img[r1 + c0], img[r1 + c1], img[r1 + c2],
+                                 img[r1 + c3], img[r2 + c0], img[r2 + c1], img[r2 + c2], img[r2 + c3],
+                                 img[r3 + c1], img[r3 + c2]);
+                }
+            }
+            const float sc = tp5.sc, gx2 = tp5.gx2, gy2 = tp5.gy2;
+            // pmCostComputation_shared, gipuma.cu:251-274
+            const float colDiff = t4.w - sc;  // t4.w == t4.x == I(q); |.| taken in the min below
+            const float gx1 = t4.y;
+            const float gy1 = t4.z;
+            const float gradX = gx1 - gx2;
+            const float gradY = gy1 - gy2;
+            const float gradDis = min_nc((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
+            const float colDis = min_abs_nc(colDiff, tau_color);
+            const float dis = __builtin_fmaf(alpha, gradDis, oma * colDis);
+            cost = __builtin_fmaf(w, dis, cost);
+        }
+    }
+    return cost;
+}
+
+// The same loop for the shipped case (square compile-time box, gray U8 planes with float-encoded
+// offsets), software-pipelined by hand: the window of sample s+2 is requested before sample s is
+// reduced, across column boundaries, so that each wavefront keeps two 16-byte loads in flight
+// instead of waiting for the one it has just issued.  Per sample the arithmetic and the order of
+// the cost accumulation are those of view_cost_loop -- the results are bit-identical.  (The two
+// requests past the last sample fetch clamped, valid addresses and are dropped.)
+struct WinReq {
+    float a, b;
+    u32x4_a4 w;
+};
+template <int BOX, bool FAST, bool ET>
+__device__ __forceinline__ float view_cost_pipe(const Problem *__restrict__ P, const ViewCam &vc,
+                                                const float *__restrict__ H, const float *__restrict__ tp0,
+                                                int tw, const float *__restrict__ lut, int px, int py, float tau,
+                                                int *cols_done = nullptr)
+{
+    static_assert(BOX > 0, "compile-time window only");
+    constexpr int R = (BOX - 1) / 2, N = R + 1;  // offsets -R, -R+2, ..., R
+    const float colsf = (float)P->cols, rowsf = (float)P->rows;
+    const float alpha = P->alpha, oma = 1.f - P->alpha;
+    const float tau_color = P->tau_color, tau_gradient = P->tau_gradient;
+    const float centre = tp0[0];
+    const float pwf = (float)P->pw;
+    const float magic_c = kMagicF + (float)(2 * P->pw + 2);
+    const gptr_bytes magic_base = (gptr_bytes)((uintptr_t)vc.packed - (uintptr_t)kMagicBits);
+    const char *lut_magic = (const char *)lut - kMagicBits;
+    const float H1 = H[1], H4 = H[4], H7 = H[7];
+
+    auto request = [&](float X0, float Y0, float Z0, float qy) -> WinReq {
+        // getCorrespondingPoint_cu, gipuma.cu:207-217
+        const float X = __builtin_fmaf(H1, qy, X0);
+        const float Y = __builtin_fmaf(H4, qy, Y0);
+        const float Z = __builtin_fmaf(H7, qy, Z0);
+        const float rz = recip<FAST>(Z);
+        const float sx = X * rz, sy = Y * rz;
+        const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
+        WinReq r;
+        r.a = sx - fx0;
+        r.b = sy - fy0;
+        const float Xc = __builtin_amdgcn_fmed3f(fx0, -2.0f, colsf);
+        const float Yc = __builtin_amdgcn_fmed3f(fy0, -2.0f, rowsf);
+        const uint32_t off = __float_as_uint(__builtin_fmaf(Yc, pwf, Xc + magic_c));
+        r.w = *(gptr_u32x4)(magic_base + off);
+        return r;
+    };
+
+    const float qy0 = (float)(py - R);
+    float qx = (float)(px - R);
+    float X0 = __builtin_fmaf(H[0], qx, H[2]);
+    float Y0 = __builtin_fmaf(H[3], qx, H[5]);
+    float Z0 = __builtin_fmaf(H[6], qx, H[8]);
+    WinReq r0 = request(X0, Y0, Z0, qy0), r1 = request(X0, Y0, Z0, qy0 + 2.0f);
+    float cost = 0.0f;
+    const float *tcol = tp0 + 4 * (-R * tw - R);  // texel (-R, -R) of the window
+    for (int c = 0; c < N; c++, tcol += 8) {
+        const float qxn = qx + 2.0f;
+        const float X0n = __builtin_fmaf(H[0], qxn, H[2]);
+        const float Y0n = __builtin_fmaf(H[3], qxn, H[5]);
+        const float Z0n = __builtin_fmaf(H[6], qxn, H[8]);
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const WinReq cur = r0;
+            r0 = r1;
+            // sample k+2 of this column, or the first two of the next one
+            if (k + 2 < N)
+                r1 = request(X0, Y0, Z0, qy0 + (float)(2 * (k + 2)));
+            else
+                r1 = request(X0n, Y0n, Z0n, qy0 + (float)(2 * (k + 2 - N)));
+            __builtin_amdgcn_sched_barrier(0);  // keep the request ahead of this sample's reduction
+            // one ds_read_b128: {I(q), gx1(q), gy1(q), I(q)} of the reference tile
+            const float4 t4 = *reinterpret_cast<const float4 *>(tcol + 8 * k * tw);
+            // weight_cu, gipuma.cu:186-193: 256 possible weights
+            const float colorDis = __builtin_fabsf(t4.x - centre);
+            const float w = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
+            const Taps tp5 = taps_u8(cur.a, cur.b, cur.w.x, cur.w.y, cur.w.z, cur.w.w);
+            // pmCostComputation_shared, gipuma.cu:251-274
+            const float colDiff = t4.w - tp5.sc;
+            const float gradX = t4.y - tp5.gx2;
+            const float gradY = t4.z - tp5.gy2;
+            const float gradDis = min_nc((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
+            const float colDis = min_abs_nc(colDiff, tau_color);
+            const float dis = __builtin_fmaf(alpha, gradDis, oma * colDis);
+            cost = __builtin_fmaf(w, dis, cost);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        qx = qxn;
+        X0 = X0n;
+        Y0 = Y0n;
+        Z0 = Z0n;
+        // early termination (ET): the partial sum only grows (w, dis >= 0, fmaf rounds monotonically),
+        // so once every lane of the wavefront has reached its bound the rest of the view cannot
+        // matter (see multiview_cost); the two windows already requested are dropped
+        if (ET && __all(cost >= tau)) {
+            if (cols_done) *cols_done -= N - 1 - c;  // (wave-uniform bookkeeping of the probe workgroups)
+            break;
+        }
+    }
+    if (ET && cols_done) *cols_done += N + 1;  // (+1: homography and set-up of the view, paid again by a redo)
+    return cost;
+}
+
+// view_cost_pipe restricted to the window columns [c0, c1), continuing from the partial sum `cost`
+// (the value view_cost_pipe holds after column c0 - 1): the same samples, the same instruction
+// sequence per sample, the same accumulation order.  `magic_base` may differ per lane (the lanes
+// of a wavefront may work on different source views, see refine_two_phase).  The wavefront leaves
+// after the first column at which every lane has reached its `tau`; *cols_run += columns evaluated.
+template <int BOX, bool FAST>
+__device__ __forceinline__ float view_cost_pipe_range(const Problem *__restrict__ P, gptr_bytes magic_base,
+                                                      const float *__restrict__ H, const float *__restrict__ tp0,
+                                                      int tw, const float *__restrict__ lut, int px, int py, int c0,
+                                                      int c1, float cost, float tau, int *cols_run)
+{
+    static_assert(BOX > 0, "compile-time window only");
+    constexpr int R = (BOX - 1) / 2, N = R + 1;
+    const float colsf = (float)P->cols, rowsf = (float)P->rows;
+    const float alpha = P->alpha, oma = 1.f - P->alpha;
+    const float tau_color = P->tau_color, tau_gradient = P->tau_gradient;
+    const float centre = tp0[0];
+    const float pwf = (float)P->pw;
+    const float magic_c = kMagicF + (float)(2 * P->pw + 2);
+    const char *lut_magic = (const char *)lut - kMagicBits;
+    const float H1 = H[1], H4 = H[4], H7 = H[7];
+
+    auto request = [&](float X0, float Y0, float Z0, float qy) -> WinReq {
+        const float X = __builtin_fmaf(H1, qy, X0);
+        const float Y = __builtin_fmaf(H4, qy, Y0);
+        const float Z = __builtin_fmaf(H7, qy, Z0);
+        const float rz = recip<FAST>(Z);
+        const float sx = X * rz, sy = Y * rz;
+        const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
+        WinReq r;
+        r.a = sx - fx0;
+        r.b = sy - fy0;
+        const float Xc = __builtin_amdgcn_fmed3f(fx0, -2.0f, colsf);
+        const float Yc = __builtin_amdgcn_fmed3f(fy0, -2.0f, rowsf);
+        const uint32_t off = __float_as_uint(__builtin_fmaf(Yc, pwf, Xc + magic_c));
+        r.w = *(gptr_u32x4)(magic_base + off);
+        return r;
+    };
+
+    const float qy0 = (float)(py - R);
+    float qx = (float)(px - R + 2 * c0);  // (exact: small integers)
+    float X0 = __builtin_fmaf(H[0], qx, H[2]);
+    float Y0 = __builtin_fmaf(H[3], qx, H[5]);
+    float Z0 = __builtin_fmaf(H[6], qx, H[8]);
+    WinReq r0 = request(X0, Y0, Z0, qy0), r1 = request(X0, Y0, Z0, qy0 + 2.0f);
+    const float *tcol = tp0 + 4 * (-R * tw - R) + 8 * c0;
+    int c = c0;
+    for (; c < c1; c++, tcol += 8) {
+        const float qxn = qx + 2.0f;
+        const float X0n = __builtin_fmaf(H[0], qxn, H[2]);
+        const float Y0n = __builtin_fmaf(H[3], qxn, H[5]);
+        const float Z0n = __builtin_fmaf(H[6], qxn, H[8]);
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const WinReq cur = r0;
+            r0 = r1;
+            if (k + 2 < N)
+                r1 = request(X0, Y0, Z0, qy0 + (float)(2 * (k + 2)));
+            else
+                r1 = request(X0n, Y0n, Z0n, qy0 + (float)(2 * (k + 2 - N)));
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 t4 = *reinterpret_cast<const float4 *>(tcol + 8 * k * tw);
+            const float colorDis = __builtin_fabsf(t4.x - centre);
+            const float w = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
+            const Taps tp5 = taps_u8(cur.a, cur.b, cur.w.x, cur.w.y, cur.w.z, cur.w.w);
+            const float colDiff = t4.w - tp5.sc;
+            const float gradX = t4.y - tp5.gx2;
+            const float gradY = t4.z - tp5.gy2;
+            const float gradDis = min_nc((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
+            const float colDis = min_abs_nc(colDiff, tau_color);
+            const float dis = __builtin_fmaf(alpha, gradDis, oma * colDis);
+            cost = __builtin_fmaf(w, dis, cost);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        qx = qxn;
+        X0 = X0n;
+        Y0 = Y0n;
+        Z0 = Z0n;
+        if (__all(cost >= tau)) {
+            c++;
+            break;
+        }
+    }
+    if (cols_run) *cols_run += c - c0;
+    return cost;
+}
+
+template <int BOX, bool U8, bool INTERIOR, bool ET = false>
+__device__ __forceinline__ float view_cost(const Problem *__restrict__ P, const ViewCam &vc,
+                                           const float *__restrict__ tp0, int tw,
+                                           const float *__restrict__ lut, int px, int py, float4 pl,
+                                           const Win<BOX> &win, float tau = 0.0f, int *cols_done = nullptr)
+{
+    float H[9];
+    homography(P->rc.K_inv, vc, pl, H);
+    const int hr = win.hrad(), vr = win.vrad();
+    const bool safe = window_z_safe(H, (float)(px - hr), (float)(px + hr), (float)(py - vr), (float)(py + vr));
+    if constexpr (U8) {
+        if (P->magic_addr) {
+            if constexpr (BOX > 0) {
+                if (__all(safe)) return view_cost_pipe<BOX, true, ET>(P, vc, H, tp0, tw, lut, px, py, tau, cols_done);
+                return view_cost_pipe<BOX, false, ET>(P, vc, H, tp0, tw, lut, px, py, tau, cols_done);
+            } else {
+                if (__all(safe))
+                    return view_cost_loop<BOX, U8, INTERIOR, true, true>(P, vc, H, tp0, tw, lut, px, py, win);
+                return view_cost_loop<BOX, U8, INTERIOR, false, true>(P, vc, H, tp0, tw, lut, px, py, win);
+            }
+        }
+    }
+    if (__all(safe)) return view_cost_loop<BOX, U8, INTERIOR, true, false>(P, vc, H, tp0, tw, lut, px, py, win);
+    return view_cost_loop<BOX, U8, INTERIOR, false, false>(P, vc, H, tp0, tw, lut, px, py, win);
+}
+
+// The same patch cost instantiated for T = float4 (-color_processing, gipuma.cu:1965-1968): every
+// image difference is taken per channel and reduced with l1_norm(float4) = mean |.| of x, y, z
+// (gipuma.cu:174-179; the float4 operators zero .w, vector_operations.h:9-14).  `tp0` points at the
+// lane's own texel in a float4 LDS tile.  U8: weight table indexed by the integer
+// |dB|+|dG|+|dR| (766 values), three 16-byte loads for the 4x4x3 window.
+__device__ __forceinline__ float l1_3(float x, float y, float z)
+{
+    return (__builtin_fabsf(x) + __builtin_fabsf(y) + __builtin_fabsf(z)) * 0.3333333f;
+}
+
+template <int BOX, bool U8, bool FAST, bool ET = false>
+__device__ __forceinline__ float view_cost_c4_loop(const Problem *__restrict__ P, const ViewCam &vc,
+                                                   const float *__restrict__ H, const float *__restrict__ tp0,
+                                                   int tw, const float *__restrict__ lut, int px, int py,
+                                                   const Win<BOX> &win, float tau = 0.0f, int c0 = 0, int c1 = 1 << 20,
+                                                   float cost0 = 0.0f, int *cols_run = nullptr)
+{
+    // (c0, c1, cost0: window columns [c0, c1) only, continuing from the partial sum cost0 -- see
+    //  view_cost_pipe_range / refine_two_phase)
+    const gptr_f32 img = (gptr_f32)vc.img;
+    const uint32_t *__restrict__ packed = vc.packed;
+    const uint32_t pw = (uint32_t)P->pw;
+    const uint32_t xmax = (uint32_t)(P->cols + 2), ymax = (uint32_t)(P->rows + 2);
+    const int rows = P->rows, cols = P->cols, pitch = P->pitch;
+    const float colsf = (float)cols, rowsf = (float)rows;
+    const float alpha = P->alpha, oma = 1.f - P->alpha;
+    const float tau_color = P->tau_color, tau_gradient = P->tau_gradient, gamma = P->gamma;
+    const float4 centre = *reinterpret_cast<const float4 *>(tp0);
+    const int hr = win.hrad(), vr = win.vrad();
+    float cost = cost0;
+    float qx = (float)(px - hr + 2 * c0);
+    int col = c0;
+    for (int i = -hr + 2 * c0; i <= hr && col < c1; i += 2, qx += 2.0f) {
+        const float X0 = __builtin_fmaf(H[0], qx, H[2]);
+        const float Y0 = __builtin_fmaf(H[3], qx, H[5]);
+        const float Z0 = __builtin_fmaf(H[6], qx, H[8]);
+        float qy = (float)(py - vr);
+        for (int j = -vr; j <= vr; j += 2, qy += 2.0f) {
+            const float *tp = tp0 + 4 * (j * tw + i);
+            const float4 lv = *reinterpret_cast<const float4 *>(tp);
+            float w;
+            if (U8) {
+                const float S = __builtin_fabsf(lv.x - centre.x) + __builtin_fabsf(lv.y - centre.y) +
+                                __builtin_fabsf(lv.z - centre.z);  // exact integer 0..765
+                w = lut[(int)S];
+            } else {
+                w = exp_model(-l1_3(lv.x - centre.x, lv.y - centre.y, lv.z - centre.z) / gamma);
+            }
+            const float X = __builtin_fmaf(H[1], qy, X0);
+            const float Y = __builtin_fmaf(H[4], qy, Y0);
+            const float Z = __builtin_fmaf(H[7], qy, Z0);
+            const float rz = recip<FAST>(Z);
+            const float sx = X * rz, sy = Y * rz;
+            const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
+            const float a = sx - fx0, b = sy - fy0;
+            Taps t[3];
+            if (U8) {
+                const uint32_t Xw = min(cvt_u32_sat(fx0 + 2.0f), xmax);
+                const uint32_t Yw = min(cvt_u32_sat(fy0 + 2.0f), ymax);
+                const uint32_t off = (Yw * pw + Xw) * 12u;
+                const gptr_bytes base = (gptr_bytes)packed + off;
+                const u32x4_a4 q0 = *(gptr_u32x4)(base), q1 = *(gptr_u32x4)(base + 16), q2 = *(gptr_u32x4)(base + 32);
+                // word 3k+c = column k, channel c
+                t[0] = taps_u8(a, b, q0.x, q0.w, q1.z, q2.y);
+                t[1] = taps_u8(a, b, q0.y, q1.x, q1.w, q2.z);
+                t[2] = taps_u8(a, b, q0.z, q1.y, q2.x, q2.w);
+            } else {
+                const int ix = (int)__builtin_fminf(__builtin_fmaxf(fx0, -2.0f), colsf);
+                const int iy = (int)__builtin_fminf(__builtin_fmaxf(fy0, -2.0f), rowsf);
+                const int c0 = 4 * clampi(ix - 1, 0, cols - 1), c1 = 4 * clampi(ix, 0, cols - 1);
+                const int c2 = 4 * clampi(ix + 1, 0, cols - 1), c3 = 4 * clampi(ix + 2, 0, cols - 1);
+                const int r0 = clampi(iy - 1, 0, rows - 1) * pitch, r1 = clampi(iy, 0, rows - 1) * pitch;
+                const int r2 = clampi(iy + 1, 0, rows - 1) * pitch, r3 = clampi(iy + 2, 0, rows - 1) * pitch;
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+                    t[c] = taps12(a, b, img[r0 + c1 + c], img[r0 + c2 + c], img[r1 + c0 + c], img[r1 + c1 + c],
+                                  img[r1 + c2 + c], img[r1 + c3 + c], img[r2 + c0 + c], img[r2 + c1 + c],
+                                  img[r2 + c2 + c], img[r2 + c3 + c], img[r3 + c1 + c], img[r3 + c2 + c]);
+            }
+            const float4 up = *reinterpret_cast<const float4 *>(tp - 4 * tw);
+            const float4 down = *reinterpret_cast<const float4 *>(tp + 4 * tw);
+            const float4 left = *reinterpret_cast<const float4 *>(tp - 4);
+            const float4 right = *reinterpret_cast<const float4 *>(tp + 4);
+            const float colDiff = l1_3(lv.x - t[0].sc, lv.y - t[1].sc, lv.z - t[2].sc);
+            const float gX = l1_3((right.x - left.x) - t[0].gx2, (right.y - left.y) - t[1].gx2,
+                                  (right.z - left.z) - t[2].gx2);
+            const float gY = l1_3((down.x - up.x) - t[0].gy2, (down.y - up.y) - t[1].gy2,
+                                  (down.z - up.z) - t[2].gy2);
+            const float gradDis = min_nc((gX + gY) * 0.0625f, tau_gradient);
+            const float colDis = min_nc(colDiff, tau_color);
+            const float dis = __builtin_fmaf(alpha, gradDis, oma * colDis);
+            cost = __builtin_fmaf(w, dis, cost);
+        }
+        col++;
+        if (ET && __all(cost >= tau)) break;  // early termination, see multiview_cost
+    }
+    if (cols_run) *cols_run += col - c0;
+    return cost;
+}
+
+template <int BOX, bool U8, bool ET = false>
+__device__ __forceinline__ float view_cost_c4(const Problem *__restrict__ P, const ViewCam &vc,
+                                              const float *__restrict__ tp0, int tw,
+                                              const float *__restrict__ lut, int px, int py, float4 pl,
+                                              const Win<BOX> &win, float tau = 0.0f)
+{
+    float H[9];
+    homography(P->rc.K_inv, vc, pl, H);
+    const int hr = win.hrad(), vr = win.vrad();
+    const bool safe = window_z_safe(H, (float)(px - hr), (float)(px + hr), (float)(py - vr), (float)(py + vr));
+    if (__all(safe)) return view_cost_c4_loop<BOX, U8, true, ET>(P, vc, H, tp0, tw, lut, px, py, win, tau);
+    return view_cost_c4_loop<BOX, U8, false, ET>(P, vc, H, tp0, tw, lut, px, py, win, tau);
+}
+
+// Accumulation of the per-view costs of pmCostMultiview_cu (gipuma.cu:771-805), shared by the
+// pixel-per-lane and the column-per-lane evaluation.  COMBINE_REG: best-N with n_best <= 4 keeps the
+// four smallest view costs in registers (a sorting-network insert per view, same values and the
+// same ascending summation order as sort_small + the loop at :781-797); otherwise the view costs go
+// through a per-lane LDS column `cv` and the literal insertion sort.
+template <bool COMBINE_REG>
+struct ViewCombiner {
+    int numValid = 0;
+    float b0 = kMaxCost, b1 = kMaxCost, b2 = kMaxCost, b3 = kMaxCost;
+    __device__ __forceinline__ void add(float c, int v, float *cv)
+    {
+        if (c < kMaxCost)
+            numValid++;
+        else
+            c = kMaxCost;
+        if (COMBINE_REG) {
+            float t = c, lo;
+            lo = __builtin_fminf(b0, t); t = __builtin_fmaxf(b0, t); b0 = lo;
+            lo = __builtin_fminf(b1, t); t = __builtin_fmaxf(b1, t); b1 = lo;
+            lo = __builtin_fminf(b2, t); t = __builtin_fmaxf(b2, t); b2 = lo;
+            b3 = __builtin_fminf(b3, t);
+        } else {
+            // sort_small (gipuma.cu:684-693) as an online insertion into the lane's column
+            int j = v;
+            for (; j >= 1 && c < cv[(j - 1) * kThreads]; j--) cv[j * kThreads] = cv[(j - 1) * kThreads];
+            cv[j * kThreads] = c;
+        }
+    }
+    // m-th smallest value so far (m = 1..4; COMBINE_REG only): b0 <= b1 <= b2 <= b3, so it is the
+    // largest of the first m; spelled with min/max so that the registers are not spilled to an array
+    __device__ __forceinline__ float kth(int m) const
+    {
+        const float inf = __builtin_inff();
+        const float s1 = m >= 2 ? inf : -inf, s2 = m >= 3 ? inf : -inf, s3 = m >= 4 ? inf : -inf;
+        return __builtin_fmaxf(__builtin_fmaxf(b0, __builtin_fminf(b1, s1)),
+                               __builtin_fmaxf(__builtin_fminf(b2, s2), __builtin_fminf(b3, s3)));
+    }
+    __device__ __forceinline__ float finish(const Problem *__restrict__ P, int n, const float *cv) const
+    {
+        float cost = 0.0f;
+        int numConsidered = 0;
+        if (COMBINE_REG) {
+            const int numBest = min(numValid, P->n_best);
+            if (numBest > 0) cost = cost + b0;
+            if (numBest > 1) cost = cost + b1;
+            if (numBest > 2) cost = cost + b2;
+            if (numBest > 3) cost = cost + b3;
+            numConsidered = numBest;
+        } else {
+            int numBest = numValid;
+            if (P->cost_comb == 1) numBest = min(numBest, P->n_best);  // COMB_BEST_N
+            if (P->cost_comb == 3) numBest = n;                        // COMB_GOOD
+            const float costThresh = (n > 0 ? cv[0] : 0.0f) * P->good_factor;
+            for (int i = 0; i < numBest; i++) {
+                numConsidered++;
+                float c = cv[i * kThreads];
+                if (P->cost_comb == 3) c = __builtin_fminf(c, costThresh);
+                cost = cost + c;
+            }
+        }
+        cost = cost / ((float)numConsidered);
+        if (numConsidered < 1) cost = kMaxCost;
+        if (cost != cost || cost > kMaxCost || cost < 0) cost = kMaxCost;
+        return cost;
+    }
+};
+
+// pmCostMultiview_cu, gipuma.cu:720-806
+//
+// Early termination (ET; best-N with n_best <= 4 on packed gray planes, enabled by the host through
+// Problem::et_enable only when the parameters make every view cost finite and < MAXCOST, so that
+// numValid == n_sel for every plane).  Work reduction that cannot change a result:
+//   A view cost is a sum of terms w*dis >= 0 accumulated by fmaf, so its partial sums never
+//   decrease: a view stopped early leaves a LOWER BOUND l_v <= c_v.  Let m = min(n_sel, n_best),
+//   b[0..m-1] the m smallest values seen so far (exact costs and lower bounds alike) and
+//   tau = min(b[m-1], thr).  A view is abandoned -- by the whole wavefront, after a window column --
+//   once every lane's partial sum has reached its own tau.  At the end F' = mean of b[0..m-1] is a
+//   lower bound of the exact result F (the m smallest of elementwise smaller values, summed in the
+//   same order; rounding is monotone), and
+//     * if b[m-1] < thr, no abandoned view is among the m smallest: one abandoned against b[m-1] had
+//       m values at or below it already, one abandoned against thr is >= thr > b[m-1].  The m smallest
+//       are exact and every other view is >= b[m-1]: F' == F bit for bit;
+//     * else if F' >= bound (the cost the candidate must beat): F >= F', the candidate is rejected
+//       either way and its cost is never stored;
+//     * else the caller re-evaluates with thr = infinity (first case).
+//   thr = infinity leaves only the value-exact rule; Problem::et_theta scales thr = theta * bound.
+template <int BOX, bool U8, bool INTERIOR, bool COMBINE_REG, int CH, bool ET = false>
+__device__ __forceinline__ float multiview_cost(const Problem *__restrict__ P, const float *__restrict__ tp0,
+                                                int tw, const float *__restrict__ lut, float *cv, int px,
+                                                int py, float4 pl, const Win<BOX> &win, bool et_on = false,
+                                                float thr = 0.0f, float *kth_out = nullptr, int *cols_done = nullptr)
+{
+    static_assert(!ET || (COMBINE_REG && U8 && (CH == 4 || BOX > 0)), "ET: register combiner on packed 8-bit planes");
+    const int n = P->n_sel;
+    const int m = min(n, P->n_best);
+    ViewCombiner<COMBINE_REG> comb;
+    for (int v = 0; v < n; v++) {
+        float c;
+        if constexpr (CH == 4 && ET) {
+            const float tau = et_on ? __builtin_fminf(comb.kth(m), thr) : __builtin_inff();
+            c = view_cost_c4<BOX, U8, true>(P, P->view[v], tp0, tw, lut, px, py, pl, win, tau);
+        } else if constexpr (CH == 4) {
+            c = view_cost_c4<BOX, U8>(P, P->view[v], tp0, tw, lut, px, py, pl, win);
+        } else if constexpr (ET) {
+            const float tau = et_on ? __builtin_fminf(comb.kth(m), thr) : __builtin_inff();
+            c = view_cost<BOX, U8, INTERIOR, true>(P, P->view[v], tp0, tw, lut, px, py, pl, win, tau, cols_done);
+        } else {
+            c = view_cost<BOX, U8, INTERIOR>(P, P->view[v], tp0, tw, lut, px, py, pl, win);
+        }
+        comb.add(c, v, cv);
+    }
+    if constexpr (ET)
+        if (kth_out) *kth_out = comb.kth(m);
+    return comb.finish(P, n, cv);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Column-per-lane evaluation, used for the first iterations (planes still random).
+//
+// With one lane per pixel, the 64 lanes of a window load sit in 64 different cache lines as long as
+// neighbouring pixels hold unrelated planes, and the vector L1 needs two clocks per distinct
+// 128-byte line (scripts/ubench/l1_window_rate.hip): launches 0-3 run at 2.2x their VALU bound.
+// Here 8 consecutive lanes evaluate ONE (pixel, plane) pair, lane c taking window column c: at
+// each of the N row steps the 8 lanes sample the same plane at points 2 pixels apart, i.e. windows
+// that share one to three lines, and a wavefront (8 pairs) touches ~20 lines per load instead of
+// ~64.  Every sample is computed by the same instruction sequence as in view_cost_pipe.  The
+// reference's summation order (columns outer, rows inner, one fmaf per sample into a single
+// accumulator, gipuma.cu:633-676) is kept by a relay: each lane stores the N (w, dis) pairs of its
+// column; in relay step c every lane re-runs its N fmafs starting from the value its left
+// neighbour produced in step c-1, so after step c lane c holds the exact prefix over columns 0..c
+// (the other lanes' values are never used).  N*(N+1) extra instructions per N samples per lane --
+// irrelevant where the launch is bound by line fills.
+// ---------------------------------------------------------------------------------------------
+#ifndef PM_COLS_PD
+#define PM_COLS_PD 8
+#endif
+// lanes per (pixel, plane) pair: 8 for windows of up to 8 columns (box <= 15), 16 for up to 16
+// (box 25: 13 columns, three lanes of a group shadow the last one); groups never straddle a DPP row
+template <int BOX>
+__host__ __device__ constexpr int col_group()
+{
+    return (BOX + 1) / 2 <= 8 ? 8 : 16;
+}
+template <int BOX>
+__host__ __device__ constexpr int col_tasks()  // pairs evaluated concurrently by a workgroup
+{
+    return kThreads / col_group<BOX>();
+}
+
+template <int BOX, bool FAST>
+__device__ __forceinline__ float view_cost_cols(const Problem *__restrict__ P, const ViewCam &vc,
+                                                const float *__restrict__ H, const float *__restrict__ tp0,
+                                                int tw, const float *__restrict__ lut, int px, int py, int col)
+{
+    constexpr int R = (BOX - 1) / 2, N = R + 1;
+    static_assert(BOX > 0 && N <= col_group<BOX>(), "one lane per window column");
+    const float colsf = (float)P->cols, rowsf = (float)P->rows;
+    const float alpha = P->alpha, oma = 1.f - P->alpha;
+    const float tau_color = P->tau_color, tau_gradient = P->tau_gradient;
+    const float centre = tp0[0];
+    const float pwf = (float)P->pw;
+    const float magic_c = kMagicF + (float)(2 * P->pw + 2);
+    const gptr_bytes magic_base = (gptr_bytes)((uintptr_t)vc.packed - (uintptr_t)kMagicBits);
+    const char *lut_magic = (const char *)lut - kMagicBits;
+    const float H1 = H[1], H4 = H[4], H7 = H[7];
+    const int mycol = col < N ? col : N - 1;  // spare lanes of a smaller box shadow the last column
+    const float qx = (float)(px - R + 2 * mycol);
+    const float X0 = __builtin_fmaf(H[0], qx, H[2]);
+    const float Y0 = __builtin_fmaf(H[3], qx, H[5]);
+    const float Z0 = __builtin_fmaf(H[6], qx, H[8]);
+
+    auto request = [&](float qy) -> WinReq {
+        const float X = __builtin_fmaf(H1, qy, X0);
+        const float Y = __builtin_fmaf(H4, qy, Y0);
+        const float Z = __builtin_fmaf(H7, qy, Z0);
+        const float rz = recip<FAST>(Z);
+        const float sx = X * rz, sy = Y * rz;
+        const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
+        WinReq r;
+        r.a = sx - fx0;
+        r.b = sy - fy0;
+        const float Xc = __builtin_amdgcn_fmed3f(fx0, -2.0f, colsf);
+        const float Yc = __builtin_amdgcn_fmed3f(fy0, -2.0f, rowsf);
+        const uint32_t off = __float_as_uint(__builtin_fmaf(Yc, pwf, Xc + magic_c));
+        r.w = *(gptr_u32x4)(magic_base + off);
+        return r;
+    };
+
+    const float qy0 = (float)(py - R);
+    const float *tcol = tp0 + 4 * (-R * tw - R + 2 * mycol);  // texel (column, -R) of the window
+    float wgt[N], dis[N];
+    // PD window requests in flight (these launches wait on L2 misses, and the kernel has registers
+    // to spare below its 3-wavefront budget)
+    constexpr int PDmax = N > 8 ? 4 : PM_COLS_PD;  // (13 samples per column: keep the registers for wgt/dis)
+    constexpr int PD = PDmax < N ? PDmax : N;
+    WinReq req[PD];
+#pragma unroll
+    for (int p = 0; p < PD; p++) req[p] = request(qy0 + (float)(2 * p));
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const WinReq cur = req[k % PD];
+        if (k + PD < N) req[k % PD] = request(qy0 + (float)(2 * (k + PD)));
+        const float4 t4 = *reinterpret_cast<const float4 *>(tcol + 8 * k * tw);
+        const float colorDis = __builtin_fabsf(t4.x - centre);
+        wgt[k] = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
+        const Taps tp5 = taps_u8(cur.a, cur.b, cur.w.x, cur.w.y, cur.w.z, cur.w.w);
+        const float colDiff = t4.w - tp5.sc;
+        const float gradX = t4.y - tp5.gx2;
+        const float gradY = t4.z - tp5.gy2;
+        const float gradDis = min_nc((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
+        const float colDis = min_abs_nc(colDiff, tau_color);
+        dis[k] = __builtin_fmaf(alpha, gradDis, oma * colDis);
+    }
+    // relay: after step c, lane c of the group holds the sum over columns 0..c in reference order
+    float out = 0.0f;
+#pragma unroll
+    for (int c = 0; c < N; c++) {
+        // lane i takes lane i-1's value: DPP row_shr:1 (groups of 8 never straddle a row of 16)
+        float acc = c == 0 ? 0.0f
+                           : __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(out), 0x111, 0xf, 0xf, false));
+#pragma unroll
+        for (int k = 0; k < N; k++) acc = __builtin_fmaf(wgt[k], dis[k], acc);
+        out = acc;
+    }
+    return out;  // exact in lane N-1 of the group
+}
+
+// view_cost_cols for T = float4 (-color_processing): lane c evaluates window column c by the
+// arithmetic of view_cost_c4_loop (three 16-byte window loads and tap sets per sample, l1_norm(float4)
+// reductions, weight table indexed by |dB|+|dG|+|dR|, integer window addressing), the relay keeps the
+// reference's summation order.  `tp0` points at the pixel's own texel in the float4 {B, G, R, 0} tile.
+struct WinReq3 {
+    float a, b;
+    u32x4_a4 q0, q1, q2;
+};
+template <int BOX, bool FAST>
+__device__ __forceinline__ float view_cost_cols_c4(const Problem *__restrict__ P, const ViewCam &vc,
+                                                   const float *__restrict__ H, const float *__restrict__ tp0,
+                                                   int tw, const float *__restrict__ lut, int px, int py, int col)
+{
+    constexpr int R = (BOX - 1) / 2, N = R + 1;
+    static_assert(BOX > 0 && N <= col_group<BOX>(), "one lane per window column");
+    const gptr_bytes packed = (gptr_bytes)vc.packed;
+    const uint32_t pw = (uint32_t)P->pw;
+    const uint32_t xmax = (uint32_t)(P->cols + 2), ymax = (uint32_t)(P->rows + 2);
+    const float alpha = P->alpha, oma = 1.f - P->alpha;
+    const float tau_color = P->tau_color, tau_gradient = P->tau_gradient;
+    const float4 centre = *reinterpret_cast<const float4 *>(tp0);
+    const float H1 = H[1], H4 = H[4], H7 = H[7];
+    const int mycol = col < N ? col : N - 1;
+    const float qx = (float)(px - R + 2 * mycol);
+    const float X0 = __builtin_fmaf(H[0], qx, H[2]);
+    const float Y0 = __builtin_fmaf(H[3], qx, H[5]);
+    const float Z0 = __builtin_fmaf(H[6], qx, H[8]);
+
+    auto request = [&](float qy) -> WinReq3 {
+        const float X = __builtin_fmaf(H1, qy, X0);
+        const float Y = __builtin_fmaf(H4, qy, Y0);
+        const float Z = __builtin_fmaf(H7, qy, Z0);
+        const float rz = recip<FAST>(Z);
+        const float sx = X * rz, sy = Y * rz;
+        const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
+        WinReq3 r;
+        r.a = sx - fx0;
+        r.b = sy - fy0;
+        const uint32_t Xw = min(cvt_u32_sat(fx0 + 2.0f), xmax);
+        const uint32_t Yw = min(cvt_u32_sat(fy0 + 2.0f), ymax);
+        const gptr_bytes base = packed + (Yw * pw + Xw) * 12u;
+        r.q0 = *(gptr_u32x4)(base);
+        r.q1 = *(gptr_u32x4)(base + 16);
+        r.q2 = *(gptr_u32x4)(base + 32);
+        return r;
+    };
+
+    const float qy0 = (float)(py - R);
+    const float *tcol = tp0 + 4 * (-R * tw - R + 2 * mycol);  // texel (column, -R) of the window
+    float wgt[N], dis[N];
+#ifndef PM_COLS_C4_PD
+#define PM_COLS_C4_PD 3
+#endif
+    constexpr int PD = PM_COLS_C4_PD < N ? PM_COLS_C4_PD : N;  // window requests (three loads each) in flight
+    WinReq3 req[PD];
+#pragma unroll
+    for (int p = 0; p < PD; p++) req[p] = request(qy0 + (float)(2 * p));
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const WinReq3 cur = req[k % PD];
+        if (k + PD < N) req[k % PD] = request(qy0 + (float)(2 * (k + PD)));
+        const float *tp = tcol + 8 * k * tw;
+        const float4 lv = *reinterpret_cast<const float4 *>(tp);
+        const float S = __builtin_fabsf(lv.x - centre.x) + __builtin_fabsf(lv.y - centre.y) +
+                        __builtin_fabsf(lv.z - centre.z);  // exact integer 0..765
+        wgt[k] = lut[(int)S];
+        Taps t[3];  // word 3k+c = column k, channel c
+        t[0] = taps_u8(cur.a, cur.b, cur.q0.x, cur.q0.w, cur.q1.z, cur.q2.y);
+        t[1] = taps_u8(cur.a, cur.b, cur.q0.y, cur.q1.x, cur.q1.w, cur.q2.z);
+        t[2] = taps_u8(cur.a, cur.b, cur.q0.z, cur.q1.y, cur.q2.x, cur.q2.w);
+        const float4 up = *reinterpret_cast<const float4 *>(tp - 4 * tw);
+        const float4 down = *reinterpret_cast<const float4 *>(tp + 4 * tw);
+        const float4 left = *reinterpret_cast<const float4 *>(tp - 4);
+        const float4 right = *reinterpret_cast<const float4 *>(tp + 4);
+        const float colDiff = l1_3(lv.x - t[0].sc, lv.y - t[1].sc, lv.z - t[2].sc);
+        const float gX = l1_3((right.x - left.x) - t[0].gx2, (right.y - left.y) - t[1].gx2,
+                              (right.z - left.z) - t[2].gx2);
+        const float gY = l1_3((down.x - up.x) - t[0].gy2, (down.y - up.y) - t[1].gy2,
+                              (down.z - up.z) - t[2].gy2);
+        const float gradDis = min_nc((gX + gY) * 0.0625f, tau_gradient);
+        const float colDis = min_nc(colDiff, tau_color);
+        dis[k] = __builtin_fmaf(alpha, gradDis, oma * colDis);
+    }
+    // relay: after step c, lane c of the group holds the sum over columns 0..c in reference order
+    float out = 0.0f;
+#pragma unroll
+    for (int c = 0; c < N; c++) {
+        float acc = c == 0 ? 0.0f
+                           : __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(out), 0x111, 0xf, 0xf, false));
+#pragma unroll
+        for (int k = 0; k < N; k++) acc = __builtin_fmaf(wgt[k], dis[k], acc);
+        out = acc;
+    }
+    return out;  // exact in lane N-1 of the group
+}
+
+// pmCostMultiview_cu for one (pixel, plane) pair evaluated by a group of col_group<BOX>() lanes; the
+// result is exact in every lane of the group
+template <int BOX, bool COMBINE_REG, int CH = 1>
+__device__ __forceinline__ float multiview_cost_cols(const Problem *__restrict__ P, const float *__restrict__ tp0,
+                                                     int tw, const float *__restrict__ lut, float *cv, int px,
+                                                     int py, float4 pl, int col)
+{
+    constexpr int R = (BOX - 1) / 2, N = R + 1;
+    const int n = P->n_sel;
+    ViewCombiner<COMBINE_REG> comb;
+    constexpr int G = col_group<BOX>();
+    const int grp_lane0 = (int)(threadIdx.x & 63u & ~(unsigned)(G - 1));
+    const int src_lane = grp_lane0 + (N - 1);
+    // the homography of a (plane, view) pair is the same for the lanes of a group: lane c computes
+    // it for view vb + c (the literal arithmetic of homography()), the lanes then pass them round
+    for (int vb = 0; vb < n; vb += G) {
+        float Hl[9];
+        homography(P->rc.K_inv, P->view[min(vb + col, n - 1)], pl, Hl);
+        const int vend = min(vb + G, n);
+        for (int v = vb; v < vend; v++) {
+            float H[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) H[k] = __shfl(Hl[k], grp_lane0 + (v - vb));
+            const bool safe = window_z_safe(H, (float)(px - R), (float)(px + R), (float)(py - R), (float)(py + R));
+            float c;
+            if constexpr (CH == 4) {
+                if (__all(safe))
+                    c = view_cost_cols_c4<BOX, true>(P, P->view[v], H, tp0, tw, lut, px, py, col);
+                else
+                    c = view_cost_cols_c4<BOX, false>(P, P->view[v], H, tp0, tw, lut, px, py, col);
+            } else if (__all(safe))
+                c = view_cost_cols<BOX, true>(P, P->view[v], H, tp0, tw, lut, px, py, col);
+            else
+                c = view_cost_cols<BOX, false>(P, P->view[v], H, tp0, tw, lut, px, py, col);
+            comb.add(__shfl(c, src_lane), v, cv);  // the group's exact value
+        }
+    }
+    return comb.finish(P, n, cv);
+}
+
+}  // namespace pm

@@ -454,3 +454,30 @@ def test_pfm_ground_truth_keeps_the_last_channel(tmp_path):
         assert L.gipuma_host_read_gt_map(path.encode(), out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(r), C.byref(c)) == 0
         assert (r.value, c.value) == (rows, cols)
         assert np.array_equal(out, want)
+
+
+def test_projection_matrices_with_negative_scale_decompose_to_the_same_cameras():
+    """a projection matrix is defined up to scale, including its sign: P and -P describe the same camera, and a
+    3x3 part with negative determinant (det(M) < 0) is what -P of an ordinary calibration looks like.  Both
+    front-ends (numpy QR in cameras.py, Gram-Schmidt in gipuma_host.cpp) negate such a P before the RQ step and
+    must return the cameras of +P -- K with a positive diagonal, R a rotation (det +1), the same centre.
+    (OpenCV's decomposeProjectionMatrix, cameraGeometryUtils.h:252, only fixes the signs of two diagonal
+    entries; the reference never meets det(M) < 0 on its own data sets)"""
+    P = synth.dtu_projection_matrices()
+    ids = [15, 2, 9, 24]
+    Pl = [P[k] for k in ids]
+    neg = [-p for p in Pl]
+    mixed = [Pl[0], -Pl[1], Pl[2], -Pl[3]]
+    assert np.linalg.det(neg[0][:, :3]) < 0 < np.linalg.det(Pl[0][:, :3])
+    py = get_camera_parameters(Pl)
+    for variant in (neg, mixed):
+        py2 = get_camera_parameters(variant)
+        cpp2 = cpp_cameras(variant)
+        for i in range(len(ids)):
+            a, b, c = cam_fields(py.c_array[i]), cam_fields(py2.c_array[i]), cam_fields(cpp2.c_array[i])
+            assert np.allclose(a, b, rtol=1e-6, atol=1e-6), (i, np.abs(a - b).max())
+            assert np.allclose(a, c, rtol=2e-5, atol=2e-5), (i, np.abs(a - c).max())
+            K = np.array(cpp2.c_array[i].K[:]).reshape(3, 3)
+            R = np.array(cpp2.c_array[i].R[:]).reshape(3, 3)
+            assert K[0, 0] > 0 and K[1, 1] > 0 and K[2, 2] > 0
+            assert np.linalg.det(R) == pytest.approx(1.0, abs=1e-5)
