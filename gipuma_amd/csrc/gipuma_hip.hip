@@ -697,7 +697,7 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     if (s->push_launches <= 0) s->push_ok = false;
     // OPT-IN (GIPUMA_HIP_GROUP_FROM=<first half-sweep>): measured on config C it halves the propagation stage's
     // instructions (6.4e8 instead of 13.5e8 per late half-sweep) but runs them at a third of the fused kernel's issue
-    // rate -- short phases between ~100 barriers per workgroup --: 4.07 ms against 3.31 ms per late half-sweep
+    // rate (strips of 8-15 samples, an LDS-bound chain phase): 4.1-4.2 ms against 3.3 ms per late half-sweep
     s->group_from = -1;
     if (const char *t = getenv("GIPUMA_HIP_GROUP_FROM")) s->group_from = atoi(t);  // < 0 = never
     if (s->group_from < 0) s->group_ok = false;
@@ -926,6 +926,11 @@ int gipuma_hip_solve(gipuma_hip_session *s, gipuma_hip_timing *timing)
             HIP_OK(hipMemset(s->dbg, 0, h.size() * sizeof(unsigned long long)));
             const double px = 0.5 * (double)s->rows * (double)s->cols;
             static const char *names[] = {"tasks/px", "seen/px", "items/px", "open items/px", "redone cands/px", "cands/px"};
+            if (h[62 * pm::kDbgSlots + 0]) {  // pm::group_kernel's phase clocks (100 MHz ticks summed over workgroups -> ms per workgroup-slot)
+                fprintf(stderr, "gipuma_hip group_kernel phase ticks (state, tasks, grouping, cut, strips, chains):");
+                for (int k = 0; k < 6; k++) fprintf(stderr, " %llu", h[62 * pm::kDbgSlots + k]);
+                fprintf(stderr, "\n");
+            }
             for (int k = 0; k < 6; k++) {
                 fprintf(stderr, "gipuma_hip counts %s:", names[k]);
                 for (int ph = 1; ph <= 2 * s->iterations && ph < 64; ph++)

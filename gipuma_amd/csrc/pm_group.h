@@ -37,8 +37,11 @@
 namespace pm {
 
 constexpr int kGrpMaxTasks = 8 * kThreads;  // 2048
-constexpr int kGrpStride = 17;              // words per strip in the sample buffer (odd: columns in different banks)
 constexpr int kGrpHashSize = 2048;
+
+constexpr int kSbGroups = 128;       // groups per super-batch
+constexpr int kSbStripsPerLane = 5;  // strips (sample columns) per lane and view
+constexpr int kSbTasksPerLane = 2;   // tasks per lane (their combiners live in registers across the view loop; 4: 256 VGPRs and scratch)
 
 template <int BOX>
 struct GroupLayout {  // offsets in 32-bit words into the dynamic LDS array
@@ -46,12 +49,11 @@ struct GroupLayout {  // offsets in 32-bit words into the dynamic LDS array
     static constexpr int R = (BOX - 1) / 2, N = R + 1;
     static constexpr int tw = kTileW + 2 * N, th = kSweepTileH + 2 * N;
     static constexpr int max_rows = N + (kSweepTileH - 1) / 2;  // samples per strip: 8 + 7 = 15 for box 15
-    static_assert(max_rows < kGrpStride, "a strip fits its row of the sample buffer");
-    static constexpr int max_batch_groups = (kThreads + N - 1) / N;  // a group has at least N strips
+    static constexpr int max_strips = kSbStripsPerLane * kThreads, max_tasks = kSbTasksPerLane * kThreads;
     // sweep_read_state stages the float4 tile of the sweep kernels at [kLutSize, kLutSize + 4 tw th) and its scalar
     // staging plane -- I alone, clamp-to-edge point samples -- right behind it.  This kernel keeps the PLANE (the
     // gradients are two subtractions per sample, the ones stage_tile does) and puts its tables where the float4
-    // tile was: three workgroups fit a CU.
+    // tile was.
     static constexpr int meta = kLutSize;                    // [2048 groups][2]: task0 | count << 11 ; rep | bbox << 11
     static constexpr int plane = kLutSize + 4 * tw * th;     // [th][tw] reference texels
     static_assert(meta + 2 * kGrpMaxTasks <= plane, "the group table fits where the float4 tile was");
@@ -59,15 +61,18 @@ struct GroupLayout {  // offsets in 32-bit words into the dynamic LDS array
     static constexpr bool lists_in_front = meta + 2 * kGrpMaxTasks + kGrpMaxTasks <= plane;
     static constexpr int btask = lists_in_front ? meta + 2 * kGrpMaxTasks : plane + tw * th;  // [2048] u16: owner | slot << 8
     static constexpr int sorted = btask + kGrpMaxTasks / 2;  // [2048] u16: task indices ordered by group
-    static constexpr int misc = (lists_in_front ? plane + tw * th : sorted + kGrpMaxTasks / 2);  // counters, per-batch prefix tables
-    static constexpr int gplane = misc + 128;                // [max_batch_groups] float4: the planes of the batch's groups
-    static constexpr int hbuf = gplane + 4 * 48;             // [2][max_batch_groups][10]: homography + fast-reciprocal flag
-    static constexpr int dis = hbuf + 2 * 10 * 48;           // [256 strips][kGrpStride]; while grouping: hash table + group ids
-    static constexpr int total = dis + kThreads * kGrpStride;
-    static_assert(max_batch_groups <= 48, "homography buffer");
-    static_assert(kGrpHashSize + kGrpMaxTasks / 2 <= kThreads * kGrpStride, "hash table + group ids alias the sample buffer");
-    static constexpr int wg_per_cu = total * 4 <= (160 * 1024) / 3 ? 3 : 2;  // box 15: three workgroups per CU
-    static_assert(total * 4 <= 80 * 1024, "at least two workgroups per CU");
+    static constexpr int misc = (lists_in_front ? plane + tw * th : sorted + kGrpMaxTasks / 2);  // counters
+    static constexpr int gtab = misc + 128;                  // [kSbGroups + 1][4]: first strip, first task, first sample of a group
+    static constexpr int gplane = gtab + 4 * (kSbGroups + 1);  // [kSbGroups] float4: the planes of the super-batch's groups
+    static constexpr int hbuf = gplane + 4 * kSbGroups;      // [kSbGroups][10]: homography + fast-reciprocal flag
+    static constexpr int sgroup = hbuf + 10 * kSbGroups;     // [max_strips] u8: group (within the super-batch) of a strip
+    static constexpr int tgroup = sgroup + max_strips / 4;   // [max_tasks] u8: ... of a task
+    static constexpr int dis = tgroup + max_tasks / 4;       // the sample buffer; while grouping: hash table + group ids
+    static constexpr int total = (80 * 1024) / 4;            // two workgroups per CU
+    static constexpr int capacity = total - dis;             // samples (of one view) a super-batch may hold
+    static_assert(kGrpHashSize + kGrpMaxTasks / 2 <= capacity, "hash table + group ids alias the sample buffer");
+    static_assert(capacity >= (N + 15) * max_rows, "the largest possible group fits the sample buffer");
+    static_assert(capacity < 65536, "sample offsets fit 16 bits");
 };
 
 __device__ __forceinline__ uint32_t plane_hash(float4 pl, int cls)
@@ -142,7 +147,7 @@ __device__ __forceinline__ void group_strip(const Problem *__restrict__ P, gptr_
 // grid = tiles of the sweep kernels; `colour`: the colour about to be swept (the consumers); `hist`: rule (H) is
 // valid for that half-sweep (the consumer replays only the slots whose producer changed)
 template <int BOX>
-__global__ __launch_bounds__(kThreads, GroupLayout<BOX>::wg_per_cu) void group_kernel(const Problem *__restrict__ P,
+__global__ __launch_bounds__(kThreads, 2) void group_kernel(const Problem *__restrict__ P,
                                                                       const float4 *__restrict__ norm4,
                                                                       const float *__restrict__ cost, int colour,
                                                                       int hist, unsigned tune)
@@ -154,6 +159,16 @@ __global__ __launch_bounds__(kThreads, GroupLayout<BOX>::wg_per_cu) void group_k
     const int rows = P->rows, cols = P->cols, n = P->n_sel;
     const size_t np = (size_t)rows * (size_t)cols;
 
+    // (GIPUMA_HIP_COUNTS: 100 MHz wall-clock ticks per phase, summed over the workgroups, in row 62 of Problem::dbg)
+    const bool prof = P->dbg != nullptr && tid == 0;
+    unsigned long long tick = prof ? wall_clock64() : 0ull;
+    auto lap = [&](int slot) {
+        if (prof) {
+            const unsigned long long now = wall_clock64();
+            atomicAdd(&P->dbg[62 * kDbgSlots + slot], now - tick);
+            tick = now;
+        }
+    };
     // ---- tile, state, skip rules: what sweep_setup does for the half-sweep itself ----
     SweepLane L;
     {
@@ -161,6 +176,7 @@ __global__ __launch_bounds__(kThreads, GroupLayout<BOX>::wg_per_cu) void group_k
         const unsigned t2 = (tune & ~(Tune::kPushConsume | Tune::kHistorySkip)) | (hist ? Tune::kHistorySkip : 0u);
         sweep_read_state<BOX, 1>(L, P, lds, norm4, cost, colour, 3u, t2, true);
     }
+    lap(0);  // tile + state
     unsigned short *btask = reinterpret_cast<unsigned short *>(lds + LY::btask);
     unsigned short *sorted = reinterpret_cast<unsigned short *>(lds + LY::sorted);
     uint32_t *meta = reinterpret_cast<uint32_t *>(lds + LY::meta);
@@ -206,6 +222,7 @@ __global__ __launch_bounds__(kThreads, GroupLayout<BOX>::wg_per_cu) void group_k
             if ((L.needmask >> k) & 1u) btask[pos++] = (unsigned short)(tid | (k << 8));
         __syncthreads();
     }
+    lap(1);  // MAXCOST writes + task list
     if (n_tasks == 0) return;  // (uniform)
 
     auto task_plane = [&](int t, int &olx, int &oly, int &nb) -> float4 {
@@ -312,128 +329,181 @@ __global__ __launch_bounds__(kThreads, GroupLayout<BOX>::wg_per_cu) void group_k
     }
     __syncthreads();
 
-    // ---- batches of consecutive groups: at most 256 strips and 256 tasks each ----
-    int *bstrip0 = misc + 16;   // [max_batch_groups + 1] first strip of each group of the batch
-    int *btask0 = misc + 80;    // [max_batch_groups + 1] first task (position in `sorted`) of each group
+    lap(2);  // grouping, sort, bounding boxes
+    // ---- super-batches of consecutive groups: as many as the sample buffer, kSbStripsPerLane strips and
+    //      kSbTasksPerLane tasks per lane allow.  Per super-batch the views are looped outside: all its strips for
+    //      view v (phase A), then all its chains (phase B) -- two barriers per view, thousands of instructions
+    //      between them ----
+    uint32_t *gtab = reinterpret_cast<uint32_t *>(lds + LY::gtab);
+    unsigned char *sgroup = reinterpret_cast<unsigned char *>(lds + LY::sgroup);
+    unsigned char *tgroup = reinterpret_cast<unsigned char *>(lds + LY::tgroup);
     int g_first = 0;
     while (g_first < n_groups) {  // (uniform)
-        // the first wavefront cuts the batch: groups g_first .. g_first + ng - 1
-        if (wave == 0) {
-            const int g = g_first + lane;
-            int nc = 0, nt = 0;
-            if (lane < LY::max_batch_groups && g < n_groups) {
-                nc = N + (int)((meta[2 * g + 1] >> 20) & 31u);
+        // cut: groups g_first .. g_first + ng - 1 (lane i of the first two wavefronts looks at group g_first + i)
+        {
+            const int g = g_first + tid;
+            int nc = 0, nt = 0, npnt = 0;
+            if (tid < kSbGroups && g < n_groups) {
+                const uint32_t m1 = meta[2 * g + 1];
+                nc = N + (int)((m1 >> 20) & 31u);
                 nt = (int)(meta[2 * g] >> 11);
+                npnt = nc * (N + (int)((m1 >> 25) & 15u));
             }
-            int ic = nc, it = nt;
+            int ic = nc, it = nt, ip = npnt;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
-                const int uc = __shfl_up(ic, d), ut = __shfl_up(it, d);
+                const int uc = __shfl_up(ic, d), ut = __shfl_up(it, d), up = __shfl_up(ip, d);
                 if (lane >= d) {
                     ic += uc;
                     it += ut;
+                    ip += up;
                 }
             }
-            const bool fits = nc > 0 && ic <= kThreads && it <= kThreads;
-            const unsigned long long fb = __ballot(fits);
-            // groups are taken while they fit: the batch is the run of set bits from bit 0
-            const int ng = (int)__builtin_ctzll(~fb);
-            if (lane <= LY::max_batch_groups) {
-                bstrip0[lane] = ic - nc;  // (exclusive prefix; entry ng = totals of the batch)
-                btask0[lane] = it - nt;
+            if (wave == 0 && lane == 63) {
+                misc[16] = ic;
+                misc[17] = it;
+                misc[18] = ip;
             }
-            if (lane == 0) misc[9] = ng;
+            __syncthreads();
+            if (wave == 1) {
+                ic += misc[16];
+                it += misc[17];
+                ip += misc[18];
+            }
+            const bool fits = nc > 0 && ic <= LY::max_strips && it <= LY::max_tasks && ip <= LY::capacity;
+            const unsigned long long fb = __ballot(fits);
+            // groups are taken while they fit: the run of set bits from bit 0 of the first wavefront on
+            if (wave < 2 && lane == 0) misc[20 + wave] = fb == ~0ull ? 64 : (int)__builtin_ctzll(~fb);
+            if (tid < kSbGroups) {  // exclusive prefixes; the entry behind the last group taken = the totals
+                gtab[4 * (tid + 1) + 0] = (uint32_t)ic;
+                gtab[4 * (tid + 1) + 1] = (uint32_t)it;
+                gtab[4 * (tid + 1) + 2] = (uint32_t)ip;
+            }
+            if (tid == 0) gtab[0] = gtab[1] = gtab[2] = 0u;
+            __syncthreads();
+        }
+        const int ng = misc[20] < 64 ? misc[20] : 64 + misc[21];  // (a single group always fits)
+        const int n_strips = (int)gtab[4 * ng + 0], n_btasks = (int)gtab[4 * ng + 1];
+        // tables: which group a strip / a task of the super-batch belongs to; the groups' planes
+        if (tid < ng) {
+            const uint32_t m1 = meta[2 * (g_first + tid) + 1];
+            const int s0 = (int)gtab[4 * tid + 0], s1 = (int)gtab[4 * tid + 4];
+            const int t0 = (int)gtab[4 * tid + 1], t1 = (int)gtab[4 * tid + 5];
+            for (int k = s0; k < s1; k++) sgroup[k] = (unsigned char)tid;
+            for (int k = t0; k < t1; k++) tgroup[k] = (unsigned char)tid;
+            int rlx, rly, rnb;
+            gplane[tid] = task_plane((int)(m1 & 2047u), rlx, rly, rnb);
         }
         __syncthreads();
-        const int ng = misc[9];
-        const int n_strips = bstrip0[ng], n_btasks = btask0[ng];
-        // (a single group always fits: at most 24 strips and 256 tasks?  tasks of one group <= 256 pixels of the tile x 1)
-        // this lane's strip and this lane's task
-        int sj = 0;  // group (within the batch) of strip `tid`
-        int tj = 0;  // group of task `tid`
-        for (int j = 1; j < ng; j++) {
-            if (tid >= bstrip0[j]) sj = j;
-            if (tid >= btask0[j]) tj = j;
+        // this lane's tasks (kept in registers across the views)
+        int t_off[kSbTasksPerLane], t_slot[kSbTasksPerLane], t_center[kSbTasksPerLane];  // sample-buffer offset, slot, pixel
+        int t_nrows[kSbTasksPerLane];
+        const float *t_tp0[kSbTasksPerLane];
+        ViewCombiner<true> comb[kSbTasksPerLane];
+#pragma unroll
+        for (int k = 0; k < kSbTasksPerLane; k++) {
+            const int t = tid + k * kThreads;
+            t_off[k] = 0;
+            t_slot[k] = 0;
+            t_center[k] = 0;
+            t_nrows[k] = N;
+            t_tp0[k] = plane + (L.hh * tw + L.hw);
+            if (t < n_btasks) {
+                const int j = tgroup[t];
+                const uint32_t m0 = meta[2 * (g_first + j)], m1 = meta[2 * (g_first + j) + 1];
+                const unsigned bt = btask[sorted[(int)(m0 & 2047u) + (t - (int)gtab[4 * j + 1])]];
+                int olx, oly;
+                owner_pixel(L, (int)(bt & 255u), colour, olx, oly);
+                const int nrows = N + (int)((m1 >> 25) & 15u);
+                t_nrows[k] = nrows;
+                t_off[k] = (int)gtab[4 * j + 2] + ((olx - (int)((m1 >> 11) & 31u)) >> 1) * nrows + ((oly - (int)((m1 >> 16) & 15u)) >> 1);
+                t_slot[k] = (int)(bt >> 8);
+                t_center[k] = (L.y0 + oly) * cols + (L.x0 + olx);
+                t_tp0[k] = plane + ((oly + L.hh) * tw + (olx + L.hw));
+            }
         }
-        const bool has_strip = tid < n_strips, has_task = tid < n_btasks;
-        // strip geometry
-        const uint32_t sm1 = meta[2 * (g_first + sj) + 1];
-        const int s_col = tid - bstrip0[sj];
-        const int s_lx = (int)((sm1 >> 11) & 31u) - R + 2 * s_col, s_ly = (int)((sm1 >> 16) & 15u) - R;
-        const int s_rows = has_strip ? N + (int)((sm1 >> 25) & 15u) : 0;
-        const float s_qx = (float)(L.x0 + s_lx), s_qy0 = (float)(L.y0 + s_ly);
-        const float *s_tcol = plane + ((s_ly + L.hh) * tw + (s_lx + L.hw));
-        // task geometry
-        const uint32_t tm0 = meta[2 * (g_first + tj)], tm1 = meta[2 * (g_first + tj) + 1];
-        int olx = 0, oly = 0, t_slot = 0;
-        if (has_task) {
-            const unsigned bt = btask[sorted[(int)(tm0 & 2047u) + (tid - btask0[tj])]];
-            owner_pixel(L, (int)(bt & 255u), colour, olx, oly);
-            t_slot = (int)(bt >> 8);
-        }
-        const int t_strip = bstrip0[tj] + ((olx - (int)((tm1 >> 11) & 31u)) >> 1);
-        const int t_row = (oly - (int)((tm1 >> 16) & 15u)) >> 1;
-        const float *t_tp0 = plane + ((oly + L.hh) * tw + (olx + L.hw));
-        const float centre = t_tp0[0];
-        ViewCombiner<true> comb;
-        // the planes of the batch's groups, and the homographies of the first view
-        auto group_h = [&](int j, int v) {  // (group j of the batch, view v) -> hbuf[v & 1][j]
+        // homography of (group plane, view) -> hbuf; [9] = the fast reciprocal is exact on the whole box
+        auto group_h = [&](int j, int v) {
             const uint32_t m1 = meta[2 * (g_first + j) + 1];
             float H[9];
             homography(P->rc.K_inv, P->view[v], gplane[j], H);
             const int bx0 = L.x0 + (int)((m1 >> 11) & 31u) - R, by0 = L.y0 + (int)((m1 >> 16) & 15u) - R;
             const int bx1 = bx0 + 2 * (N - 1 + (int)((m1 >> 20) & 31u)), by1 = by0 + 2 * (N - 1 + (int)((m1 >> 25) & 15u));
             const bool safe = window_z_safe(H, (float)bx0, (float)bx1, (float)by0, (float)by1);
-            float *h = hbuf + (v & 1) * 10 * 48 + 10 * j;
+            float *h = hbuf + 10 * j;
 #pragma unroll
             for (int k = 0; k < 9; k++) h[k] = H[k];
             h[9] = safe ? 1.0f : 0.0f;
         };
-        if (tid < ng) {
-            int rlx, rly, rnb;
-            gplane[tid] = task_plane((int)(meta[2 * (g_first + tid) + 1] & 2047u), rlx, rly, rnb);
-            group_h(tid, 0);
-        }
+        if (tid < ng) group_h(tid, 0);
         __syncthreads();
+        lap(3);  // super-batch cut, tables, task geometry, first homographies
         for (int v = 0; v < n; v++) {
             const ViewCam &vc = P->view[v];
-            // strips: dis of the group's sample columns
-            {
-                const float *h = hbuf + (v & 1) * 10 * 48 + 10 * sj;
+            const gptr_bytes base = (gptr_bytes)((uintptr_t)vc.packed - (uintptr_t)kMagicBits);
+            // phase A: dis of every sample column of the super-batch
+#ifndef PM_GROUP_EXP_STRIP_REPEAT
+#define PM_GROUP_EXP_STRIP_REPEAT 1  // (timing experiments: phase A run this many times, same results)
+#endif
+            for (int rep = 0; rep < PM_GROUP_EXP_STRIP_REPEAT; rep++)
+            for (int s0 = 0; s0 < n_strips; s0 += kThreads) {  // (uniform trip count)
+                const int sidx = s0 + tid;
+                const bool has = sidx < n_strips;
+                const int j = has ? (int)sgroup[sidx] : 0;
+                const uint32_t m1 = meta[2 * (g_first + j) + 1];
+                const int nrows = N + (int)((m1 >> 25) & 15u);
+                const int c = has ? sidx - (int)gtab[4 * j + 0] : 0;
+                const int s_lx = (int)((m1 >> 11) & 31u) - R + 2 * c, s_ly = (int)((m1 >> 16) & 15u) - R;
+                const float *h = hbuf + 10 * j;
                 float H[9];
 #pragma unroll
                 for (int k = 0; k < 9; k++) H[k] = h[k];
-                const bool safe = h[9] != 0.0f || !has_strip;
-                const gptr_bytes base = (gptr_bytes)((uintptr_t)vc.packed - (uintptr_t)kMagicBits);
+                const bool safe = h[9] != 0.0f || !has;
+                const float *tcol = plane + ((s_ly + L.hh) * tw + (s_lx + L.hw));
+                float *out = dbuf + (int)gtab[4 * j + 2] + c * nrows;
                 if (__all(safe))
-                    group_strip<true>(P, base, H, s_tcol, tw, s_qx, s_qy0, s_rows, dbuf + tid * kGrpStride);
+                    group_strip<true>(P, base, H, tcol, tw, (float)(L.x0 + s_lx), (float)(L.y0 + s_ly), has ? nrows : 0, out);
                 else
-                    group_strip<false>(P, base, H, s_tcol, tw, s_qx, s_qy0, s_rows, dbuf + tid * kGrpStride);
+                    group_strip<false>(P, base, H, tcol, tw, (float)(L.x0 + s_lx), (float)(L.y0 + s_ly), has ? nrows : 0, out);
             }
             __syncthreads();
-            // chains: the reference's summation order over the task's own window
-            if (has_task) {
-                float c = 0.0f;
-                const float *dcol = dbuf + t_strip * kGrpStride + t_row;
-                const float *tcol = t_tp0 + (-R * tw - R);
-                for (int i = 0; i < N; i++, dcol += kGrpStride, tcol += 2) {
+            lap(4);  // phase A
+            // phase B: the reference's summation order over each task's own window ...
 #pragma unroll
-                    for (int j = 0; j < N; j++) {
-                        const float colorDis = __builtin_fabsf(tcol[2 * j * tw] - centre);
-                        const float w = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
-                        c = __builtin_fmaf(w, dcol[j], c);
+            for (int k = 0; k < kSbTasksPerLane; k++) {
+                if (tid + k * kThreads < n_btasks) {
+                    const float centre = t_tp0[k][0];
+                    float cst = 0.0f;
+#ifndef PM_GROUP_EXP_CHAIN_REPEAT
+#define PM_GROUP_EXP_CHAIN_REPEAT 1  // (timing experiments: the chain run this many times, same results)
+#endif
+                    for (int rep = 0; rep < PM_GROUP_EXP_CHAIN_REPEAT; rep++) {
+                    cst = 0.0f;
+                    const float *dcol = dbuf + t_off[k];
+                    const float *tcol = t_tp0[k] + (-R * tw - R);
+                    const int nrows = t_nrows[k];
+                    __builtin_amdgcn_sched_barrier(0);
+                    for (int i = 0; i < N; i++, dcol += nrows, tcol += 2) {
+#pragma unroll
+                        for (int jj = 0; jj < N; jj++) {
+                            const float colorDis = __builtin_fabsf(tcol[2 * jj * tw] - centre);
+                            const float w = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
+                            cst = __builtin_fmaf(w, dcol[jj], cst);
+                        }
                     }
+                    }
+                    comb[k].add(cst, v, nullptr);
                 }
-                comb.add(c, v, nullptr);
             }
-            // ... while the last wavefront -- it seldom has tasks -- prepares the next view's homographies
-            if (v + 1 < n && tid >= kThreads - 64 && tid - (kThreads - 64) < ng) group_h(tid - (kThreads - 64), v + 1);
-            __syncthreads();  // the sample buffer is rewritten for the next view
+            // ... and the next view's homographies (read by phase A only)
+            if (v + 1 < n && tid < ng) group_h(tid, v + 1);
+            __syncthreads();
+            lap(5);  // phase B + next homographies
         }
-        if (has_task) {
-            const int center = (L.y0 + oly) * cols + (L.x0 + olx);
-            P->push_cost[(size_t)t_slot * np + (size_t)center] = comb.finish(P, n, nullptr);
-        }
+#pragma unroll
+        for (int k = 0; k < kSbTasksPerLane; k++)
+            if (tid + k * kThreads < n_btasks)
+                P->push_cost[(size_t)t_slot[k] * np + (size_t)t_center[k]] = comb[k].finish(P, n, nullptr);
         g_first += ng;
     }
 }
