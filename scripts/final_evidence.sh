@@ -9,6 +9,9 @@ sh $R/scripts/gpu_prof.sh final_prof GIPUMA_HIP_LAUNCH_TIMES=1 > $O/prof.txt 2>&
 cp $R/gpurun_out/final_prof/kernel_stats.txt $R/gpurun_out/final_prof/series_named.txt $R/gpurun_out/final_prof/err.txt $O/ 2>/dev/null
 sh $R/scripts/pmc_passes.sh final_pmc > $O/pmc.txt 2>&1
 cp $R/gpurun_out/final_pmc/pmc_summary*.json $O/ 2>/dev/null
+# the bench line imports these counters: hand it the ones just collected (the same files are then committed)
+cp $O/pmc_summary.json $R/profiles/pmc_latest.json
+cp $O/pmc_summary_pixel_per_lane.json $R/profiles/pmc_latest_sweep_kernel.json
 cd $R
 GIPUMA_HIP_LAUNCH_TIMES=1 python bench.py > $O/bench_C.json 2> $O/bench_C.err
 python bench.py --config B --steps 20 --no-cpu-baseline --no-extras > $O/bench_B.json 2> $O/bench_B.err
