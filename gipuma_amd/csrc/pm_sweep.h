@@ -878,8 +878,11 @@ __device__ __forceinline__ bool refine_step_items(const Problem *__restrict__ P,
 #ifndef PM_SWEEP_WG
 #define PM_SWEEP_WG 3  // workgroups per CU the packed-gray sweep kernel is compiled for (3: 168 VGPRs, no spills; 4: 128 VGPRs, measured level)
 #endif
+#ifndef PM_SWEEP_WG_C4
+#define PM_SWEEP_WG_C4 4  // ... and the colour one (4: 128 VGPRs)
+#endif
 template <int BOX, bool U8, bool COMBINE_REG, bool INTERIOR, int CH>
-__global__ __launch_bounds__(kThreads, U8 ? (CH == 4 ? 4 : PM_SWEEP_WG) : 1) void sweep_kernel(const Problem *__restrict__ P,
+__global__ __launch_bounds__(kThreads, U8 ? (CH == 4 ? PM_SWEEP_WG_C4 : PM_SWEEP_WG) : 1) void sweep_kernel(const Problem *__restrict__ P,
                                                          float4 *__restrict__ norm4, float *__restrict__ cost,
                                                          int colour, uint32_t phase, unsigned stages,
                                                          unsigned tune)
