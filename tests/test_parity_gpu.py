@@ -763,6 +763,24 @@ def test_config_d_and_colour_default_equals_exhaustive(hip):
     _default_equals_exhaustive(gs, "colour config C")
 
 
+@pytest.mark.parametrize("cfg,colour,iterations", [("D", False, 2), ("C", True, 2)])
+def test_config_d_and_colour_whole_frame_against_the_oracle(hip, cfg, colour, iterations):
+    """config D (20 views, box 25; scripts/dtu_accurate.sh) and the colour variant of config C's geometry, two
+    iterations each (push launches, column-per-lane launches, the first fused launch): the whole free-running
+    solve against the oracle's, every pixel of the 1600x1200 frame bit for bit.  (The oracle needs ~70 s per
+    config-D iteration and ~30 s per colour iteration on the box's 16 cores; with 3 iterations config D was
+    checked the same way once, 211 s.  All 8 iterations are covered launch by launch on bands and by
+    default == exhaustive on whole frames.)"""
+    import time
+    gs, info = full_problem(cfg, colour=colour, iterations=iterations)
+    a = runcuda(gs)
+    t0 = time.time()
+    o_n4, o_c = OracleState(gs).run()
+    print("config %s%s, %d iterations: oracle free-running solve %.1f s" % (cfg, " colour" if colour else "", iterations, time.time() - t0))
+    assert_same(a[0], o_n4, "config %s colour=%r whole frame norm4" % (cfg, colour))
+    assert_same(a[1], o_c, "config %s colour=%r whole frame cost" % (cfg, colour))
+
+
 @pytest.mark.parametrize("cfg,kw,bands", [("C", {}, [(0, 6), (604, 612)]), ("D", dict(iterations=2), [(0, 3), (606, 610)]),
                                           ("C", dict(colour=True, iterations=2), [(0, 3), (606, 610)])])
 def test_exhaustive_schedule_every_launch_at_full_size(hip, cfg, kw, bands):
