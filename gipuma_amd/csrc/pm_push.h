@@ -152,6 +152,9 @@ struct PushEval {
     __device__ __forceinline__ WinReq request(const float *__restrict__ H, gptr_bytes magic_base, float qx, float qy) const
     {
         // getCorrespondingPoint_cu, gipuma.cu:207-217, the fmaf nesting of view_cost_pipe
+#ifdef PM_PUSH_EXP_ONE_WINDOW_PER_GROUP  // (timing experiment, wrong results: the 8 lanes of a group fetch ONE window --
+        qx = qx - (float)(2 * l);        //  the vector L1's cost if a group's window bytes were fetched once)
+#endif
         const float X = __builtin_fmaf(H[1], qy, __builtin_fmaf(H[0], qx, H[2]));
         const float Y = __builtin_fmaf(H[4], qy, __builtin_fmaf(H[3], qx, H[5]));
         const float Z = __builtin_fmaf(H[7], qy, __builtin_fmaf(H[6], qx, H[8]));
