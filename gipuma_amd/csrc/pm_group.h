@@ -24,13 +24,17 @@
 //           view_cost_pipe (same X0/Y0/Z0 per column, same fmaf per row: the same bits) and leaves dis in LDS;
 //   chain   one lane per task then runs the reference's 64-term fmaf chain over ITS window -- its own support
 //           weights, the reference's order -- and feeds the view cost to its ViewCombiner.
-// Groups are processed in batches of at most 256 strips and 256 tasks; per batch the views are looped outside,
-// so a task's combiner stays in its lane's registers.  The aggregate goes to Problem::push_cost[slot][pixel],
+// Groups are processed in super-batches -- as many consecutive groups as the sample buffer (38 KB), five strips
+// and two tasks per lane allow --; per super-batch the views are looped outside (all its strips for a view, a
+// barrier, all its chains, a barrier), so a task's combiner stays in its lane's registers.  The aggregate goes to
+// Problem::push_cost[slot][pixel],
 // where the half-sweep finds it (Tune::kPushConsume); candidates the skip rules removed get MAXCOST there,
 // which the strict < of the accept test (gipuma.cu:868) rejects like their true cost would be.
 // Same terms, same order, same roundings as view_cost_pipe + multiview_cost: bit-identical.
 //
 // Supported: gray window-packed planes with float-encoded offsets, box 11 / 15, best-N with n_best <= 4.
+// OPT-IN (GIPUMA_HIP_GROUP_FROM): it halves the propagation stage's instructions and is still slower than the fused
+// kernel's propagation rounds (phase clocks).  GIPUMA_HIP_COUNTS=1 reports its phase clocks.
 #pragma once
 #include "pm_device.h"
 
@@ -382,7 +386,8 @@ __global__ __launch_bounds__(kThreads, 2) void group_kernel(const Problem *__res
             if (tid == 0) gtab[0] = gtab[1] = gtab[2] = 0u;
             __syncthreads();
         }
-        const int ng = misc[20] < 64 ? misc[20] : 64 + misc[21];  // (a single group always fits)
+        // (a single group always fits: at most 23 strips of 15 samples and the 128 pixels of its lattice)
+        const int ng = misc[20] < 64 ? misc[20] : 64 + misc[21];
         const int n_strips = (int)gtab[4 * ng + 0], n_btasks = (int)gtab[4 * ng + 1];
         // tables: which group a strip / a task of the super-batch belongs to; the groups' planes
         if (tid < ng) {
