@@ -243,6 +243,18 @@ constexpr int kTpViews = 5;
 // length the probes used
 constexpr unsigned kEtSlot = 24;  // ... and [16 + step] = the prefilter length (lb_item) they used
 constexpr int kLbMax = 32, kLbDwords = kLbMax / 2;
+constexpr int kLbRegDwords = 8;  // lists of up to 16 samples travel in registers (lb_item)
+template <int BOX>
+__host__ __device__ constexpr int lb_max();
+template <int BOX>
+__host__ __device__ constexpr bool lb_in_registers()
+{
+#ifdef PM_LB_FORCE_STREAM  // (A/B builds)
+    return false;
+#else
+    return lb_max<BOX>() <= 2 * kLbRegDwords;
+#endif
+}
 template <int BOX>
 __host__ __device__ constexpr int lb_max()  // samples listed per pixel: a quarter of the window, at most kLbMax
 {

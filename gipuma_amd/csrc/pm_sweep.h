@@ -647,7 +647,7 @@ __device__ __forceinline__ float refine_two_phase(const Problem *__restrict__ P,
                                                   const float *__restrict__ lut, int colour, bool valid, float4 cand,
                                                   float thr, int g0, float *kth_out, int &seq, int *cols_run,
                                                   int *items_left, int lbk, const uint32_t *ordp,
-                                                  int *items_short = nullptr)
+                                                  const uint32_t (&ord)[kLbRegDwords], int *items_short = nullptr)
 {
     constexpr int R = (BOX - 1) / 2, N = R + 1;
     float *accv = work + TpLayout::acc;
@@ -684,9 +684,9 @@ __device__ __forceinline__ float refine_two_phase(const Problem *__restrict__ P,
                 } else {
                     const gptr_bytes base = (gptr_bytes)((uintptr_t)P->view[v].packed - (uintptr_t)kMagicBits);
                     if (__all(safe))
-                        lb = lb_item<BOX, true>(P, base, H, tp0, L.tw, lut, L.px, L.py, ordp, np, lbk >> 1, &lbs);
+                        lb = lb_item<BOX, true>(P, base, H, tp0, L.tw, lut, L.px, L.py, ordp, np, ord, lbk >> 1, &lbs);
                     else
-                        lb = lb_item<BOX, false>(P, base, H, tp0, L.tw, lut, L.px, L.py, ordp, np, lbk >> 1, &lbs);
+                        lb = lb_item<BOX, false>(P, base, H, tp0, L.tw, lut, L.px, L.py, ordp, np, ord, lbk >> 1, &lbs);
                 }
                 if (cols_run) *cols_run += 1 + (lbk + N - 1) / N;
                 const float bound = lb * kLbShrink;  // <= the reference's chain value (see lb_item)
@@ -815,6 +815,14 @@ __device__ __forceinline__ bool refine_step_items(const Problem *__restrict__ P,
         }
         ordp += L.active ? (size_t)L.center : 0;
     }
+    uint32_t ord[kLbRegDwords] = {};
+    if constexpr (CH == 1 && lb_in_registers<BOX>()) {
+        if (lbk > 0) {
+            const size_t npx = (size_t)P->rows * (size_t)P->cols;
+#pragma unroll
+            for (int d = 0; d < lb_max<BOX>() / 2; d++) ord[d] = ordp[(size_t)d * npx];
+        }
+    }
     const int lbk_used = lbk;
     int items_left = 0, items_short = 0, n_redo = 0;
     float thr = P->et_theta[step] * L.cst;
@@ -825,7 +833,7 @@ __device__ __forceinline__ bool refine_step_items(const Problem *__restrict__ P,
         float kth;
         const float cc = refine_two_phase<BOX, CH>(P, L, L.bres, lds, colour, need, cand, thr, g0, &kth, tp_seq,
                                                    probe ? &cols_run : nullptr, pass == 0 ? &items_left : nullptr,
-                                                   lbk, ordp, probe && pass == 0 ? &items_short : nullptr);
+                                                   lbk, ordp, ord, probe && pass == 0 ? &items_short : nullptr);
         const bool open = need && kth >= thr && cc < L.cst;
         if (need && !open) c = cc;
         need = open;
