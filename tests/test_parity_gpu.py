@@ -763,6 +763,20 @@ def test_config_d_and_colour_default_equals_exhaustive(hip):
     _default_equals_exhaustive(gs, "colour config C")
 
 
+def test_stepped_noisy_scene_whole_run_against_the_oracle(hip):
+    """the scene bench.py reports as value_scene_steps -- depth steps of +-30 mm, an occluding disc, sigma = 2 sensor
+    noise: candidates are accepted far more often, bounds hold less often, whole regions lose their best views --
+    with config C's cameras and parameters on an 800x600 frame: the whole free-running solve against the oracle's,
+    and the shipped schedule against the exhaustive one"""
+    gs, info = synth.build_problem("C", cols=800, rows=600, scene="steps")
+    a = _default_equals_exhaustive(gs, "stepped scene")
+    o_n4, o_c = OracleState(gs).run()
+    assert_same(a[0], o_n4, "stepped scene norm4")
+    assert_same(a[1], o_c, "stepped scene cost")
+    gt = info["gt_depth"]
+    assert (np.abs(a[0][..., 3] - gt) / gt < 0.01).mean() > 0.9  # (and it reconstructs the scene)
+
+
 @pytest.mark.parametrize("cfg,colour,iterations", [("D", False, 2), ("C", True, 2)])
 def test_config_d_and_colour_whole_frame_against_the_oracle(hip, cfg, colour, iterations):
     """config D (20 views, box 25; scripts/dtu_accurate.sh) and the colour variant of config C's geometry, two
