@@ -32,6 +32,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+def _exp_env(name, default):
+    """the library (and gipuma_amd.abi) read their A/B switches only when GIPUMA_HIP_EXPERIMENTS is set"""
+    if os.environ.get("GIPUMA_HIP_EXPERIMENTS", "0") in ("", "0"):
+        return default
+    return os.environ.get(name, default)
+
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -380,7 +387,7 @@ def main():
         hs = np.asarray(half_sweeps, dtype=np.float64)  # [steps][2 * iterations]
         first_plain = 0
         if hs.size:
-            cols_first = int(os.environ.get("GIPUMA_HIP_COLS_LAUNCHES", {15: "4", 25: "3"}.get(gs.params.box_hsize, "0"))) \
+            cols_first = int(_exp_env("GIPUMA_HIP_COLS_LAUNCHES", {15: "4", 25: "3"}.get(gs.params.box_hsize, "0"))) \
                 if not args.colour else 0
             first_plain = min(hs.shape[1], max(cols_first, hs_pushed))
         dominant = hs[:, first_plain:] if hs.size and first_plain < hs.shape[1] else None
@@ -410,7 +417,7 @@ def main():
         try:
             import glob
             import hashlib
-            lib_now = hashlib.sha256(open(os.environ.get("GIPUMA_HIP_LIB") or abi.LIB_PATH, "rb").read()).hexdigest()[:16]
+            lib_now = hashlib.sha256(open(_exp_env("GIPUMA_HIP_LIB", None) or abi.LIB_PATH, "rb").read()).hexdigest()[:16]
             src_now = hashlib.sha256(b"".join(open(f, "rb").read() for f in sorted(
                 glob.glob(os.path.join(ROOT, "gipuma_amd", "csrc", "*.h*"))))).hexdigest()[:16]
         except Exception:  # noqa: BLE001
@@ -441,10 +448,10 @@ def main():
             r_ref += 1
             dz /= 10.0
         samples_per_frame = n_pix * (1 + iterations * (8 + r_ref)) * n_views * S
-        cols_l = int(os.environ.get("GIPUMA_HIP_COLS_LAUNCHES", {15: "4", 25: "3"}.get(box, "0"))) if not args.colour else 0
+        cols_l = int(_exp_env("GIPUMA_HIP_COLS_LAUNCHES", {15: "4", 25: "3"}.get(box, "0"))) if not args.colour else 0
         n_launch = 2 * iterations
         # leading half-sweeps whose propagation costs are pushed by pm::push_kernel (pm_push.h: boxes 11 / 15 / 25, gray, best-N <= 4)
-        push_l = int(os.environ.get("GIPUMA_HIP_PUSH_LAUNCHES", "6" if args.colour else {15: "4", 25: "3", 11: "2"}.get(box, "0"))) \
+        push_l = int(_exp_env("GIPUMA_HIP_PUSH_LAUNCHES", "6" if args.colour else {15: "4", 25: "3", 11: "2"}.get(box, "0"))) \
             if ((box in (11, 15, 25) and not args.colour) or (box == 15 and args.colour)) and gs.params.n_best <= 4 and n_views > 0 else 0
         push_l = max(0, min(push_l, n_launch))
         out = {
@@ -516,6 +523,8 @@ def main():
             from gipuma_amd.problem import GlobalState, runcuda
             # (a) the same workload with every exact work-reduction switched off (skip rules A/D/H, early
             #     termination): what a scene that defeats them would cost
+            exp_before = os.environ.get("GIPUMA_HIP_EXPERIMENTS")
+            os.environ["GIPUMA_HIP_EXPERIMENTS"] = "1"  # (the library reads its A/B switches only under this one)
             os.environ["GIPUMA_HIP_TUNE"] = str(64 | (1 << 23) | (1 << 25))
             try:
                 with Session(gs) as s2:
@@ -535,6 +544,10 @@ def main():
                                                    "termination (all 11 hypotheses x 640 samples per pixel and half-sweep)"}
             finally:
                 del os.environ["GIPUMA_HIP_TUNE"]
+                if exp_before is None:
+                    del os.environ["GIPUMA_HIP_EXPERIMENTS"]
+                else:
+                    os.environ["GIPUMA_HIP_EXPERIMENTS"] = exp_before
             # (b) a scene with depth discontinuities, an occluder and sensor noise
             if args.scene == "smooth":
                 gs3, info3 = synth.build_problem(args.config, ref_view=ref_view, device=dev, keep_on_device=True,

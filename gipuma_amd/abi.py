@@ -99,7 +99,8 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or os.environ.get("GIPUMA_HIP_LIB") or LIB_PATH  # env: A/B a differently built library
+    exp = os.environ.get("GIPUMA_HIP_EXPERIMENTS", "0") not in ("", "0")
+    p = path or (os.environ.get("GIPUMA_HIP_LIB") if exp else None) or LIB_PATH  # A/B: a differently built library
     if not os.path.exists(p):
         raise GipumaHipError(
             "HIP extension not built: %s is missing (run `python -c 'import __graft_entry__ as g; "

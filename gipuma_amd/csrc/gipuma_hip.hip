@@ -8,7 +8,9 @@
 //     each of its 6 launches per iteration, gipuma.cu:1916-1936);
 //   * cameras are packed once into one POD block read through scalar loads, instead of the
 //     ~3600 managed allocations the reference dereferences on the device (camera.h:45-51);
-//   * no per-pixel RNG state array (48 B/pixel, gipuma.cu:1840): the RNG is counter based.
+//   * no per-pixel RNG state array (48 B/pixel, gipuma.cu:1840): the RNG is counter based.  Per-pixel state of a
+//     session: 20 B planes + costs, 1 B history flag, and -- performance only, optional (the solve runs without
+//     them when the allocation fails) -- 32 B pushed propagation costs and 16-64 B prefilter sample lists.
 #include "../../include/gipuma_hip.h"
 #include "pm_device.h"
 #include "pm_push.h"
@@ -48,6 +50,18 @@ struct CachedImage {
 typedef std::tuple<int, const void *, int, int, int, int> CacheKey;
 std::map<CacheKey, CachedImage> g_cache;
 std::mutex g_cache_mutex;
+
+// Experiment switches (A/B runs, tests of the work-reduction rules): every GIPUMA_HIP_<name> variable below is read
+// ONLY when GIPUMA_HIP_EXPERIMENTS is set to a non-zero value -- a production process never changes its schedule on
+// ambient environment variables.  None of them changes a result (tests/test_parity_gpu.py).
+const char *exp_env(const char *name)
+{
+    const char *on = getenv("GIPUMA_HIP_EXPERIMENTS");
+    if (!on || atoi(on) == 0) return nullptr;
+    char buf[64];
+    snprintf(buf, sizeof buf, "GIPUMA_HIP_%s", name);
+    return getenv(buf);
+}
 
 #define HIP_OK(expr)                                                                                  \
     do {                                                                                              \
@@ -89,8 +103,6 @@ struct gipuma_hip_session {
     // pixel, listed by pm::weight_order_kernel at the start of every solve (init_planes) or before the
     // first sweep that needs them
     unsigned long long *dbg = nullptr;  // device, Problem::dbg (GIPUMA_HIP_COUNTS=1)
-    float4 *seen_ring = nullptr;        // device, Problem::seen_ring (skip rule (S))
-    unsigned char *seen_pos = nullptr;  // device, Problem::seen_pos
     uint32_t *worder = nullptr;  // device, Problem::worder
     bool worder_valid = false;
     size_t et_hint_bytes = 0;
@@ -228,7 +240,7 @@ int launch_push(gipuma_hip_session *s, int colour, bool hist)
                                           : s->box == 15 ? pm::PushLayout<15>::total
                                           : s->box == 25 ? pm::PushLayout<25>::total
                                                          : pm::PushLayout<11>::total);
-    if (const char *t = getenv("GIPUMA_HIP_PUSH_LDS_KB")) lds = std::max(lds, (size_t)atoi(t) * 1024);  // experiment: fewer workgroups per CU
+    if (const char *t = exp_env("PUSH_LDS_KB")) lds = std::max(lds, (size_t)atoi(t) * 1024);  // experiment: fewer workgroups per CU
     if (!s->push_attr_set) {
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         s->push_attr_set = true;
@@ -429,15 +441,28 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         return fail(GIPUMA_HIP_ERR_ARG, "device_id out of range");
     gipuma_hip_session *s = new (std::nothrow) gipuma_hip_session;
     if (!s) return fail(GIPUMA_HIP_ERR_DEVICE, "out of host memory");
-    // from here on, destroy() cleans up whatever was built
+    // from here on, destroy() cleans up whatever was built.  The image cache is locked while this call looks at /
+    // adds entries; a failure inside that region first takes back the packed planes this call put into the cache
+    // (never verified), then UNLOCKS -- destroy() takes the same non-recursive mutex to give the use counts back.
+    std::unique_lock<std::mutex> cache_lock(g_cache_mutex, std::defer_lock);
+    std::vector<CachedImage *> fresh_cached;  // cache entries whose `packed` this call allocated
+    auto abandon = [&]() {
+        std::string keep = g_err;
+        for (CachedImage *e : fresh_cached) {
+            if (e->packed) (void)hipFree(e->packed);
+            e->packed = nullptr;
+        }
+        fresh_cached.clear();
+        if (cache_lock.owns_lock()) cache_lock.unlock();
+        gipuma_hip_destroy(s);
+        g_err = keep;
+    };
 #define CREATE_OK(expr)                        \
     do {                                       \
         hipError_t e_ = (expr);                \
         if (e_ != hipSuccess) {                \
             fail(GIPUMA_HIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
-            std::string keep = g_err;          \
-            gipuma_hip_destroy(s);             \
-            g_err = keep;                      \
+            abandon();                         \
             return GIPUMA_HIP_ERR_DEVICE;      \
         }                                      \
     } while (0)
@@ -448,12 +473,12 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     s->n_sel = d->n_selected;
     s->iterations = d->params.iterations;
     s->unfused = (d->flags & GIPUMA_HIP_FLAG_UNFUSED) != 0;
-    if (const char *t = getenv("GIPUMA_HIP_TUNE")) {
+    if (const char *t = exp_env("TUNE")) {
         s->tune = (unsigned)strtoul(t, nullptr, 0);
         s->tune &= ~(Tune::kHistorySkip | Tune::kUntrustedCosts | Tune::kAccumChanged | Tune::kPushConsume);  // host-internal bits
     }
-    if (const char *t = getenv("GIPUMA_HIP_COLS_LAUNCHES")) s->cols_launches = atoi(t);  // experiment
-    if (const char *t = getenv("GIPUMA_HIP_LAUNCH_TIMES")) s->launch_times = atoi(t) != 0;
+    if (const char *t = exp_env("COLS_LAUNCHES")) s->cols_launches = atoi(t);  // experiment
+    if (const char *t = exp_env("LAUNCH_TIMES")) s->launch_times = atoi(t) != 0;
     if (d->stream) {
         s->stream = (hipStream_t)d->stream;
     } else {
@@ -506,8 +531,7 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     // integer valued in [0,255] -- 8-bit input converted to float, main.cpp:941
     {
         const bool cached = on_device && (d->flags & GIPUMA_HIP_FLAG_CACHE_IMAGES) != 0;
-        std::unique_lock<std::mutex> lock(g_cache_mutex, std::defer_lock);
-        if (cached) lock.lock();
+        if (cached) cache_lock.lock();
         auto entry = [&](const float *img) -> CachedImage * {
             return cached ? &g_cache[CacheKey(s->device, img, d->rows, d->cols, hp.pitch, d->channels)] : nullptr;
         };
@@ -560,10 +584,12 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
                 }
                 uint32_t *pk = nullptr;
                 CREATE_OK(hipMalloc(&pk, words * sizeof(uint32_t)));
-                if (e)
+                if (e) {
                     e->packed = pk;
-                else
+                    fresh_cached.push_back(e);
+                } else {
                     s->packed.push_back(pk);
+                }
                 hp.view[i].packed = pk;
                 hipLaunchKernelGGL(pack, pgid, dim3(pm::kThreads), 0, s->stream, hp.view[i].img,
                                    hp.rows, hp.cols, hp.pitch, hp.pw, pk);
@@ -571,6 +597,8 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
             CREATE_OK(hipGetLastError());
             if (cached) CREATE_OK(hipStreamSynchronize(s->stream));  // other sessions' streams may read them next
         }
+        fresh_cached.clear();  // packed and synchronised: they belong to the cache now
+        if (cache_lock.owns_lock()) cache_lock.unlock();
     }
 
     // cameras -> one POD block
@@ -605,14 +633,7 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         CREATE_OK(hipMemsetAsync(s->et_stat, 0, 3 * pm::kEtSlot * sizeof(unsigned), s->stream));
         hp.et_stat = s->et_stat;
     }
-    if (!(s->tune & (Tune::kNoSeen | Tune::kNoSkip))) {
-        CREATE_OK(hipMalloc(&s->seen_ring, (size_t)pm::kSeenRing * np * sizeof(float4)));
-        CREATE_OK(hipMalloc(&s->seen_pos, np));
-        CREATE_OK(hipMemsetAsync(s->seen_pos, 0, np, s->stream));
-        hp.seen_ring = s->seen_ring;
-        hp.seen_pos = s->seen_pos;
-    }
-    if (getenv("GIPUMA_HIP_COUNTS") && atoi(getenv("GIPUMA_HIP_COUNTS"))) {  // experiment aid
+    if (exp_env("COUNTS") && atoi(exp_env("COUNTS"))) {  // experiment aid
         CREATE_OK(hipMalloc(&s->dbg, 64 * pm::kDbgSlots * sizeof(unsigned long long)));
         CREATE_OK(hipMemsetAsync(s->dbg, 0, 64 * pm::kDbgSlots * sizeof(unsigned long long), s->stream));
         hp.dbg = s->dbg;
@@ -653,19 +674,19 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         // the occasional redo pass of a bounded evaluation lengthens exactly that (configs A, B: -5..-13 %)
         const size_t tiles = (size_t)((d->cols + pm::kTileW - 1) / pm::kTileW) *
                              (size_t)((d->rows + pm::kSweepTileH - 1) / pm::kSweepTileH);
-        const bool big = tiles >= 1024 || getenv("GIPUMA_HIP_ET_FORCE") != nullptr;  // (env: tests on small frames)
+        const bool big = tiles >= 1024 || exp_env("ET_FORCE") != nullptr;  // (env: tests on small frames)
         // (gray: the pipelined loop on float-encoded offsets; colour: its integer-addressed loop)
         hp.et_enable = sane && big && s->u8 && s->combine_reg && (s->ch == 4 || (hp.magic_addr && s->box > 0));
         // GIPUMA_HIP_ET_FORCE=2 (tests): every workgroup bounds every step, whatever the probes measured
-        if (hp.et_enable && getenv("GIPUMA_HIP_ET_FORCE") && atoi(getenv("GIPUMA_HIP_ET_FORCE")) >= 2) hp.et_enable = 2;
+        if (hp.et_enable && exp_env("ET_FORCE") && atoi(exp_env("ET_FORCE")) >= 2) hp.et_enable = 2;
         hp.et_theta[0] = 1.0f;
         hp.et_theta[1] = 1.0f;
         // the two-phase refinement (compile-time box) redoes open candidates item by item, which
         // is cheap; the per-wavefront bound repeats the whole wavefront and wants a looser third bound
         const bool two_phase = s->box > 0 && !(s->tune & Tune::kNoTwoPhase);
         hp.et_theta[2] = two_phase ? 1.0f : 1.5f;
-        if (const char *g = getenv("GIPUMA_HIP_TP_G0")) hp.tp_g0 = atoi(g);  // experiment: phase-1 columns
-        if (const char *t = getenv("GIPUMA_HIP_ET_THETA")) {  // experiment: "t0,t1,t2" (any value is exact)
+        if (const char *g = exp_env("TP_G0")) hp.tp_g0 = atoi(g);  // experiment: phase-1 columns
+        if (const char *t = exp_env("ET_THETA")) {  // experiment: "t0,t1,t2" (any value is exact)
             float a, b, c;
             if (sscanf(t, "%f,%f,%f", &a, &b, &c) == 3) {
                 hp.et_theta[0] = a;
@@ -676,13 +697,18 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     }
     // lower-bound prefilter of refinement candidates: where the two-phase refinement runs on gray planes
     hp.lb_k = 0;  // chosen by the probe workgroups
-    if (const char *t = getenv("GIPUMA_HIP_LB_K")) hp.lb_k = atoi(t);  // experiment: fixed length, < 0 = off
+    if (const char *t = exp_env("LB_K")) hp.lb_k = atoi(t);  // experiment: fixed length, < 0 = off
     if (hp.et_enable && s->box > 0 && hp.lb_k >= 0 && !(s->tune & (Tune::kNoTwoPhase | Tune::kNoEarlyExit))) {
-        CREATE_OK(hipMalloc(&s->worder, (size_t)pm::kLbDwords * np * sizeof(uint32_t)));
+        // (one plane of rows*cols words per two listed samples: 8 planes for box 15, 16 for box 25, 4 for box 11)
+        const int lb_planes = (s->box == 15 ? pm::lb_max<15>() : s->box == 25 ? pm::lb_max<25>() : pm::lb_max<11>()) / 2;
+        // performance-only state: without the memory for it the solve runs without the prefilter, same results
+        if (hipMalloc(&s->worder, (size_t)lb_planes * np * sizeof(uint32_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            s->worder = nullptr;
+        }
         hp.worder = s->worder;
-    } else {
-        hp.lb_k = -1;
     }
+    if (!s->worder) hp.lb_k = -1;
     // push propagation (pm_push.h): box 11 / 15 / 25, register combiner, packed gray planes with float-encoded offsets
     // ... or colour (three words per texel, integer addressing), box 15
     s->push_ok = s->u8 && s->combine_reg && s->n_sel > 0 && !(s->tune & (Tune::kNoInterior | Tune::kNoSkip)) &&
@@ -691,7 +717,7 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     // measured: config C 4 (5 and 6 level), config D 3 (4 level, 6 loses), config B 2 (+1 %)
     // colour (config C geometry): 6 (4: -1.3 %, 8: -0.7 %, 16: -7 %)
     s->push_launches = s->ch == 4 ? 6 : s->box == 15 ? 4 : s->box == 25 ? 3 : 2;
-    if (const char *t = getenv("GIPUMA_HIP_PUSH_LAUNCHES")) s->push_launches = atoi(t);  // A/B runs: 0 = never
+    if (const char *t = exp_env("PUSH_LAUNCHES")) s->push_launches = atoi(t);  // A/B runs: 0 = never
     // plane-keyed propagation (pm_group.h) after the pushed half-sweeps: box 11 / 15, gray
     s->group_ok = s->push_ok && s->ch == 1 && (s->box == 11 || s->box == 15);
     if (s->push_launches <= 0) s->push_ok = false;
@@ -699,19 +725,22 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     // instructions (6.4e8 instead of 13.5e8 per late half-sweep) but runs them at a third of the fused kernel's issue
     // rate (strips of 8-15 samples, an LDS-bound chain phase): 4.1-4.2 ms against 3.3 ms per late half-sweep
     s->group_from = -1;
-    if (const char *t = getenv("GIPUMA_HIP_GROUP_FROM")) s->group_from = atoi(t);  // < 0 = never
+    if (const char *t = exp_env("GROUP_FROM")) s->group_from = atoi(t);  // < 0 = never
     if (s->group_from < 0) s->group_ok = false;
     if (s->push_ok || s->group_ok) {
-        CREATE_OK(hipMalloc(&s->push_cost, 8 * np * sizeof(float)));
+        // performance-only state too: without it every half-sweep evaluates its own propagation candidates
+        if (hipMalloc(&s->push_cost, 8 * np * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            s->push_cost = nullptr;
+            s->push_ok = s->group_ok = false;
+        }
         hp.push_cost = s->push_cost;
     }
     s->lds_sweep = lds_bytes(s, pm::kSweepTileH, !s->combine_reg, true);
     s->lds_dense = lds_bytes(s, pm::kDenseTileH, true, false);
     if (s->lds_sweep > 160u * 1024u || s->lds_dense > 160u * 1024u) {  // 160 KiB of LDS per CU on gfx950
         fail(GIPUMA_HIP_ERR_UNSUPPORTED, "window x views needs more than 160 KiB of LDS per workgroup");
-        std::string keep = g_err;
-        gipuma_hip_destroy(s);
-        g_err = keep;
+        abandon();
         return GIPUMA_HIP_ERR_UNSUPPORTED;
     }
     CREATE_OK(hipMalloc(&s->dp, sizeof(pm::Problem)));
@@ -744,8 +773,6 @@ int gipuma_hip_destroy(gipuma_hip_session *s)
     if (s->et_hint) (void)hipFree(s->et_hint);
     if (s->worder) (void)hipFree(s->worder);
     if (s->dbg) (void)hipFree(s->dbg);
-    if (s->seen_ring) (void)hipFree(s->seen_ring);
-    if (s->seen_pos) (void)hipFree(s->seen_pos);
     if (s->et_stat) (void)hipFree(s->et_stat);
     if (s->norm4) (void)hipFree(s->norm4);
     if (s->cost) (void)hipFree(s->cost);
@@ -765,7 +792,6 @@ int gipuma_hip_init_planes(gipuma_hip_session *s)
     HIP_OK(hipMemsetAsync(s->et_hint, 0, s->et_hint_bytes, s->stream));
     HIP_OK(hipMemsetAsync(s->et_stat, 0, 3 * pm::kEtSlot * sizeof(unsigned), s->stream));
     s->worder_valid = false;  // (listed again by the first sweep: part of every solve)
-    if (s->seen_pos) HIP_OK(hipMemsetAsync(s->seen_pos, 0, (size_t)s->rows * s->cols, s->stream));  // rule (S): new planes
     const int rc = launch_dense(s, true, s->norm4, s->cost);
     if (!rc) s->costs_trusted = true;
     s->finalized = false;
@@ -857,7 +883,6 @@ int gipuma_hip_set_state(gipuma_hip_session *s, const float *norm4_host, const f
         HIP_OK(hipMemcpyAsync(s->norm4, norm4_host, np * sizeof(float4), hipMemcpyHostToDevice, s->stream));
     if (cost_host)
         HIP_OK(hipMemcpyAsync(s->cost, cost_host, np * sizeof(float), hipMemcpyHostToDevice, s->stream));
-    if (s->seen_pos) HIP_OK(hipMemsetAsync(s->seen_pos, 0, np, s->stream));  // rule (S): a cost may have gone up
     HIP_OK(hipStreamSynchronize(s->stream));
     s->costs_trusted = false;
     s->prev1 = s->prev2 = -1;
@@ -925,7 +950,7 @@ int gipuma_hip_solve(gipuma_hip_session *s, gipuma_hip_timing *timing)
             HIP_OK(hipMemcpy(h.data(), s->dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             HIP_OK(hipMemset(s->dbg, 0, h.size() * sizeof(unsigned long long)));
             const double px = 0.5 * (double)s->rows * (double)s->cols;
-            static const char *names[] = {"tasks/px", "seen/px", "items/px", "open items/px", "redone cands/px", "cands/px"};
+            static const char *names[] = {"tasks/px", "-", "items/px", "open items/px", "redone cands/px", "cands/px"};
             if (h[62 * pm::kDbgSlots + 0]) {  // pm::group_kernel's phase clocks (100 MHz ticks summed over workgroups -> ms per workgroup-slot)
                 fprintf(stderr, "gipuma_hip group_kernel phase ticks (state, tasks, grouping, cut, strips, chains):");
                 for (int k = 0; k < 6; k++) fprintf(stderr, " %llu", h[62 * pm::kDbgSlots + k]);

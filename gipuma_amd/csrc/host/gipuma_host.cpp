@@ -121,6 +121,7 @@ int parse_command_line(int argc, char **argv, InputFiles &in, OutputFiles &out, 
         in.images_folder = in.pmvs_folder + "/visualize/";
         in.p_folder = in.pmvs_folder + "/txt/";
         in.img_filenames.clear();
+        int n_skipped = 0;
         if (DIR *dir = opendir(in.images_folder.c_str())) {
             while (dirent *ent = readdir(dir)) {
                 if (!strcmp(ent->d_name, ".") || !strcmp(ent->d_name, "..")) continue;
@@ -130,9 +131,21 @@ int parse_command_line(int argc, char **argv, InputFiles &in, OutputFiles &out, 
                 const size_t dot = nm.find_last_of('.');
                 std::string ext = dot == std::string::npos ? "" : nm.substr(dot + 1);
                 for (char &ch : ext) ch = (char)tolower((unsigned char)ch);
-                if (ext == "pgm" || ext == "ppm" || ext == "pnm" || ext == "pfm") in.img_filenames.push_back(nm);
+                if (ext == "pgm" || ext == "ppm" || ext == "pnm" || ext == "pfm")
+                    in.img_filenames.push_back(nm);
+                else
+                    n_skipped++;
             }
             closedir(dir);
+        } else {
+            printf("Cannot open the image folder %s\n", in.images_folder.c_str());
+        }
+        if (n_skipped > 0)
+            printf("%d file(s) in %s are in formats this front-end does not read (it reads pgm/ppm/pnm/pfm; a PMVS "
+                   "visualize/ folder holds jpg): convert them to PNM\n", n_skipped, in.images_folder.c_str());
+        if (in.img_filenames.empty()) {
+            printf("No readable images in %s\n", in.images_folder.c_str());
+            return -1;
         }
         std::sort(in.img_filenames.begin(), in.img_filenames.end());  // sorted like the reference's list (main.cpp:153)
         if (camera_idx < 0 || camera_idx >= (int)in.img_filenames.size()) {

@@ -236,14 +236,6 @@ __global__ __launch_bounds__(kThreads) void init_cols_kernel(const Problem *__re
 //         (Problem::changed), then this pixel met exactly that plane one half-sweep ago and did
 //         not end up with it at a lower cost -- it was rejected against a cost that has only
 //         decreased since, or accepted and improved upon
-//     (S) a plane this pixel's propagation evaluated before (a ring of its last kSeenRing evaluated
-//         candidates, Problem::seen_ring): its cost F is a pure function of (pixel, plane); it was then
-//         rejected against a cost that has only decreased since (or for its depth, which is a pure
-//         function too), or accepted -- and the pixel's cost has been <= F ever since.  This does not
-//         need the state invariant, only that the pixel's cost never increases between the two
-//         half-sweeps: the host clears the rings whenever planes are (re-)installed.  A plane that
-//         spreads over a patch reaches a pixel that turned it down again and again, through every
-//         neighbour that adopts it: 8 % (fifth half-sweep) to 20 % (last) of the remaining candidates
 //   can never be accepted (strict <, gipuma.cu:868) and is not evaluated.  On config C the
 //   evaluated candidates drop from 8 to 2.7 per pixel by the last half-sweep.  Because the
 //   per-wavefront MAXIMUM stays near 8, the surviving (pixel, candidate) pairs of the whole
@@ -286,7 +278,6 @@ struct SweepLane {
     unsigned needmask;                // candidate slots that must be evaluated
     unsigned chg;                     // the plane changed in this half-sweep
     int n_tasks;                      // surviving (pixel, candidate) pairs of the workgroup
-    int n_seen;                       // (statistics) candidates of this pixel removed by rule (S)
 };
 
 // tile staging, lane -> pixel mapping, state read (gipuma.cu:1527-1530) and the exact skipping rules:
@@ -333,7 +324,6 @@ __device__ __forceinline__ void sweep_read_state(SweepLane &L, const Problem *__
     L.needmask = 0;
     L.chg = 0;
     L.n_tasks = 0;
-    L.n_seen = 0;
     const bool history = (tune & Tune::kHistorySkip) != 0;
     if (L.active) {
         const float4 pl = norm4[L.center];
@@ -378,32 +368,6 @@ __device__ __forceinline__ void sweep_read_state(SweepLane &L, const Problem *__
                 for (int j = 0; j < k; j++)
                     if (fresh && ((valid >> j) & 1u) && same_bits(cands[k], cands[j])) fresh = false;  // (D)
                 if (fresh) needmask |= 1u << k;
-            }
-            if (P->seen_ring != nullptr && !(tune & Tune::kNoSeen)) {  // (S)
-                const size_t np = (size_t)rows * (size_t)cols;
-                const unsigned st = P->seen_pos[L.center];
-                const unsigned before_seen = needmask;
-                const int cnt = (st & 8u) ? kSeenRing : (int)(st & 7u);
-#pragma unroll
-                for (int a = 0; a < kSeenRing; a++) {
-                    if (a < cnt && needmask != 0u) {
-                        const float4 e = P->seen_ring[(size_t)a * np + (size_t)L.center];
-#pragma unroll
-                        for (int k = 0; k < 8; k++)
-                            if (((needmask >> k) & 1u) && same_bits(cands[k], e)) needmask &= ~(1u << k);
-                    }
-                }
-                L.n_seen = __popc(before_seen) - __popc(needmask);
-                unsigned pos = st & 7u, full = st & 8u;
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    if ((needmask >> k) & 1u) {
-                        P->seen_ring[(size_t)pos * np + (size_t)L.center] = cands[k];
-                        pos = (pos + 1u) & 7u;
-                        if (pos == 0u) full = 8u;
-                    }
-                }
-                P->seen_pos[L.center] = (unsigned char)(pos | full);
             }
         }
         L.needmask = needmask;
@@ -904,10 +868,6 @@ __global__ __launch_bounds__(kThreads, U8 ? (CH == 4 ? PM_SWEEP_WG_C4 : PM_SWEEP
     if (P->dbg != nullptr) {
         unsigned long long *d = P->dbg + (size_t)(phase & 63u) * kDbgSlots;
         if (threadIdx.x == 0) atomicAdd(&d[kDbgTasks], (unsigned long long)L.n_tasks);
-        int ns = L.n_seen;  // (one atomic per wavefront: per-lane atomics on one address would distort the timing)
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) ns += __shfl_xor(ns, o);
-        if ((threadIdx.x & 63u) == 0u && ns) atomicAdd(&d[kDbgSeen], (unsigned long long)ns);
     }
     RefineDraws R;
     refine_init(R, P, stages);

@@ -116,6 +116,9 @@ class GlobalState:
         return self.rows * self.cols
 
 
+SNAPSHOT_VERSION = 2  # 2: parameters as JSON text (1: repr() text, no longer read)
+
+
 def save_problem(path, gs, P_matrices, cam_scale=1.0):
     """Snapshot of one reference view's problem (host images, projection matrices, parameters) as an
     .npz, so that another process can rebuild the identical GlobalState without rendering anything
@@ -126,7 +129,8 @@ def save_problem(path, gs, P_matrices, cam_scale=1.0):
     np.save(path + ".images.npy", np.stack(imgs))
     np.savez(path, P=np.stack([np.asarray(p, dtype=np.float64) for p in P_matrices]),
              cam_scale=float(cam_scale), selected=np.asarray(gs.selected, dtype=np.int32),
-             seed=int(gs.desc.seed), params=np.array([_params_to_json(gs.params)]))
+             seed=int(gs.desc.seed), params=np.array([_params_to_json(gs.params)]),
+             format_version=np.int32(SNAPSHOT_VERSION))
 
 
 def _params_to_json(ap):
@@ -143,6 +147,10 @@ def _params_to_json(ap):
         elif isinstance(v, (float, np.floating)):
             v = float(v)
             out[k] = v if math.isfinite(v) else repr(v)
+        elif isinstance(v, np.ndarray):
+            out[k] = v.tolist()
+        elif isinstance(v, (tuple, list)):
+            out[k] = [x.item() if isinstance(x, np.generic) else x for x in v]
         else:
             out[k] = v
     return json.dumps(out)
@@ -161,6 +169,10 @@ def _params_from_json(text):
 def load_problem(path):
     from .cameras import get_camera_parameters
     z = np.load(path, allow_pickle=False)
+    version = int(z["format_version"]) if "format_version" in z.files else 1
+    if version != SNAPSHOT_VERSION:
+        raise ValueError("%s is a problem snapshot of format %d, this build reads format %d: re-save it with "
+                         "gipuma_amd.problem.save_problem" % (path, version, SNAPSHOT_VERSION))
     cs = get_camera_parameters([p for p in z["P"]], cam_scale=float(z["cam_scale"]))
     ap = AlgorithmParameters()
     for k, v in _params_from_json(str(z["params"][0])).items():

@@ -30,7 +30,10 @@
 #define __device__
 #define __global__
 #define __host__
-#define __shared__
+/* a block's shared memory, its thread / block index and its barrier pass belong to the host thread that runs the
+ * block: the harness runs the blocks of a launch under OpenMP (they are independent: a launch only writes pixels
+ * of its own colour and reads the other's) */
+#define __shared__ thread_local
 #define __constant__
 #define __managed__
 #define __forceinline__ inline __attribute__((always_inline))
@@ -45,11 +48,11 @@ struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c 
 static inline float4 make_float4(float x, float y, float z, float w) { float4 r = {x, y, z, w}; return r; }
 static inline int2 make_int2(int x, int y) { int2 r = {x, y}; return r; }
 
-extern uint3 threadIdx, blockIdx;
-extern dim3 blockDim, gridDim;
+extern thread_local uint3 threadIdx, blockIdx;
+extern dim3 blockDim, gridDim; /* launch constants */
 /* block-level barrier: the harness runs every block twice; in pass 0 each thread stops at the
  * barrier (after loading its slice of the shared tile), in pass 1 it runs through */
-extern int ref_pass;
+extern thread_local int ref_pass;
 #define __syncthreads() do { if (ref_pass == 0) return; } while (0)
 
 /* ---- math under --use_fast_math (numerical model M2) ---- */

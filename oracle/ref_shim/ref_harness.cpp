@@ -9,15 +9,16 @@
  */
 #include "../../include/gipuma_hip.h"
 
+#include <omp.h>
 #include <time.h>
 
-uint3 threadIdx, blockIdx;
+thread_local uint3 threadIdx, blockIdx;
 dim3 blockDim, gridDim;
-int ref_pass = 1;
+thread_local int ref_pass = 1;
 RefTexture ref_textures[MAX_IMAGES];
 int ref_tex_mode = 0;
 unsigned ref_seed = 1, ref_phase = 0;
-unsigned char my_smem[256 * 1024] __attribute__((aligned(16)));
+thread_local unsigned char my_smem[64 * 1024] __attribute__((aligned(16))); /* (32 + 2*13)^2 float4 texels at most: box <= 25 */
 /* optional window of 32x32-pixel blocks (timing on a bounded sample): [bx0,bx1) x [by0,by1), -1 = all */
 static int g_wbx0 = -1, g_wbx1 = -1, g_wby0 = -1, g_wby1 = -1;
 
@@ -117,8 +118,9 @@ static void launch_colour(colour_kernel k, int it)
     gridDim = dim3((cols + 31) / 32, ((rows / 2) + 15) / 16, 1);
     const int bx0 = g_wbx0 < 0 ? 0 : g_wbx0, bx1 = g_wbx0 < 0 ? (int)gridDim.x : g_wbx1;
     const int by0 = g_wbx0 < 0 ? 0 : g_wby0, by1 = g_wbx0 < 0 ? (int)gridDim.y : g_wby1;
-    /* (single host thread: the device code keeps its block state in globals; bench.py runs one
-     *  process per core on disjoint windows for the all-cores figure) */
+    /* the blocks of a launch are independent; block state (threadIdx, blockIdx, the barrier pass, the shared tile)
+     * is thread_local (ref_cuda_on_cpu.h), the tile-size globals and gridDim / blockDim are launch constants */
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
     for (int by = by0; by < by1; by++)
         for (int bx = bx0; bx < bx1; bx++) {
             blockIdx.x = (unsigned)bx; blockIdx.y = (unsigned)by; blockIdx.z = 0;
@@ -142,6 +144,7 @@ static void launch_dense(void (*k)(GlobalState &))
     /* a 32x32 block of the colour kernels = 2x2 blocks here */
     const int bx0 = g_wbx0 < 0 ? 0 : 2 * g_wbx0, bx1 = g_wbx0 < 0 ? (int)gridDim.x : min(2 * g_wbx1, (int)gridDim.x);
     const int by0 = g_wbx0 < 0 ? 0 : 2 * g_wby0, by1 = g_wbx0 < 0 ? (int)gridDim.y : min(2 * g_wby1, (int)gridDim.y);
+#pragma omp parallel for collapse(2) schedule(dynamic, 4)
     for (int by = by0; by < by1; by++)
         for (int bx = bx0; bx < bx1; bx++) {
             ref_pass = 1;
@@ -221,7 +224,8 @@ static double ref_now(void)
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
-int ref_num_threads(void) { return 1; }
+int ref_num_threads(void) { return omp_get_max_threads(); }
+void ref_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 int ref_init_planes(void);
 int ref_sweep(int iteration, int colour, unsigned stages);
 /* cpu_baseline leg of bench.py: the reference's init kernel and one iteration (6 launches) of its

@@ -1,4 +1,5 @@
 #!/bin/sh
+export GIPUMA_HIP_EXPERIMENTS=1  # the library reads its A/B switches only under this one
 # build a differently configured library for A/B runs (loaded through GIPUMA_HIP_LIB):
 #   sh scripts/build_variant.sh <name> [-DFLAG ...]   ->  gipuma_amd/csrc/variants/libgipuma_hip_<name>.so
 R=$(cd "$(dirname "$0")/.." && pwd)

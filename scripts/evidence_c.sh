@@ -1,4 +1,5 @@
 #!/bin/sh
+export GIPUMA_HIP_EXPERIMENTS=1  # the library reads its A/B switches only under this one
 # config-C evidence only: kernel trace + per-launch series, PMC passes, the default bench line
 #   sh scripts/evidence_c.sh   ->  gpurun_out/final/
 R=${GRAFT_REPO_ROOT:-$(pwd)}

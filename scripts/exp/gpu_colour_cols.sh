@@ -1,4 +1,5 @@
 #!/bin/sh
+export GIPUMA_HIP_EXPERIMENTS=1  # the library reads its A/B switches only under this one
 # colour column-per-lane kernels: parity tests, then A/B timing
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/ccols

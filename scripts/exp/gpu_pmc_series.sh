@@ -1,4 +1,5 @@
 #!/bin/sh
+export GIPUMA_HIP_EXPERIMENTS=1  # the library reads its A/B switches only under this one
 # per-launch PMC series of one kernel: sh scripts/exp/gpu_pmc_series.sh <name> <kernel-substring> [ENV=VAL ...]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 NAME=$1; SUB=$2; shift; shift

@@ -1,4 +1,5 @@
 #!/bin/sh
+export GIPUMA_HIP_EXPERIMENTS=1  # the library reads its A/B switches only under this one
 # first GPU check of the push kernel: parity tests, then A/B timing on config C
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/push1

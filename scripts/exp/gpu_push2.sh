@@ -1,4 +1,5 @@
 #!/bin/sh
+export GIPUMA_HIP_EXPERIMENTS=1  # the library reads its A/B switches only under this one
 # push kernel on boxes 11 / 25: parity tests, then A/B timing on configs D, B and the generic loop on C
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/push2

@@ -1,4 +1,5 @@
 #!/bin/sh
+export GIPUMA_HIP_EXPERIMENTS=1  # the library reads its A/B switches only under this one
 # PMC passes over the push kernel's dispatches of one config-C view (every half-sweep pushed), per dispatch
 #   sh scripts/gpu_push_pmc.sh <name> [ENV=VAL ...]
 R=${GRAFT_REPO_ROOT:-$(pwd)}

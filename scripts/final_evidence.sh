@@ -1,4 +1,5 @@
 #!/bin/sh
+export GIPUMA_HIP_EXPERIMENTS=1  # the library reads its A/B switches only under this one
 # One gpurun call that regenerates the round's evidence: kernel trace + per-launch series, PMC passes,
 # bench lines for config C (default, with CPU baselines and extras), B, D and colour.
 #   sh scripts/final_evidence.sh   ->  gpurun_out/final/

@@ -1,4 +1,5 @@
 #!/bin/sh
+export GIPUMA_HIP_EXPERIMENTS=1  # the library reads its A/B switches only under this one
 # A/B runs of bench.py on the GPU box: each line of stdin is "<label> <ENV=VAL ...>"; prints the
 # bench JSON's value / ms and the last step's per-launch times.   sh scripts/gpu_ab.sh [bench args] < list
 R=${GRAFT_REPO_ROOT:-$(pwd)}

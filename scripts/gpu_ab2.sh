@@ -1,4 +1,5 @@
 #!/bin/sh
+export GIPUMA_HIP_EXPERIMENTS=1  # the library reads its A/B switches only under this one
 # like gpu_ab.sh, but each line of stdin is "<label> [bench args and ENV=VAL ...]" (words containing '=' and no
 # leading '-' go to the environment, the rest to bench.py)
 R=${GRAFT_REPO_ROOT:-$(pwd)}

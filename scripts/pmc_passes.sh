@@ -1,4 +1,5 @@
 #!/bin/sh
+export GIPUMA_HIP_EXPERIMENTS=1  # the library reads its A/B switches only under this one
 # Collect PMC passes for the PatchMatch kernels only, one rocprofv3 run per counter group
 # (counters only with --kernel-trace; never together with sys/hip/hsa tracing), summarise on the
 # box and keep just the small JSON (the rocpd databases are deleted: gpurun copies back <= 64 MiB).

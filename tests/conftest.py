@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# the library reads its A/B switches (GIPUMA_HIP_TUNE, ..._LB_K, ...: the knobs the exactness tests turn) only
+# when this one is set; a production process never sets it
+os.environ["GIPUMA_HIP_EXPERIMENTS"] = "1"
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

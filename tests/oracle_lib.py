@@ -36,12 +36,17 @@ def _granted_cores():
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(ORACLE_SO):
+        # always through make (incremental): a library left by an earlier checkout may lack newer symbols
+        try:
             build()
+        except (OSError, subprocess.CalledProcessError):
+            if not os.path.exists(ORACLE_SO):
+                raise
         L = C.CDLL(ORACLE_SO)
         if "OMP_NUM_THREADS" not in os.environ:  # (libgomp may be loaded already: set it through the library)
-            L.gipuma_oracle_set_threads.argtypes = [C.c_int]
-            L.gipuma_oracle_set_threads(_granted_cores())
+            if hasattr(L, "gipuma_oracle_set_threads"):
+                L.gipuma_oracle_set_threads.argtypes = [C.c_int]
+                L.gipuma_oracle_set_threads(_granted_cores())
         D = C.POINTER(abi.Desc)
         L.gipuma_oracle_run.argtypes = [D, _FP, _FP, C.c_int]
         L.gipuma_oracle_init_planes.argtypes = [D, _FP, _FP]

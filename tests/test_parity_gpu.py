@@ -240,14 +240,13 @@ def test_image_cache_is_pinned_by_live_sessions(hip):
 
 @pytest.mark.parametrize("tune", [1 << 30, 1 << 29, 1 << 28, (1 << 30) | (1 << 28), 1 << 27, 1 << 26,
                                   (1 << 26) | (1 << 29), 1 << 23, 1 << 25, (1 << 25) | (1 << 27),
-                                  (1 << 27) | (1 << 25), 1 << 19, (1 << 19) | (1 << 27), 1 << 22,
-                                  (1 << 22) | (1 << 27)])
+                                  (1 << 27) | (1 << 25), 1 << 19, (1 << 19) | (1 << 27)])
 def test_kernel_variants_are_bit_identical(hip, tune):
     """the performance-only choices of the sweep kernels -- float-encoded window offsets + the
     hand-pipelined loop (off: bit 30), task order owner-major (bit 29) / source-major (bit 28) in
     every iteration instead of switching after iteration 1, the column-per-lane kernel never (bit
     27) / in every half-sweep (bit 26) instead of the first four, the history skip rule off (bit
-    23), skip rule (S) off (bit 22), early termination of view costs off (bit 25), refinement
+    23), early termination of view costs off (bit 25), refinement
     bounded per wavefront instead of per (candidate, view) item (bit 19: pm::refine_two_phase off) -- must
     not change a single bit.
     Box 15 (the pipelined and column-per-lane instantiations), 4 iterations so that the default run
@@ -1091,37 +1090,6 @@ def test_inconsistent_installed_costs_are_not_trusted(hip, tiny_problem):
                     # exactly what rule (A) would have missed had it trusted the installed costs
                     kept = (bits(before_n4) == bits(o.norm4)).all(-1)
                     assert (kept & (before_c != o.cost)).sum() > 50
-
-
-def test_seen_rule_is_reset_when_planes_are_installed(hip):
-    """skip rule (S) -- a plane a pixel's propagation evaluated before can never be accepted, because the
-    pixel's cost only decreases -- must forget its rings when the caller installs state: after two
-    iterations every stored cost is RAISED through gipuma_hip_set_state (planes unchanged), so planes
-    turned down before are acceptable again; the oracle, which always evaluates, adopts many of them."""
-    gs, _ = synth.build_problem(synth.tiny_config(cols=96, rows=64, n_src=3, blocksize=11, iterations=4, n_best=2))
-    o = OracleState(gs)
-    o.init_planes()
-    with Session(gs) as s:
-        s.init_planes()
-        for it in range(2):
-            for colour in (abi.BLACK, abi.RED):
-                s.sweep(it, colour)
-                o.sweep(it, colour)
-        n4, c = s.get_state()
-        assert_same(n4, o.norm4, "before the install, norm4")
-        o.cost[:] = o.cost * np.float32(4.0) + np.float32(1.0)
-        s.set_state(o.norm4, o.cost)
-        changed = 0
-        for it in range(2, 4):
-            for colour in (abi.BLACK, abi.RED):
-                before = o.norm4.copy()
-                s.sweep(it, colour, abi.STAGE_CLOSE | abi.STAGE_FAR)
-                o.sweep(it, colour, abi.STAGE_CLOSE | abi.STAGE_FAR)
-                n4, c = s.get_state()
-                assert_same(n4, o.norm4, "after the install, it %d colour %d norm4" % (it, colour))
-                assert_same(c, o.cost, "after the install, it %d colour %d cost" % (it, colour))
-                changed += int((bits(before) != bits(o.norm4)).any(-1).sum())
-        assert changed > 500  # the scenario bites: propagation alone re-adopts planes
 
 
 def test_shared_planes_with_consistent_costs(hip, tiny_problem):
