@@ -956,6 +956,13 @@ int gipuma_hip_solve(gipuma_hip_session *s, gipuma_hip_timing *timing)
                 for (int k = 0; k < 6; k++) fprintf(stderr, " %llu", h[62 * pm::kDbgSlots + k]);
                 fprintf(stderr, "\n");
             }
+            if (h[61 * pm::kDbgSlots + 0]) {  // pm::group_kernel's batches, summed over the solve's launches
+                const double nb = (double)h[61 * pm::kDbgSlots + 0], nt = (double)h[61 * pm::kDbgSlots + 7];
+                fprintf(stderr, "gipuma_hip group_kernel batches: %.1f per tile; per batch %.1f strips, %.1f tasks, %.2f groups, "
+                                "%.2f rows; per tile %.1f groups, %.1f tasks\n", nb / nt, h[61 * pm::kDbgSlots + 1] / nb,
+                        h[61 * pm::kDbgSlots + 2] / nb, h[61 * pm::kDbgSlots + 3] / nb, h[61 * pm::kDbgSlots + 4] / nb,
+                        h[61 * pm::kDbgSlots + 5] / nt, h[61 * pm::kDbgSlots + 6] / nt);
+            }
             for (int k = 0; k < 6; k++) {
                 fprintf(stderr, "gipuma_hip counts %s:", names[k]);
                 for (int ph = 1; ph <= 2 * s->iterations && ph < 64; ph++)

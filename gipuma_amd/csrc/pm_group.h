@@ -3,7 +3,7 @@
 // What it replaces: the cost evaluations inside gipuma_checkerboard_spatialPropClose_cu / ...Far_cu
 // (reference gipuma.cu:1471-1588, 1353-1468; pmCostMultiview_cu :720-806 at :865-872) of the half-sweep that
 // follows, for the half-sweeps in which pm::push_kernel (pm_push.h) no longer pays.  The accept tests stay with
-// the consumer (sweep_replay in pm_device.h, Tune::kPushConsume), exactly as with pm::push_kernel.
+// the consumer (sweep_replay in pm_sweep.h, Tune::kPushConsume), exactly as with pm::push_kernel.
 //
 // Observation (exact, as in pm_push.h).  The patch cost of plane pi at pixel p in view v is
 //     c_v(p, pi) = sum over the window samples q = p + (2i-R, 2j-R) of  w(p, q) * dis_v(q, pi)
@@ -11,7 +11,7 @@
 // first half-sweeps a plane that fits a surface patch has spread over it: the SAME plane, bit for bit, is the
 // candidate of many pixels of a tile at once (it is held by several neighbours, each offering it to its up to
 // eight consumers), and the windows of those pixels overlap.  On config C the candidates a tile still has to
-// evaluate (after the skip rules (A), (D), (H), (S) of sweep_kernel) fall into groups of on average 5 with one
+// evaluate (after the skip rules (A), (D), (H) of sweep_kernel) fall into groups of on average 5 with one
 // plane and one sample lattice, whose windows cover 0.31-0.38 of the samples the tasks have one by one
 // (scripts/exp/et_stats.py, profiles/r02_exp_sharing_stats_cpu.txt).
 //
@@ -24,17 +24,29 @@
 //           view_cost_pipe (same X0/Y0/Z0 per column, same fmaf per row: the same bits) and leaves dis in LDS;
 //   chain   one lane per task then runs the reference's 64-term fmaf chain over ITS window -- its own support
 //           weights, the reference's order -- and feeds the view cost to its ViewCombiner.
-// Groups are processed in super-batches -- as many consecutive groups as the sample buffer (38 KB), five strips
-// and two tasks per lane allow --; per super-batch the views are looped outside (all its strips for a view, a
-// barrier, all its chains, a barrier), so a task's combiner stays in its lane's registers.  The aggregate goes to
-// Problem::push_cost[slot][pixel],
-// where the half-sweep finds it (Tune::kPushConsume); candidates the skip rules removed get MAXCOST there,
-// which the strict < of the accept test (gipuma.cu:868) rejects like their true cost would be.
+// Round 3's version looped super-batches of groups with two workgroup barriers per view and lost to the fused
+// kernel (its strips, 8-15 samples long and of mixed length inside a wavefront, ran at a third of the fused loop's
+// issue rate; its chain phase was bound by three dependent LDS reads per term).  This version has NO workgroup
+// barrier after the set-up:
+//   * the groups are sorted by strip length, so the strips a wavefront walks together are equally long;
+//   * a BATCH -- a run of consecutive groups: at most kGrpBatchGroups groups, 64 strips, 32 tasks, kGrpBatchSamples
+//     samples per view -- belongs to ONE wavefront, which takes it from a shared cursor; strips
+//     and chains of a batch only meet inside that wavefront (LDS operations of a wavefront complete in order);
+//   * per view a lane walks its strips in one continuous software pipeline (the windows of sample s+2 requested
+//     before sample s is reduced, across strip boundaries), and the first two windows of the NEXT view are requested
+//     before the chain phase of this one, so their latency hides behind it;
+//   * the 64 support weights of a task depend on its pixel alone: they are computed once per batch and stay in
+//     registers, half a window per lane (two lanes per task: the first sums the left window columns and hands its
+//     partial sum to the second); a chain term is one LDS read and one fmaf;
+//   * the homographies of a batch's (group, view) pairs are computed eight views at a time, one pair per lane;
+//   * 50 KB of LDS and at most 168 registers: three workgroups per CU.
+// The aggregate goes to Problem::push_cost[slot][pixel], where the half-sweep finds it (Tune::kPushConsume);
+// candidates the skip rules removed get MAXCOST there, which the strict < of the accept test (gipuma.cu:868)
+// rejects like their true cost would be.
 // Same terms, same order, same roundings as view_cost_pipe + multiview_cost: bit-identical.
 //
 // Supported: gray window-packed planes with float-encoded offsets, box 11 / 15, best-N with n_best <= 4.
-// OPT-IN (GIPUMA_HIP_GROUP_FROM): it halves the propagation stage's instructions and is still slower than the fused
-// kernel's propagation rounds (phase clocks).  GIPUMA_HIP_COUNTS=1 reports its phase clocks.
+// GIPUMA_HIP_COUNTS=1 reports its phase clocks.
 #pragma once
 #include "pm_device.h"
 
@@ -43,40 +55,52 @@ namespace pm {
 constexpr int kGrpMaxTasks = 8 * kThreads;  // 2048
 constexpr int kGrpHashSize = 2048;
 
-constexpr int kSbGroups = 128;       // groups per super-batch
-constexpr int kSbStripsPerLane = 5;  // strips (sample columns) per lane and view
-constexpr int kSbTasksPerLane = 2;   // tasks per lane (their combiners live in registers across the view loop; 4: 256 VGPRs and scratch)
+constexpr int kGrpBatchStrips = 64;    // one strip per lane
+#ifndef PM_GROUP_TASK_LANES
+#define PM_GROUP_TASK_LANES 1
+#endif
+constexpr int kGrpTaskLanes = PM_GROUP_TASK_LANES;   // lanes per task in the chains: 1 (64 weights per lane) or 2 (32)
+constexpr int kGrpBatchTasks = 64 / kGrpTaskLanes;
+constexpr int kGrpBatchGroups = 8;     // (a group has at least 6 strips)
+constexpr int kGrpBatchSamples = 768;  // dis values of one view a wavefront's LDS slice holds
+constexpr int kGrpViewsPerH = 8;       // homographies are prepared this many views at a time: 8 groups x 8 views = 64 lanes
+#ifndef PM_GROUP_WG
+#define PM_GROUP_WG 3  // workgroups per CU the kernel is compiled for (3: 168 VGPRs)
+#endif
 
 template <int BOX>
 struct GroupLayout {  // offsets in 32-bit words into the dynamic LDS array
     static_assert(BOX == 11 || BOX == 15, "instantiated window sizes");
     static constexpr int R = (BOX - 1) / 2, N = R + 1;
+    static_assert(N % 2 == 0, "a task's window columns are split between two lanes");
     static constexpr int tw = kTileW + 2 * N, th = kSweepTileH + 2 * N;
     static constexpr int max_rows = N + (kSweepTileH - 1) / 2;  // samples per strip: 8 + 7 = 15 for box 15
-    static constexpr int max_strips = kSbStripsPerLane * kThreads, max_tasks = kSbTasksPerLane * kThreads;
-    // sweep_read_state stages the float4 tile of the sweep kernels at [kLutSize, kLutSize + 4 tw th) and its scalar
-    // staging plane -- I alone, clamp-to-edge point samples -- right behind it.  This kernel keeps the PLANE (the
-    // gradients are two subtractions per sample, the ones stage_tile does) and puts its tables where the float4
-    // tile was.
-    static constexpr int meta = kLutSize;                    // [2048 groups][2]: task0 | count << 11 ; rep | bbox << 11
-    static constexpr int plane = kLutSize + 4 * tw * th;     // [th][tw] reference texels
-    static_assert(meta + 2 * kGrpMaxTasks <= plane, "the group table fits where the float4 tile was");
-    // the two task lists: in front of the plane too where there is room (box 15), else behind it
-    static constexpr bool lists_in_front = meta + 2 * kGrpMaxTasks + kGrpMaxTasks <= plane;
-    static constexpr int btask = lists_in_front ? meta + 2 * kGrpMaxTasks : plane + tw * th;  // [2048] u16: owner | slot << 8
-    static constexpr int sorted = btask + kGrpMaxTasks / 2;  // [2048] u16: task indices ordered by group
-    static constexpr int misc = (lists_in_front ? plane + tw * th : sorted + kGrpMaxTasks / 2);  // counters
-    static constexpr int gtab = misc + 128;                  // [kSbGroups + 1][4]: first strip, first task, first sample of a group
-    static constexpr int gplane = gtab + 4 * (kSbGroups + 1);  // [kSbGroups] float4: the planes of the super-batch's groups
-    static constexpr int hbuf = gplane + 4 * kSbGroups;      // [kSbGroups][10]: homography + fast-reciprocal flag
-    static constexpr int sgroup = hbuf + 10 * kSbGroups;     // [max_strips] u8: group (within the super-batch) of a strip
-    static constexpr int tgroup = sgroup + max_strips / 4;   // [max_tasks] u8: ... of a task
-    static constexpr int dis = tgroup + max_tasks / 4;       // the sample buffer; while grouping: hash table + group ids
-    static constexpr int total = (80 * 1024) / 4;            // two workgroups per CU
-    static constexpr int capacity = total - dis;             // samples (of one view) a super-batch may hold
-    static_assert(kGrpHashSize + kGrpMaxTasks / 2 <= capacity, "hash table + group ids alias the sample buffer");
-    static_assert(capacity >= (N + 15) * max_rows, "the largest possible group fits the sample buffer");
-    static_assert(capacity < 65536, "sample offsets fit 16 bits");
+    static constexpr int max_cols = N + (kTileW - 1) / 2;       // strips per group: 8 + 15 = 23
+    // sweep_read_state<.., PLANE_ONLY> stages the scalar plane of reference texels -- clamp-to-edge point samples --
+    // right behind the weight table; the gradients are two subtractions per sample, the ones stage_tile does
+    static constexpr int plane = kLutSize;                  // [th][tw]
+    static constexpr int misc = plane + tw * th;            // counters
+    static constexpr int meta = misc + 128;                 // [2048] per group: first task | min lx << 11 | min ly << 16 | (ncols - N) << 20 | (nrows - N) << 24
+    static constexpr int sbt = meta + kGrpMaxTasks + 4;     // [2048] u16: the tasks (owner | slot << 8) ordered by group
+    static constexpr int gorder = sbt + kGrpMaxTasks / 2;   // [2048] u16: group ids ordered by strip length
+    // per wavefront: the tables, homographies and samples of the batch it is working on
+    static constexpr int w_tab = 0;                                   // [kGrpBatchGroups][4] u16: group id, first strip, first task
+    static constexpr int w_sgroup = w_tab + 2 * kGrpBatchGroups;      // [kGrpBatchStrips] u8: group (in the batch) of a strip
+    static constexpr int w_tgroup = w_sgroup + kGrpBatchStrips / 4;   // [kGrpBatchTasks] u8: ... of a task
+    static constexpr int w_gplane = w_tgroup + 16;                    // [kGrpBatchGroups] float4  (64 bytes for tgroup)
+    static constexpr int w_hbuf = w_gplane + 4 * kGrpBatchGroups;     // [kGrpViewsPerH][kGrpBatchGroups][12]: H, fast flag
+    static constexpr int w_dis = w_hbuf + kGrpViewsPerH * kGrpBatchGroups * 12;  // [kGrpBatchSamples]
+    static constexpr int w_stride = w_dis + kGrpBatchSamples;
+    static constexpr int waves = gorder + kGrpMaxTasks / 2;  // [4] of the above
+    static constexpr int total = waves + 4 * w_stride;
+    // while grouping, the wavefronts' areas hold: hash table | group id of a task (u16) | task list (u16) | counters
+    static constexpr int g_hash = waves, g_gid = g_hash + kGrpHashSize, g_btask = g_gid + kGrpMaxTasks / 2,
+                         g_cnt = g_btask + kGrpMaxTasks / 2;
+    static_assert(g_cnt + kGrpMaxTasks <= total, "the grouping tables alias the per-wavefront areas");
+    static_assert(kGrpBatchSamples >= max_cols * ((max_rows + 1) & ~1), "the largest possible group fits a wavefront's sample buffer");
+    static_assert(kGrpBatchStrips >= max_cols, "the strips of the largest possible group fit the lanes");
+    static_assert(total * 4 * PM_GROUP_WG <= 160 * 1024, "workgroups per CU");
+    static_assert((w_gplane % 4) == 0 && (w_hbuf % 4) == 0 && (waves % 4) == 0 && (w_stride % 4) == 0, "16-byte aligned float4 tables");
 };
 
 __device__ __forceinline__ uint32_t plane_hash(float4 pl, int cls)
@@ -89,28 +113,77 @@ __device__ __forceinline__ uint32_t plane_hash(float4 pl, int cls)
     return (h + (uint32_t)cls) & (kGrpHashSize - 1);
 }
 
-// dis of the samples (qx, qy0 + 2 r), r = 0 .. nrows - 1, of one view: the per-sample arithmetic of
-// view_cost_pipe (getCorrespondingPoint_cu :207-217, the five bilinear taps :251-253, pmCostComputation_shared
-// :254-274) without the weight and the accumulation.  `tcol` points at the reference texel of (qx, qy0) in the
-// scalar plane (row length tw).
-template <bool FAST>
-__device__ __forceinline__ void group_strip(const Problem *__restrict__ P, gptr_bytes magic_base,
-                                            const float *__restrict__ H, const float *__restrict__ tcol, int tw,
-                                            float qx, float qy0, int nrows, float *__restrict__ out)
-{
-    const float colsf = (float)P->cols, rowsf = (float)P->rows;
-    const float alpha = P->alpha, oma = 1.f - P->alpha;
-    const float tau_color = P->tau_color, tau_gradient = P->tau_gradient;
-    const float pwf = (float)P->pw;
-    const float magic_c = kMagicF + (float)(2 * P->pw + 2);
-    const float H1 = H[1], H4 = H[4], H7 = H[7];
-    const float X0 = __builtin_fmaf(H[0], qx, H[2]);
-    const float Y0 = __builtin_fmaf(H[3], qx, H[5]);
-    const float Z0 = __builtin_fmaf(H[6], qx, H[8]);
-    auto request = [&](float qy) -> WinReq {
-        const float X = __builtin_fmaf(H1, qy, X0);
-        const float Y = __builtin_fmaf(H4, qy, Y0);
-        const float Z = __builtin_fmaf(H7, qy, Z0);
+// One strip of one view for the walk below: the per-column terms of view_cost_pipe (X0, Y0, Z0 of getCorrespondingPoint_cu,
+// gipuma.cu:207-217) and the row coefficients of the view's homography
+struct StripView {
+    float X0, Y0, Z0, H1, H4, H7;
+};
+// the twelve texels of a 4x4 window the five taps read (corners unused), t<row><col>
+struct Tex12 {
+    float t01, t02, t10, t11, t12, t13, t20, t21, t22, t23, t31, t32;
+};
+
+// The strip of one lane for one view.  Per sample the arithmetic is view_cost_pipe's (getCorrespondingPoint_cu
+// :207-217, the five bilinear taps :251-253, pmCostComputation_shared :254-274) without the weight and the
+// accumulation; {I, gx1, gy1} of the reference texel are formed from the scalar plane as stage_tile forms them
+// (gipuma.cu:254-259: central differences).
+//
+// The rows of the strip are dealt alternately to two register sets.  A set's step: convert the twelve texels of
+// the window it holds, THEN request the window of its next row (two rows further) into the registers just freed,
+// then reduce the converted texels.  Every load so has the rest of its own step and the other set's whole step to
+// arrive, and the loop needs no register rotation although its trip count is not a compile-time constant.  Every
+// path through the walk has a fixed number of loads in flight, so the waits the compiler inserts are exact.
+template <int BOX>
+struct GroupWalk {
+    using LY = GroupLayout<BOX>;
+    static constexpr int tw = LY::tw;
+    float colsf, rowsf, pwf, magic_c, alpha, oma, tau_color, tau_gradient;  // wave-uniform
+    // this lane's strip: first sample point, reference texel of that point in the plane, where its dis values go,
+    // and its group's slot in the batch tables
+    float qx, qy0;
+    const float *tcol;
+    float *out;
+    int grp;
+
+    struct Set {  // one of the two register sets
+        float qy;          // sample row of its next request
+        const float *tq;   // reference texel of the row it holds
+        float *o;          // where that row's dis goes
+        WinReq req;        // the window it holds (or that is on its way)
+    };
+
+    __device__ __forceinline__ void init(const Problem *__restrict__ P)
+    {
+        colsf = (float)P->cols;
+        rowsf = (float)P->rows;
+        pwf = (float)P->pw;
+        magic_c = kMagicF + (float)(2 * P->pw + 2);
+        alpha = P->alpha;
+        oma = 1.f - P->alpha;
+        tau_color = P->tau_color;
+        tau_gradient = P->tau_gradient;
+    }
+    __device__ __forceinline__ StripView view_of(const float *__restrict__ hb) const
+    {
+        // hb: [kGrpBatchGroups][12] of the view; three 16-byte reads
+        const float4 a = *reinterpret_cast<const float4 *>(hb + 12 * grp);
+        const float4 b = *reinterpret_cast<const float4 *>(hb + 12 * grp + 4);
+        const float4 c = *reinterpret_cast<const float4 *>(hb + 12 * grp + 8);
+        StripView s;
+        s.X0 = __builtin_fmaf(a.x, qx, a.z);  // H0 qx + H2
+        s.Y0 = __builtin_fmaf(a.w, qx, b.y);  // H3 qx + H5
+        s.Z0 = __builtin_fmaf(b.z, qx, c.x);  // H6 qx + H8
+        s.H1 = a.y;
+        s.H4 = b.x;
+        s.H7 = b.w;
+        return s;
+    }
+    template <bool FAST>
+    __device__ __forceinline__ WinReq request(gptr_bytes magic_base, const StripView &s, float qy) const
+    {
+        const float X = __builtin_fmaf(s.H1, qy, s.X0);
+        const float Y = __builtin_fmaf(s.H4, qy, s.Y0);
+        const float Z = __builtin_fmaf(s.H7, qy, s.Z0);
         const float rz = recip<FAST>(Z);
         const float sx = X * rz, sy = Y * rz;
         const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
@@ -122,43 +195,92 @@ __device__ __forceinline__ void group_strip(const Problem *__restrict__ P, gptr_
         const uint32_t off = __float_as_uint(__builtin_fmaf(Yc, pwf, Xc + magic_c));
         r.w = *(gptr_u32x4)(magic_base + off);
         return r;
-    };
-    // (the two requests past the last sample fetch valid, clamped addresses and are dropped)
-    WinReq r0 = request(qy0), r1 = request(qy0 + 2.0f);
-    float qy = qy0 + 4.0f;
-    for (int r = 0; r < nrows; r++, qy += 2.0f) {
-        const WinReq cur = r0;
-        r0 = r1;
-        r1 = request(qy);
-        __builtin_amdgcn_sched_barrier(0);
-        // {I, gx1, gy1} of the reference texel as stage_tile forms them (gipuma.cu:254-259): central differences
-        const float *tq = tcol + 2 * r * tw;
-        const float I = tq[0];
-        const float gx1 = tq[1] - tq[-1];
-        const float gy1 = tq[tw] - tq[-tw];
-        const Taps tp5 = taps_u8(cur.a, cur.b, cur.w.x, cur.w.y, cur.w.z, cur.w.w);
+    }
+    // window words w0..w3 = columns X..X+3, byte r = row Y+r (taps_u8)
+    static __device__ __forceinline__ Tex12 unpack(const u32x4_a4 &w)
+    {
+        Tex12 t;
+        t.t01 = ub0(w.y); t.t02 = ub0(w.z);
+        t.t10 = ub1(w.x); t.t11 = ub1(w.y); t.t12 = ub1(w.z); t.t13 = ub1(w.w);
+        t.t20 = ub2(w.x); t.t21 = ub2(w.y); t.t22 = ub2(w.z); t.t23 = ub2(w.w);
+        t.t31 = ub3(w.y); t.t32 = ub3(w.z);
+        return t;
+    }
+    // (I: the reference texel of the sample; xr, xl, yd, yu: its right / left / lower / upper neighbours)
+    __device__ __forceinline__ void reduce(const Tex12 &t, float a, float b, float I, float xr, float xl, float yd,
+                                           float yu, float *__restrict__ o) const
+    {
+        const float gx1 = xr - xl;
+        const float gy1 = yd - yu;
+        const Taps tp5 = taps12(a, b, t.t01, t.t02, t.t10, t.t11, t.t12, t.t13, t.t20, t.t21, t.t22, t.t23, t.t31, t.t32);
         const float colDiff = I - tp5.sc;
         const float gradX = gx1 - tp5.gx2;
         const float gradY = gy1 - tp5.gy2;
         const float gradDis = min_nc((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
         const float colDis = min_abs_nc(colDiff, tau_color);
-        out[r] = __builtin_fmaf(alpha, gradDis, oma * colDis);
+        *o = __builtin_fmaf(alpha, gradDis, oma * colDis);
+    }
+    // the first two window requests of a view (rows 0 and 1)
+    template <bool FAST>
+    __device__ __forceinline__ void first(gptr_bytes magic_base, const float *__restrict__ hb, StripView &sv, Set &A,
+                                          Set &B) const
+    {
+        sv = view_of(hb);
+        A.req = request<FAST>(magic_base, sv, qy0);
+        B.req = request<FAST>(magic_base, sv, qy0 + 2.0f);
+        A.qy = qy0 + 4.0f;
+        B.qy = qy0 + 6.0f;
+        A.tq = tcol;
+        B.tq = tcol + 2 * tw;
+        A.o = out;
+        B.o = out + 1;
+    }
+    // A step of a set: convert the window it holds, request its next one (two rows further) unless LAST, reduce.
+    template <bool FAST, bool LAST>
+    __device__ __forceinline__ void step(gptr_bytes magic_base, const StripView &sv, Set &S) const
+    {
+        const float *tq = S.tq;
+        float *o = S.o;
+        // (the reference texels first: their LDS latency passes during the conversions and the request)
+        const float I = tq[0], xr = tq[1], xl = tq[-1], yd = tq[tw], yu = tq[-tw];
+        const Tex12 t = unpack(S.req.w);
+        const float a = S.req.a, b = S.req.b;
+        __builtin_amdgcn_sched_barrier(0);
+        if (!LAST) {
+            S.req = request<FAST>(magic_base, sv, S.qy);
+            S.qy += 4.0f;
+            S.tq = tq + 4 * tw;
+            S.o = o + 2;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        reduce(t, a, b, I, xr, xl, yd, yu, o);
         __builtin_amdgcn_sched_barrier(0);
     }
-}
-
+    // the nr rows (even, wave-uniform) of this lane's strip for the view whose first two requests are in (A, B):
+    // A walks the even rows, B the odd ones; nothing is in flight at the end
+    template <bool FAST>
+    __device__ __forceinline__ void body(gptr_bytes magic_base, int nr, const StripView &sv, Set &A, Set &B) const
+    {
+        for (int r = 0; r < nr - 2; r += 2) {
+            step<FAST, false>(magic_base, sv, A);
+            step<FAST, false>(magic_base, sv, B);
+        }
+        step<FAST, true>(magic_base, sv, A);
+        step<FAST, true>(magic_base, sv, B);
+    }
+};
 
 // grid = tiles of the sweep kernels; `colour`: the colour about to be swept (the consumers); `hist`: rule (H) is
 // valid for that half-sweep (the consumer replays only the slots whose producer changed)
 template <int BOX>
-__global__ __launch_bounds__(kThreads, 2) void group_kernel(const Problem *__restrict__ P,
+__global__ __launch_bounds__(kThreads, PM_GROUP_WG) void group_kernel(const Problem *__restrict__ P,
                                                                       const float4 *__restrict__ norm4,
                                                                       const float *__restrict__ cost, int colour,
                                                                       int hist, unsigned tune)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using LY = GroupLayout<BOX>;
-    constexpr int R = LY::R, N = LY::N, tw = LY::tw;
+    constexpr int R = LY::R, N = LY::N, tw = LY::tw, NH = N / kGrpTaskLanes;  // window columns per chain lane
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rows = P->rows, cols = P->cols, n = P->n_sel;
     const size_t np = (size_t)rows * (size_t)cols;
@@ -178,18 +300,17 @@ __global__ __launch_bounds__(kThreads, 2) void group_kernel(const Problem *__res
     {
         // rule (H) comes in through `hist`, like in pm::push_kernel; the other rules exactly as the sweep applies them
         const unsigned t2 = (tune & ~(Tune::kPushConsume | Tune::kHistorySkip)) | (hist ? Tune::kHistorySkip : 0u);
-        sweep_read_state<BOX, 1>(L, P, lds, norm4, cost, colour, 3u, t2, true);
+        sweep_read_state<BOX, 1, 0, true>(L, P, lds, norm4, cost, colour, 3u, t2, true);
     }
     lap(0);  // tile + state
-    unsigned short *btask = reinterpret_cast<unsigned short *>(lds + LY::btask);
-    unsigned short *sorted = reinterpret_cast<unsigned short *>(lds + LY::sorted);
+    unsigned short *sbt = reinterpret_cast<unsigned short *>(lds + LY::sbt);
+    unsigned short *gorder = reinterpret_cast<unsigned short *>(lds + LY::gorder);
     uint32_t *meta = reinterpret_cast<uint32_t *>(lds + LY::meta);
     int *misc = reinterpret_cast<int *>(lds + LY::misc);
-    float *hbuf = lds + LY::hbuf;
-    float4 *gplane = reinterpret_cast<float4 *>(lds + LY::gplane);
-    float *dbuf = lds + LY::dis;
-    uint32_t *hash = reinterpret_cast<uint32_t *>(lds + LY::dis);
-    unsigned short *gid_of = reinterpret_cast<unsigned short *>(lds + LY::dis + kGrpHashSize);
+    uint32_t *hash = reinterpret_cast<uint32_t *>(lds + LY::g_hash);
+    unsigned short *gid_of = reinterpret_cast<unsigned short *>(lds + LY::g_gid);
+    unsigned short *btask = reinterpret_cast<unsigned short *>(lds + LY::g_btask);
+    uint32_t *gcnt = reinterpret_cast<uint32_t *>(lds + LY::g_cnt);
     const float *plane = lds + LY::plane;
     const char *lut_magic = (const char *)lds - kMagicBits;
 
@@ -216,8 +337,12 @@ __global__ __launch_bounds__(kThreads, 2) void group_kernel(const Problem *__res
         }
         if (lane == 63) misc[wave] = incl;
         for (int k = tid; k < kGrpHashSize; k += kThreads) hash[k] = 0u;
-        if (tid == 0) misc[8] = 0;  // number of groups
-        __syncthreads();  // (the float4 tile under the tables is dead since stage_tile's last barrier)
+        if (tid == 0) {
+            misc[8] = 0;   // number of groups
+            misc[9] = 0;   // batch cursor: next position in gorder
+        }
+        if (tid < 16) misc[32 + tid] = 0;  // histogram of the groups' strip lengths
+        __syncthreads();
         const int c0 = misc[0], c1 = misc[1], c2 = misc[2], c3 = misc[3];
         int pos = incl - cnt + (wave > 0 ? c0 : 0) + (wave > 1 ? c1 : 0) + (wave > 2 ? c2 : 0);
         n_tasks = c0 + c1 + c2 + c3;
@@ -229,8 +354,8 @@ __global__ __launch_bounds__(kThreads, 2) void group_kernel(const Problem *__res
     lap(1);  // MAXCOST writes + task list
     if (n_tasks == 0) return;  // (uniform)
 
-    auto task_plane = [&](int t, int &olx, int &oly, int &nb) -> float4 {
-        const unsigned bt = btask[t];
+    // plane of a task descriptor (owner | slot << 8): the plane of the owner's neighbour in that slot
+    auto desc_plane = [&](unsigned bt, int &olx, int &oly, int &nb) -> float4 {
         owner_pixel(L, (int)(bt & 255u), colour, olx, oly);
         const int epx = L.x0 + olx, epy = L.y0 + oly;
         neighbour((int)(bt >> 8), epx, epy, rows, cols, epy * cols + epx, nb);
@@ -241,7 +366,7 @@ __global__ __launch_bounds__(kThreads, 2) void group_kernel(const Problem *__res
     // pass 1: the first task to claim a hash slot represents its group; gid_of[t] = representative's task index
     for (int t = tid; t < n_tasks; t += kThreads) {
         int olx, oly, nb;
-        const float4 pl = task_plane(t, olx, oly, nb);
+        const float4 pl = desc_plane(btask[t], olx, oly, nb);
         const int cls = olx & 1;
         uint32_t h = plane_hash(pl, cls);
         int rep = t;
@@ -250,7 +375,7 @@ __global__ __launch_bounds__(kThreads, 2) void group_kernel(const Problem *__res
             if (seen == 0u) break;  // claimed: this task represents a new group
             const int r = (int)seen - 1;
             int rlx, rly, rnb;
-            const float4 rpl = task_plane(r, rlx, rly, rnb);
+            const float4 rpl = desc_plane(btask[r], rlx, rly, rnb);
             if ((rlx & 1) == cls && (rnb == nb || same_bits(rpl, pl))) {
                 rep = r;
                 break;
@@ -265,7 +390,7 @@ __global__ __launch_bounds__(kThreads, 2) void group_kernel(const Problem *__res
         if (gid_of[t] == (unsigned short)t) {
             const int g = atomicAdd(&misc[8], 1);
             hash[t] = (uint32_t)g;
-            meta[2 * g] = 0u;  // member count, then fill position
+            gcnt[g] = 0u;  // member count, then fill position
         }
     __syncthreads();
     const int n_groups = misc[8];
@@ -273,10 +398,10 @@ __global__ __launch_bounds__(kThreads, 2) void group_kernel(const Problem *__res
     for (int t = tid; t < n_tasks; t += kThreads) {
         const int g = (int)hash[gid_of[t]];
         gid_of[t] = (unsigned short)g;
-        atomicAdd(&meta[2 * g], 1u);
+        atomicAdd(&gcnt[g], 1u);
     }
     __syncthreads();
-    // exclusive prefix sum of the member counts (8 groups per lane), meta[2g] = task0 | count << 11
+    // exclusive prefix sum of the member counts (8 groups per lane): meta[g] = first task of group g
     {
         constexpr int per = kGrpMaxTasks / kThreads;
         uint32_t loc[per];
@@ -284,7 +409,7 @@ __global__ __launch_bounds__(kThreads, 2) void group_kernel(const Problem *__res
 #pragma unroll
         for (int e = 0; e < per; e++) {
             const int g = tid * per + e;
-            loc[e] = g < n_groups ? meta[2 * g] : 0u;
+            loc[e] = g < n_groups ? gcnt[g] : 0u;
             sum += (int)loc[e];
         }
         int incl = sum;
@@ -300,217 +425,277 @@ __global__ __launch_bounds__(kThreads, 2) void group_kernel(const Problem *__res
         for (int e = 0; e < per; e++) {
             const int g = tid * per + e;
             if (g < n_groups) {
-                meta[2 * g] = (uint32_t)run | (loc[e] << 11);
-                meta[2 * g + 1] = 0u;  // fill counter of the scatter below
+                meta[g] = (uint32_t)run;
+                gcnt[g] = 0u;  // fill counter of the scatter below
             }
             run += (int)loc[e];
         }
         __syncthreads();
     }
-    // scatter: sorted[task0(g) + k] = t
+    // scatter: the task descriptors ordered by group
     for (int t = tid; t < n_tasks; t += kThreads) {
         const int g = gid_of[t];
-        const int k = (int)atomicAdd(&meta[2 * g + 1], 1u);
-        sorted[(int)(meta[2 * g] & 2047u) + k] = (unsigned short)t;
+        const int k = (int)atomicAdd(&gcnt[g], 1u);
+        sbt[(int)meta[g] + k] = btask[t];
     }
     __syncthreads();
-    // bounding box of a group's pixels, one lane per group: meta[2g+1] = rep task | minlx << 11 | minly << 16 |
-    // (ncols - N) << 20 | (nrows - N) << 25
+    // bounding box of a group's pixels, one lane per group; the histogram of the strip lengths
     for (int g = tid; g < n_groups; g += kThreads) {
-        const uint32_t m0 = meta[2 * g];
-        const int t0 = (int)(m0 & 2047u), cnt = (int)(m0 >> 11);
+        const int t0 = (int)meta[g], cnt = (int)gcnt[g];
         int mnx = 255, mxx = 0, mny = 255, mxy = 0;
         for (int k = 0; k < cnt; k++) {
             int olx, oly;
-            owner_pixel(L, (int)(btask[sorted[t0 + k]] & 255u), colour, olx, oly);
+            owner_pixel(L, (int)(sbt[t0 + k] & 255u), colour, olx, oly);
             mnx = min(mnx, olx);
             mxx = max(mxx, olx);
             mny = min(mny, oly);
             mxy = max(mxy, oly);
         }
-        meta[2 * g + 1] = (uint32_t)sorted[t0] | ((uint32_t)mnx << 11) | ((uint32_t)mny << 16) |
-                          ((uint32_t)((mxx - mnx) >> 1) << 20) | ((uint32_t)((mxy - mny) >> 1) << 25);
+        meta[g] = (uint32_t)t0 | ((uint32_t)mnx << 11) | ((uint32_t)mny << 16) | ((uint32_t)((mxx - mnx) >> 1) << 20) |
+                  ((uint32_t)((mxy - mny) >> 1) << 24);
+        atomicAdd(&misc[32 + ((mxy - mny) >> 1)], 1);
     }
     __syncthreads();
+    // groups ordered by strip length (counting sort, 8 possible lengths): the strips a wavefront walks together
+    // are then equally long, and a batch's sample buffer is laid out with ONE row count
+    if (tid == 0) {
+        int run = 0;
+        for (int b = 0; b < 16; b++) {
+            const int c = misc[32 + b];
+            misc[32 + b] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    for (int g = tid; g < n_groups; g += kThreads) {
+        const int key = (int)((meta[g] >> 24) & 7u);
+        gorder[atomicAdd(&misc[32 + key], 1)] = (unsigned short)g;
+    }
+    __syncthreads();  // LAST workgroup barrier: the grouping tables' memory becomes the wavefronts' batch areas
+    lap(2);  // grouping, sort, bounding boxes, order
+    if (P->dbg != nullptr && tid == 0) {
+        atomicAdd(&P->dbg[61 * kDbgSlots + 5], (unsigned long long)n_groups);
+        atomicAdd(&P->dbg[61 * kDbgSlots + 6], (unsigned long long)n_tasks);
+        atomicAdd(&P->dbg[61 * kDbgSlots + 7], 1ull);
+    }
+    // members of group g: sbt[first .. first + count)
+    auto group_tasks = [&](int g, int &first) -> int {
+        first = (int)(meta[g] & 2047u);
+        return (g + 1 < n_groups ? (int)(meta[g + 1] & 2047u) : n_tasks) - first;
+    };
 
-    lap(2);  // grouping, sort, bounding boxes
-    // ---- super-batches of consecutive groups: as many as the sample buffer, kSbStripsPerLane strips and
-    //      kSbTasksPerLane tasks per lane allow.  Per super-batch the views are looped outside: all its strips for
-    //      view v (phase A), then all its chains (phase B) -- two barriers per view, thousands of instructions
-    //      between them ----
-    uint32_t *gtab = reinterpret_cast<uint32_t *>(lds + LY::gtab);
-    unsigned char *sgroup = reinterpret_cast<unsigned char *>(lds + LY::sgroup);
-    unsigned char *tgroup = reinterpret_cast<unsigned char *>(lds + LY::tgroup);
-    int g_first = 0;
-    while (g_first < n_groups) {  // (uniform)
-        // cut: groups g_first .. g_first + ng - 1 (lane i of the first two wavefronts looks at group g_first + i)
-        {
-            const int g = g_first + tid;
-            int nc = 0, nt = 0, npnt = 0;
-            if (tid < kSbGroups && g < n_groups) {
-                const uint32_t m1 = meta[2 * g + 1];
-                nc = N + (int)((m1 >> 20) & 31u);
-                nt = (int)(meta[2 * g] >> 11);
-                npnt = nc * (N + (int)((m1 >> 25) & 15u));
-            }
-            int ic = nc, it = nt, ip = npnt;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int uc = __shfl_up(ic, d), ut = __shfl_up(it, d), up = __shfl_up(ip, d);
-                if (lane >= d) {
-                    ic += uc;
-                    it += ut;
-                    ip += up;
-                }
-            }
-            if (wave == 0 && lane == 63) {
-                misc[16] = ic;
-                misc[17] = it;
-                misc[18] = ip;
-            }
-            __syncthreads();
-            if (wave == 1) {
-                ic += misc[16];
-                it += misc[17];
-                ip += misc[18];
-            }
-            const bool fits = nc > 0 && ic <= LY::max_strips && it <= LY::max_tasks && ip <= LY::capacity;
-            const unsigned long long fb = __ballot(fits);
-            // groups are taken while they fit: the run of set bits from bit 0 of the first wavefront on
-            if (wave < 2 && lane == 0) misc[20 + wave] = fb == ~0ull ? 64 : (int)__builtin_ctzll(~fb);
-            if (tid < kSbGroups) {  // exclusive prefixes; the entry behind the last group taken = the totals
-                gtab[4 * (tid + 1) + 0] = (uint32_t)ic;
-                gtab[4 * (tid + 1) + 1] = (uint32_t)it;
-                gtab[4 * (tid + 1) + 2] = (uint32_t)ip;
-            }
-            if (tid == 0) gtab[0] = gtab[1] = gtab[2] = 0u;
-            __syncthreads();
+    // ---- batches: each wavefront on its own ----
+    float *wbase = lds + LY::waves + wave * LY::w_stride;
+    unsigned short *wtab = reinterpret_cast<unsigned short *>(wbase + LY::w_tab);
+    unsigned char *sgroup = reinterpret_cast<unsigned char *>(wbase + LY::w_sgroup);
+    unsigned char *tgroup = reinterpret_cast<unsigned char *>(wbase + LY::w_tgroup);
+    float4 *gplane = reinterpret_cast<float4 *>(wbase + LY::w_gplane);
+    float *hbuf = wbase + LY::w_hbuf;
+    float *dbuf = wbase + LY::w_dis;
+    GroupWalk<BOX> W;
+    W.init(P);
+    // chains: one lane per task, or (kGrpTaskLanes == 2) lane tl sums the left window columns of task tl and lane
+    // 32 + tl the right ones
+    const int half = kGrpTaskLanes == 2 ? lane >> 5 : 0, tl = kGrpTaskLanes == 2 ? lane & 31 : lane;
+
+    for (;;) {
+        // -- take the next run of groups from the cursor --
+        __builtin_amdgcn_wave_barrier();
+        int start = 0;
+        if (lane == 0) start = *(volatile int *)&misc[9];
+        start = __builtin_amdgcn_readfirstlane(start);
+        if (start >= n_groups) break;
+        int g = -1, nc = 0, nt = 0, nr = 0, tfirst = 0;
+        uint32_t m = 0u;
+        if (lane < kGrpBatchGroups && start + lane < n_groups) {
+            g = (int)gorder[start + lane];
+            m = meta[g];
+            nc = N + (int)((m >> 20) & 15u);
+            nr = N + (int)((m >> 24) & 7u);
+            nt = group_tasks(g, tfirst);
         }
-        // (a single group always fits: at most 23 strips of 15 samples and the 128 pixels of its lattice)
-        const int ng = misc[20] < 64 ? misc[20] : 64 + misc[21];
-        const int n_strips = (int)gtab[4 * ng + 0], n_btasks = (int)gtab[4 * ng + 1];
-        // tables: which group a strip / a task of the super-batch belongs to; the groups' planes
-        if (tid < ng) {
-            const uint32_t m1 = meta[2 * (g_first + tid) + 1];
-            const int s0 = (int)gtab[4 * tid + 0], s1 = (int)gtab[4 * tid + 4];
-            const int t0 = (int)gtab[4 * tid + 1], t1 = (int)gtab[4 * tid + 5];
-            for (int k = s0; k < s1; k++) sgroup[k] = (unsigned char)tid;
-            for (int k = t0; k < t1; k++) tgroup[k] = (unsigned char)tid;
+        int ic = nc, it = nt;
+#pragma unroll
+        for (int d = 1; d < kGrpBatchGroups; d <<= 1) {
+            const int uc = __shfl_up(ic, d), ut = __shfl_up(it, d);
+            if (lane >= d) {
+                ic += uc;
+                it += ut;
+            }
+        }
+        // (strip lengths do not decrease along gorder: a group's own nr is the largest of the run up to it; rows are
+        //  walked in pairs: a batch's strips get an even number of them)
+        const bool fits = g >= 0 && ic <= kGrpBatchStrips && it <= kGrpBatchTasks && ic * ((nr + 1) & ~1) <= kGrpBatchSamples;
+        const unsigned long long fb = __ballot(fits);
+        int cnt = fb == ~0ull ? 64 : (int)__builtin_ctzll(~fb);
+        if (cnt == 0) cnt = 1;  // a single group always fits the strips and the buffer; more than 32 tasks: several rounds
+        int won = 0;
+        if (lane == 0) won = atomicCAS(&misc[9], start, start + cnt) == start ? 1 : 0;
+        if (!__builtin_amdgcn_readfirstlane(won)) continue;  // another wavefront took (part of) this run
+        // (wave-uniform, in scalar registers: they steer the loops below)
+        const int n_strips = __builtin_amdgcn_readfirstlane(__shfl(ic, cnt - 1));
+        const int n_alltasks = __builtin_amdgcn_readfirstlane(__shfl(it, cnt - 1));
+        const int nr_b = (__builtin_amdgcn_readfirstlane(__shfl(nr, cnt - 1)) + 1) & ~1;
+        if (lane < cnt) {
+            const int sp = ic - nc, tp = it - nt;
+            wtab[4 * lane + 0] = (unsigned short)g;
+            wtab[4 * lane + 1] = (unsigned short)sp;
+            wtab[4 * lane + 2] = (unsigned short)tp;
+            for (int k = 0; k < nc; k++) sgroup[sp + k] = (unsigned char)lane;
+            if (n_alltasks <= kGrpBatchTasks)
+                for (int k = 0; k < nt; k++) tgroup[tp + k] = (unsigned char)lane;
             int rlx, rly, rnb;
-            gplane[tid] = task_plane((int)(m1 & 2047u), rlx, rly, rnb);
+            gplane[lane] = desc_plane(sbt[tfirst], rlx, rly, rnb);
         }
-        __syncthreads();
-        // this lane's tasks (kept in registers across the views)
-        int t_off[kSbTasksPerLane], t_slot[kSbTasksPerLane], t_center[kSbTasksPerLane];  // sample-buffer offset, slot, pixel
-        int t_nrows[kSbTasksPerLane];
-        const float *t_tp0[kSbTasksPerLane];
-        ViewCombiner<true> comb[kSbTasksPerLane];
-#pragma unroll
-        for (int k = 0; k < kSbTasksPerLane; k++) {
-            const int t = tid + k * kThreads;
-            t_off[k] = 0;
-            t_slot[k] = 0;
-            t_center[k] = 0;
-            t_nrows[k] = N;
-            t_tp0[k] = plane + (L.hh * tw + L.hw);
-            if (t < n_btasks) {
-                const int j = tgroup[t];
-                const uint32_t m0 = meta[2 * (g_first + j)], m1 = meta[2 * (g_first + j) + 1];
-                const unsigned bt = btask[sorted[(int)(m0 & 2047u) + (t - (int)gtab[4 * j + 1])]];
+        __builtin_amdgcn_wave_barrier();
+        if (P->dbg != nullptr && lane == 0) {  // (GIPUMA_HIP_COUNTS: batch statistics in row 61 of Problem::dbg)
+            unsigned long long *d = P->dbg + 61 * kDbgSlots;
+            atomicAdd(&d[0], 1ull);
+            atomicAdd(&d[1], (unsigned long long)n_strips);
+            atomicAdd(&d[2], (unsigned long long)n_alltasks);
+            atomicAdd(&d[3], (unsigned long long)cnt);
+            atomicAdd(&d[4], (unsigned long long)nr_b);
+        }
+
+        // -- this lane's strip (spare lanes shadow strip 0: the same values into the same places) --
+        {
+            const int s = lane < n_strips ? lane : 0;
+            const int j = (int)sgroup[s];
+            const uint32_t gm = meta[(int)wtab[4 * j]];
+            const int c = s - (int)wtab[4 * j + 1];
+            const int s_lx = (int)((gm >> 11) & 31u) - R + 2 * c, s_ly = (int)((gm >> 16) & 15u) - R;
+            W.qx = (float)(L.x0 + s_lx);
+            W.qy0 = (float)(L.y0 + s_ly);
+            W.tcol = plane + ((s_ly + L.hh) * tw + (s_lx + L.hw));
+            W.out = dbuf + s * nr_b;
+            W.grp = j;
+        }
+        // homographies of (group, view) for views vb .. vb + kGrpViewsPerH - 1, one pair per lane; [9] = the fast
+        // reciprocal is exact on the whole box (any such proof gives the bits of the IEEE division, see rcp_newton)
+        auto h_block = [&](int vb) {
+            const int j = lane & (kGrpBatchGroups - 1), vi = lane / kGrpBatchGroups, v = vb + vi;
+            if (vi < kGrpViewsPerH && j < cnt && v < n) {
+                const uint32_t gm = meta[(int)wtab[4 * j]];
+                float H[9];
+                homography(P->rc.K_inv, P->view[v], gplane[j], H);
+                const int bx0 = L.x0 + (int)((gm >> 11) & 31u) - R, by0 = L.y0 + (int)((gm >> 16) & 15u) - R;
+                const int bx1 = bx0 + 2 * (N - 1 + (int)((gm >> 20) & 15u)), by1 = by0 + 2 * (nr_b - 1);
+                const bool safe = window_z_safe(H, (float)bx0, (float)bx1, (float)by0, (float)by1);
+                float *h = hbuf + (vi * kGrpBatchGroups + j) * 12;
+                *reinterpret_cast<float4 *>(h) = make_float4(H[0], H[1], H[2], H[3]);
+                *reinterpret_cast<float4 *>(h + 4) = make_float4(H[4], H[5], H[6], H[7]);
+                *reinterpret_cast<float4 *>(h + 8) = make_float4(H[8], safe ? 1.0f : 0.0f, 0.0f, 0.0f);
+            }
+        };
+        auto view_fast = [&](const float *hb) -> bool { return __all(hb[12 * W.grp + 9] != 0.0f); };
+        auto view_base = [&](int v) -> gptr_bytes {
+            return (gptr_bytes)((uintptr_t)P->view[v].packed - (uintptr_t)kMagicBits);
+        };
+
+        // -- rounds of at most kGrpBatchTasks tasks (more than one only for a single group offered to more pixels) --
+        for (int t_lo = 0; t_lo < n_alltasks; t_lo += kGrpBatchTasks) {
+            const int n_bt = min(kGrpBatchTasks, n_alltasks - t_lo);
+            // this lane's task: sample-buffer offset of its half window, slot, pixel, support weights of its columns
+            int t_off = 0, t_slot = 0, t_center = 0;
+            const float *t_tp = plane + (L.hh * tw + L.hw);
+            const bool has = tl < n_bt;
+            if (has) {
+                const int j = n_alltasks <= kGrpBatchTasks ? (int)tgroup[tl] : 0;
+                const int gg = (int)wtab[4 * j];
+                const uint32_t gm = meta[gg];
+                const unsigned bt = sbt[(int)(gm & 2047u) + (t_lo + tl - (int)wtab[4 * j + 2])];
                 int olx, oly;
                 owner_pixel(L, (int)(bt & 255u), colour, olx, oly);
-                const int nrows = N + (int)((m1 >> 25) & 15u);
-                t_nrows[k] = nrows;
-                t_off[k] = (int)gtab[4 * j + 2] + ((olx - (int)((m1 >> 11) & 31u)) >> 1) * nrows + ((oly - (int)((m1 >> 16) & 15u)) >> 1);
-                t_slot[k] = (int)(bt >> 8);
-                t_center[k] = (L.y0 + oly) * cols + (L.x0 + olx);
-                t_tp0[k] = plane + ((oly + L.hh) * tw + (olx + L.hw));
+                t_off = ((int)wtab[4 * j + 1] + ((olx - (int)((gm >> 11) & 31u)) >> 1) + half * NH) * nr_b +
+                        ((oly - (int)((gm >> 16) & 15u)) >> 1);
+                t_slot = (int)(bt >> 8);
+                t_center = (L.y0 + oly) * cols + (L.x0 + olx);
+                t_tp = plane + ((oly + L.hh) * tw + (olx + L.hw));
             }
-        }
-        // homography of (group plane, view) -> hbuf; [9] = the fast reciprocal is exact on the whole box
-        auto group_h = [&](int j, int v) {
-            const uint32_t m1 = meta[2 * (g_first + j) + 1];
-            float H[9];
-            homography(P->rc.K_inv, P->view[v], gplane[j], H);
-            const int bx0 = L.x0 + (int)((m1 >> 11) & 31u) - R, by0 = L.y0 + (int)((m1 >> 16) & 15u) - R;
-            const int bx1 = bx0 + 2 * (N - 1 + (int)((m1 >> 20) & 31u)), by1 = by0 + 2 * (N - 1 + (int)((m1 >> 25) & 15u));
-            const bool safe = window_z_safe(H, (float)bx0, (float)bx1, (float)by0, (float)by1);
-            float *h = hbuf + 10 * j;
+            // support weights (weight_cu, gipuma.cu:186-193: 256 possible weights) of this lane's window columns,
+            // column outer, row inner -- the order of the chain
+            float wgt[NH * N];
+            {
+                const float centre = t_tp[0];
+                const float *tc = t_tp + (-R * tw - R + 2 * half * NH);
 #pragma unroll
-            for (int k = 0; k < 9; k++) h[k] = H[k];
-            h[9] = safe ? 1.0f : 0.0f;
-        };
-        if (tid < ng) group_h(tid, 0);
-        __syncthreads();
-        lap(3);  // super-batch cut, tables, task geometry, first homographies
-        for (int v = 0; v < n; v++) {
-            const ViewCam &vc = P->view[v];
-            const gptr_bytes base = (gptr_bytes)((uintptr_t)vc.packed - (uintptr_t)kMagicBits);
-            // phase A: dis of every sample column of the super-batch
-#ifndef PM_GROUP_EXP_STRIP_REPEAT
-#define PM_GROUP_EXP_STRIP_REPEAT 1  // (timing experiments: phase A run this many times, same results)
-#endif
-            for (int rep = 0; rep < PM_GROUP_EXP_STRIP_REPEAT; rep++)
-            for (int s0 = 0; s0 < n_strips; s0 += kThreads) {  // (uniform trip count)
-                const int sidx = s0 + tid;
-                const bool has = sidx < n_strips;
-                const int j = has ? (int)sgroup[sidx] : 0;
-                const uint32_t m1 = meta[2 * (g_first + j) + 1];
-                const int nrows = N + (int)((m1 >> 25) & 15u);
-                const int c = has ? sidx - (int)gtab[4 * j + 0] : 0;
-                const int s_lx = (int)((m1 >> 11) & 31u) - R + 2 * c, s_ly = (int)((m1 >> 16) & 15u) - R;
-                const float *h = hbuf + 10 * j;
-                float H[9];
+                for (int i = 0; i < NH; i++)
 #pragma unroll
-                for (int k = 0; k < 9; k++) H[k] = h[k];
-                const bool safe = h[9] != 0.0f || !has;
-                const float *tcol = plane + ((s_ly + L.hh) * tw + (s_lx + L.hw));
-                float *out = dbuf + (int)gtab[4 * j + 2] + c * nrows;
-                if (__all(safe))
-                    group_strip<true>(P, base, H, tcol, tw, (float)(L.x0 + s_lx), (float)(L.y0 + s_ly), has ? nrows : 0, out);
+                    for (int jj = 0; jj < N; jj++) {
+                        const float colorDis = __builtin_fabsf(tc[2 * jj * tw + 2 * i] - centre);
+                        wgt[i * N + jj] = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
+                    }
+            }
+            ViewCombiner<true> comb;
+
+            h_block(0);
+            __builtin_amdgcn_wave_barrier();
+            StripView sv;
+            typename GroupWalk<BOX>::Set SA, SB;
+            bool fast = view_fast(hbuf);
+            if (fast)
+                W.template first<true>(view_base(0), hbuf, sv, SA, SB);
+            else
+                W.template first<false>(view_base(0), hbuf, sv, SA, SB);
+            for (int v = 0; v < n; v++) {
+                // strips: dis of every sample column of the batch
+                if (fast)
+                    W.template body<true>(view_base(v), nr_b, sv, SA, SB);
                 else
-                    group_strip<false>(P, base, H, tcol, tw, (float)(L.x0 + s_lx), (float)(L.y0 + s_ly), has ? nrows : 0, out);
-            }
-            __syncthreads();
-            lap(4);  // phase A
-            // phase B: the reference's summation order over each task's own window ...
-#pragma unroll
-            for (int k = 0; k < kSbTasksPerLane; k++) {
-                if (tid + k * kThreads < n_btasks) {
-                    const float centre = t_tp0[k][0];
-                    float cst = 0.0f;
-#ifndef PM_GROUP_EXP_CHAIN_REPEAT
-#define PM_GROUP_EXP_CHAIN_REPEAT 1  // (timing experiments: the chain run this many times, same results)
-#endif
-                    for (int rep = 0; rep < PM_GROUP_EXP_CHAIN_REPEAT; rep++) {
-                    cst = 0.0f;
-                    const float *dcol = dbuf + t_off[k];
-                    const float *tcol = t_tp0[k] + (-R * tw - R);
-                    const int nrows = t_nrows[k];
-                    __builtin_amdgcn_sched_barrier(0);
-                    for (int i = 0; i < N; i++, dcol += nrows, tcol += 2) {
-#pragma unroll
-                        for (int jj = 0; jj < N; jj++) {
-                            const float colorDis = __builtin_fabsf(tcol[2 * jj * tw] - centre);
-                            const float w = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
-                            cst = __builtin_fmaf(w, dcol[jj], cst);
-                        }
+                    W.template body<false>(view_base(v), nr_b, sv, SA, SB);
+                __builtin_amdgcn_wave_barrier();
+                // the next view's first windows travel during the chains
+                if (v + 1 < n) {
+                    if ((v + 1) % kGrpViewsPerH == 0) {
+                        h_block(v + 1);
+                        __builtin_amdgcn_wave_barrier();
                     }
-                    }
-                    comb[k].add(cst, v, nullptr);
+                    const float *hn = hbuf + ((v + 1) % kGrpViewsPerH) * (kGrpBatchGroups * 12);
+                    fast = view_fast(hn);
+                    if (fast)
+                        W.template first<true>(view_base(v + 1), hn, sv, SA, SB);
+                    else
+                        W.template first<false>(view_base(v + 1), hn, sv, SA, SB);
                 }
-            }
-            // ... and the next view's homographies (read by phase A only)
-            if (v + 1 < n && tid < ng) group_h(tid, v + 1);
-            __syncthreads();
-            lap(5);  // phase B + next homographies
-        }
+                // chains: the reference's summation order over each task's own window -- the left columns by lane
+                // tl, then, continuing from its sum, the right columns by lane 32 + tl.  A window column's samples
+                // are read while the column before is summed.
+                const float *dcol = dbuf + t_off;
+                float cst = 0.0f;
+                auto half_chain = [&]() {
+                    float dv[2][N];
 #pragma unroll
-        for (int k = 0; k < kSbTasksPerLane; k++)
-            if (tid + k * kThreads < n_btasks)
-                P->push_cost[(size_t)t_slot[k] * np + (size_t)t_center[k]] = comb[k].finish(P, n, nullptr);
-        g_first += ng;
+                    for (int jj = 0; jj < N; jj++) dv[0][jj] = dcol[jj];
+#pragma unroll
+                    for (int i = 0; i < NH; i++) {
+                        if (i + 1 < NH) {
+#pragma unroll
+                            for (int jj = 0; jj < N; jj++) dv[(i + 1) & 1][jj] = dcol[(i + 1) * nr_b + jj];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int jj = 0; jj < N; jj++) cst = __builtin_fmaf(wgt[i * N + jj], dv[i & 1][jj], cst);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                if (kGrpTaskLanes == 2) {
+                    if (half == 0 && has) half_chain();
+                    const float left = __shfl(cst, tl);
+                    if (half == 1 && has) {
+                        cst = left;
+                        half_chain();
+                        comb.add(cst, v, nullptr);
+                    }
+                } else if (has) {
+                    half_chain();
+                    comb.add(cst, v, nullptr);
+                }
+                __builtin_amdgcn_wave_barrier();  // the next view's strips overwrite the samples
+            }
+            if (half == kGrpTaskLanes - 1 && has) P->push_cost[(size_t)t_slot * np + (size_t)t_center] = comb.finish(P, n, nullptr);
+        }
     }
+    lap(3);  // batches (this workgroup's first wavefront)
 }
 
 }  // namespace pm

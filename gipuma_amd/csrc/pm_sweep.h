@@ -51,10 +51,13 @@ __device__ __forceinline__ TileXY tile_of(int b, int gx, int gy, unsigned tune)
 // stage the reference tile (+halo) and the weight table; the tile holds clamp-to-edge point
 // samples exactly like the reference's (gipuma.cu:1393-1402, 1513-1522)
 // (PAD: extra texels per tile row, so that lanes two tile rows apart do not share LDS banks)
-template <int BOX, int CH, int PAD = 0>
+// (PLANE_ONLY, gray: only the scalar plane of point samples, AT the float4 tile's place -- for kernels that form
+//  the gradients per sample and want the LDS, pm_group.h)
+template <int BOX, int CH, int PAD = 0, bool PLANE_ONLY = false>
 __device__ __forceinline__ void stage_tile(const Problem *__restrict__ P, float *lds, int x0, int y0,
                                            int tile_h, const Win<BOX> &win, bool want_lut)
 {
+    static_assert(!PLANE_ONLY || (CH == 1 && PAD == 0), "plane-only staging: gray tiles");
     const int hw = win.halo_w(), hh = win.halo_h();
     const int tw = kTileW + 2 * hw, th = tile_h + 2 * hh;
     const int tws = tw + PAD;  // row stride of the float4 tile
@@ -62,7 +65,7 @@ __device__ __forceinline__ void stage_tile(const Problem *__restrict__ P, float 
     float *tile = lds + lut_size<CH>();  // float4 per texel
     // gray: the scalar image goes to a scratch plane behind the float4 tile first, so that the
     // central differences can be formed once per tile instead of once per sample
-    float *plane = tile + 4 * tws * th;
+    float *plane = PLANE_ONLY ? tile : tile + 4 * tws * th;
     for (int k = threadIdx.x; k < tw * th; k += kThreads) {
         const int ty = k / tw, tx = k - ty * tw;
         const int gx = clampi(x0 - hw + tx, 0, P->cols - 1);
@@ -78,7 +81,7 @@ __device__ __forceinline__ void stage_tile(const Problem *__restrict__ P, float 
         for (int k = threadIdx.x; k < lut_size<CH>(); k += kThreads)
             lds[k] = exp_model(-(CH == 4 ? (float)k * 0.3333333f : (float)k) / P->gamma);
     __syncthreads();
-    if (CH == 1) {
+    if (CH == 1 && !PLANE_ONLY) {
         // {I, gx1, gy1, -} with gx1 = I(x+1) - I(x-1), gy1 = I(y+1) - I(y-1): the reference-side
         // terms of pmCostComputation_shared (gipuma.cu:254-259), same fp32 subtractions
         for (int k = threadIdx.x; k < tw * th; k += kThreads) {
@@ -282,7 +285,7 @@ struct SweepLane {
 
 // tile staging, lane -> pixel mapping, state read (gipuma.cu:1527-1530) and the exact skipping rules:
 // leaves L.needmask = the candidate slots of this lane's pixel that must be evaluated
-template <int BOX, int CH, int PAD = 0>
+template <int BOX, int CH, int PAD = 0, bool PLANE_ONLY = false>
 __device__ __forceinline__ void sweep_read_state(SweepLane &L, const Problem *__restrict__ P, float *lds,
                                                  const float4 *__restrict__ norm4, const float *__restrict__ cost,
                                                  int colour, unsigned stages, unsigned tune, bool want_lut)
@@ -295,7 +298,7 @@ __device__ __forceinline__ void sweep_read_state(SweepLane &L, const Problem *__
     const TileXY txy = tile_of(blockIdx.x, gx, gy, tune);
     L.x0 = txy.x * kTileW;
     L.y0 = txy.y * kSweepTileH;
-    stage_tile<BOX, CH, PAD>(P, lds, L.x0, L.y0, kSweepTileH, win, want_lut);
+    stage_tile<BOX, CH, PAD, PLANE_ONLY>(P, lds, L.x0, L.y0, kSweepTileH, win, want_lut);
     L.hw = win.halo_w();
     L.hh = win.halo_h();
     L.tw = kTileW + 2 * L.hw + PAD;  // row stride of the tile

@@ -22,6 +22,8 @@
 
 // 4 independent chains per body so latency does not bound
 KERNEL(k_fma, asm volatile("v_fma_f32 %0, %4, %5, %0\n v_fma_f32 %1, %4, %5, %1\n v_fma_f32 %2, %4, %5, %2\n v_fma_f32 %3, %4, %5, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(a2));)
+KERNEL(k_fma_s, asm volatile("v_fma_f32 %0, %4, %5, %0\n v_fma_f32 %1, %4, %5, %1\n v_fma_f32 %2, %4, %5, %2\n v_fma_f32 %3, %4, %5, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "s"(2.5f), "v"(a2));)
+KERNEL(k_fma_2, asm volatile("v_fma_f32 %0, %4, %4, %0\n v_fma_f32 %1, %4, %4, %1\n v_fma_f32 %2, %4, %4, %2\n v_fma_f32 %3, %4, %4, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
 KERNEL(k_add, asm volatile("v_add_f32 %0, %4, %0\n v_add_f32 %1, %4, %1\n v_add_f32 %2, %4, %2\n v_add_f32 %3, %4, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e));)
 KERNEL(k_mul, asm volatile("v_mul_f32 %0, %4, %0\n v_mul_f32 %1, %4, %1\n v_mul_f32 %2, %4, %2\n v_mul_f32 %3, %4, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(b2));)
 KERNEL(k_pkfma, asm volatile("v_pk_fma_f32 %0, %2, %3, %0\n v_pk_fma_f32 %1, %2, %3, %1\n v_pk_fma_f32 %0, %2, %3, %0\n v_pk_fma_f32 %1, %2, %3, %1" : "+v"(*(double*)&a), "+v"(*(double*)&c) : "v"(*(double*)&a2), "v"(*(double*)&c2));)
@@ -81,9 +83,13 @@ void run(const char *name, K k, float *d, int waves_per_simd)
     // measured by the kernel itself: s_memtime ticks per s_memrealtime tick (100 MHz)
     const double ns_per_inst = ms * 1e6 / ((double)ops * waves_per_simd);
     const double sclk_mhz = clk[1] ? 100.0 * (double)clk[0] / (double)clk[1] : 0.0;
-    const double clk_per_inst = (double)clk[0] / ((double)ops * waves_per_simd);
-    printf("%-12s waves/SIMD=%d  %.3f ns per wave-instruction per SIMD  = %.2f shader clocks (in-kernel s_memtime; "
-           "SCLK sustained %.0f MHz)\n", name, waves_per_simd, ns_per_inst, clk_per_inst, sclk_mhz);
+    // clocks per instruction per SIMD from the event time and the clock the kernel itself saw.  (Wave 0's own elapsed
+    // shader clocks per ITS instruction ride along: with several waves per SIMD the oldest wave keeps its
+    // single-wave pace while the younger ones take what is left, so that figure is not the SIMD's issue rate.)
+    const double clk_per_inst = ns_per_inst * sclk_mhz * 1e-3;
+    const double clk_wave0 = (double)clk[0] / (double)ops;
+    printf("%-12s waves/SIMD=%d  %.3f ns per wave-instruction per SIMD = %.2f shader clocks at the sustained SCLK of %.0f MHz "
+           "(wave 0 alone: %.2f clk per own instruction)\n", name, waves_per_simd, ns_per_inst, clk_per_inst, sclk_mhz, clk_wave0);
 }
 
 int main()
@@ -94,7 +100,7 @@ int main()
     printf("# encodings: fma VOP3; add/mul/min/max VOP2 (and _e64 = VOP3 forms of add, min); cvt_*/floor/fract/rcp/mov "
            "VOP1; med3/min3/bfe/perm/and_or/lshl_add/mad/div_fixup/fma_mix VOP3(P); sub_sdwa SDWA\n");
     for (int w : {1, 2, 4}) {
-        run("fma", k_fma, d, w); run("add", k_add, d, w); run("add_e64", k_add64, d, w); run("mul", k_mul, d, w);
+        run("fma", k_fma, d, w); run("fma_sgpr_src", k_fma_s, d, w); run("fma_2_vgprs", k_fma_2, d, w); run("add", k_add, d, w); run("add_e64", k_add64, d, w); run("mul", k_mul, d, w);
         run("pk_fma", k_pkfma, d, w); run("pk_add", k_pkadd, d, w);
         run("cvt_ubyte", k_cvtub, d, w); run("cvt_f32_i32", k_cvti, d, w); run("cvt_i32_f32", k_cvtf2i, d, w);
         run("add_u32", k_addu, d, w); run("mul_lo_u32", k_mullo, d, w); run("mad_u24", k_mad24, d, w);
