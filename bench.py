@@ -340,7 +340,7 @@ def main():
     iterations = gs.params.iterations
 
     sess = Session(gs)
-    sweep_ms, total_ms, init_ms, half_sweeps, hs_pushed = [], [], [], [], 0
+    sweep_ms, total_ms, init_ms, half_sweeps, hs_pushed, group_ms = [], [], [], [], 0, []
     for _ in range(args.warmup):
         sess.solve(timing=True)
     torch.cuda.synchronize()
@@ -350,6 +350,7 @@ def main():
         t = sess.solve(timing=True)  # returns after the last kernel's HIP event
         hs_ms, hs_pushed = sess.launch_times()
         half_sweeps.append(hs_ms)
+        group_ms.append(sess.group_times())
         sweep_ms.append(t.ms_sweep_avg)
         total_ms.append(t.ms_total)
         init_ms.append(t.ms_init)
@@ -392,6 +393,25 @@ def main():
             first_plain = min(hs.shape[1], max(cols_first, hs_pushed))
         dominant = hs[:, first_plain:] if hs.size and first_plain < hs.shape[1] else None
         ms_launch = float(dominant.mean()) if dominant is not None else ms_half_sweep
+        # Where the propagation costs of a half-sweep come from pm::group_kernel (pm_group.h: box 15 on frames of
+        # >= 1024 tiles, from the fifth half-sweep on), a half-sweep is TWO launches -- that kernel (the cost
+        # evaluations of the reference's close + far kernels) and the fused sweep launch (their accept tests replayed
+        # + the refinement kernel) -- and the former is the dominant kernel by time.  It is timed by its own pair of
+        # HIP events on the library's stream (gipuma_hip_group_times); its algorithmic bytes are the close + far
+        # share of SURVEY 8d's per-launch figure: (28 + 28) B of state and 2 x 4 (N + 1) B of images per active pixel.
+        gm = np.asarray(group_ms, dtype=np.float64) if group_ms and len(group_ms[0]) else np.zeros((0, 0))
+        dom_is_group = bool(gm.size and (gm > 0).any())
+        dom_name, dom_pmc_file = "pm::sweep_kernel", "pmc_latest_sweep_kernel.json"
+        ms_sweep_launch = ms_launch
+        if dom_is_group:
+            used = gm > 0
+            ms_group_launch = float(gm[used].mean())
+            ms_sweep_launch = float((hs - gm)[used].mean())  # the fused sweep launch of the same half-sweeps
+            alg_half_sweep, ms_pair = alg, ms_launch
+            alg = n_pix * (56 + 8 * (n_views + 1)) / 2.0
+            alg_sweep = n_pix * (20 + 4 * (n_views + 1)) / 2.0
+            ms_launch = ms_group_launch
+            dom_name, dom_pmc_file = "pm::group_kernel", "pmc_latest_group_kernel.json"
         achieved = alg / (ms_launch * 1e-3) / 1e9
         # HBM-side bytes per sweep launch and VALU instruction counts are NOT measured in this run: they
         # come from the PMC passes of the same command (scripts/pmc_passes.sh -> profiles/pmc_latest.json),
@@ -406,7 +426,7 @@ def main():
                 pj = None
         # ... the traffic of the dominant kernel from its own summary of the same passes
         pd = None
-        pmc_dom = os.path.join(ROOT, "profiles", "pmc_latest_sweep_kernel.json")
+        pmc_dom = os.path.join(ROOT, "profiles", dom_pmc_file)
         if pj is not None and os.path.exists(pmc_dom):
             try:
                 pd = json.load(open(pmc_dom))
@@ -428,7 +448,7 @@ def main():
         traffic = None
         if pd and "hbm_read_bytes_per_launch_x2corr" in pd:
             traffic = (pd["hbm_read_bytes_per_launch_x2corr"] + pd["hbm_write_bytes_per_launch"]) / 1e9
-        imported_dom = {"measured_in_this_run": False, "file": "profiles/pmc_latest_sweep_kernel.json",
+        imported_dom = {"measured_in_this_run": False, "file": "profiles/" + dom_pmc_file,
                         "collected_at_kernel_ms": pd.get("_kernel_ms_profiled_mean") if pd else None,
                         "collected_with_lib_sha16": pd.get("_lib_sha16") if pd else None, "commit": pd.get("_commit") if pd else None,
                         "collected_with_src_sha16": pd.get("_src_sha16") if pd else None,
@@ -484,17 +504,34 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_unit": "GB per launch (L2<->fabric incl. Infinity Cache hits)",
                          "traffic_source": imported_dom,
-                         "kernel": "pm::sweep_kernel: one fused launch per half-sweep (one colour: close+far+refine), "
-                                   "%d of the %d half-sweeps of a view (the %d before them: pm::sweep_cols_kernel x%d, "
-                                   "and pm::push_kernel x%d, which evaluates the propagation costs of the first %d "
-                                   "half-sweeps once per plane)"
-                                   % (n_launch - first_plain, n_launch, first_plain, min(cols_l, n_launch), push_l, push_l),
+                         "kernel": ("pm::group_kernel: the propagation costs (close + far) of a half-sweep, one evaluation "
+                                    "per PLANE instead of per (pixel, plane); %d of the %d half-sweeps of a view are this "
+                                    "launch + one fused pm::sweep_kernel launch (accept replay + refinement); the %d before "
+                                    "them: pm::sweep_cols_kernel x%d and pm::push_kernel x%d"
+                                    % (int((gm[0] > 0).sum()), n_launch, first_plain, min(cols_l, n_launch), push_l))
+                                   if dom_is_group else
+                                   ("pm::sweep_kernel: one fused launch per half-sweep (one colour: close+far+refine), "
+                                    "%d of the %d half-sweeps of a view (the %d before them: pm::sweep_cols_kernel x%d, "
+                                    "and pm::push_kernel x%d, which evaluates the propagation costs of the first %d "
+                                    "half-sweeps once per plane)"
+                                    % (n_launch - first_plain, n_launch, first_plain, min(cols_l, n_launch), push_l, push_l)),
                          "kernel_ms": ms_launch,
-                         "kernel_ms_source": "HIP events around each half-sweep on the library's stream "
-                                             "(gipuma_hip_launch_times), mean over the kernel's launches, this run",
+                         "kernel_ms_source": ("its own pair of HIP events on the library's stream (gipuma_hip_group_times), "
+                                              "mean over the kernel's launches, this run") if dom_is_group else
+                                             ("HIP events around each half-sweep on the library's stream "
+                                              "(gipuma_hip_launch_times), mean over the kernel's launches, this run"),
                          "half_sweep_ms_mean_all": ms_half_sweep,
                          "half_sweep_ms": [float(x) for x in hs.mean(axis=0)] if hs.size else None,
                          "algorithmic_bytes_per_launch": alg,
+                         "second_kernel": ({"kernel": "pm::sweep_kernel (accept replay + refinement of the same half-sweeps)",
+                                            "kernel_ms": ms_sweep_launch, "algorithmic_bytes_per_launch": alg_sweep,
+                                            "achieved": alg_sweep / (ms_sweep_launch * 1e-3) / 1e9, "unit": "GB/s"}
+                                           if dom_is_group else None),
+                         "half_sweep_pair": ({"algorithmic_bytes": alg_half_sweep, "ms": ms_pair,
+                                              "achieved": alg_half_sweep / (ms_pair * 1e-3) / 1e9, "unit": "GB/s",
+                                              "what": "SURVEY 8d's figure for the three reference kernels a half-sweep "
+                                                      "replaces over the time of both launches"} if dom_is_group else None),
+                         "group_kernel_ms": [float(x) for x in gm.mean(axis=0)] if gm.size else None,
                          "note": "compute/gather bound by construction (SURVEY F5): "
                                  "%.3g patch samples/s" % (samples_per_frame / (np.mean(total_ms) * 1e-3))},
             "quality": quality,
@@ -515,7 +552,7 @@ def main():
             lane_ops = pd["SQ_INSTS_VALU"] * 64.0
             peak = 256 * 4 * 32 * 2.4e9
             out["roofline_valu_kernel"] = {
-                "bound": "valu", "kernel": "pm::sweep_kernel", "achieved": lane_ops / (ms_launch * 1e-3) / 1e12,
+                "bound": "valu", "kernel": dom_name, "achieved": lane_ops / (ms_launch * 1e-3) / 1e12,
                 "peak": peak / 1e12, "unit": "T lane-instr/s", "frac": lane_ops / (ms_launch * 1e-3) / peak,
                 "valu_wave_instr_per_launch": pd["SQ_INSTS_VALU"], "kernel_ms": ms_launch,
                 "source": dict(imported_dom, counter="rocprofv3 --pmc SQ_INSTS_VALU")}

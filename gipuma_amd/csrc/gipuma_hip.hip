@@ -130,6 +130,10 @@ struct gipuma_hip_session {
     bool launch_times = false;
     std::vector<hipEvent_t> lev;
     std::vector<float> half_sweep_ms;  // of the last timed gipuma_hip_solve (gipuma_hip_launch_times)
+    std::vector<hipEvent_t> gev;       // [2 * half-sweep]: around the pm::group_kernel launch of a half-sweep
+    std::vector<char> gev_used;        // per half-sweep: it had such a launch
+    std::vector<float> group_ms;       // of the last timed solve (gipuma_hip_group_times)
+    int timed_half_sweep = -1;         // >= 0 while a timed solve is launching that half-sweep
     int n_pushed = 0;                  // leading half-sweeps of that solve that read pushed costs
     int n_push_consumed = 0;           // ... counted while the solve runs
 };
@@ -307,8 +311,15 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
     }
     // plane-keyed propagation for the later half-sweeps (any skip rule the sweep would apply is applied there)
     if (!push_now && s->group_ok && qualifies && half_sweep >= s->group_from && !(tune & Tune::kNoSkip)) {
+        const int th = s->timed_half_sweep;
+        const bool timed = th >= 0 && (size_t)(2 * th + 1) < s->gev.size();
+        if (timed) HIP_OK(hipEventRecord(s->gev[2 * th], s->stream));
         const int rc = launch_group(s, colour, (tune & Tune::kHistorySkip) != 0, tune);
         if (rc) return rc;
+        if (timed) {
+            HIP_OK(hipEventRecord(s->gev[2 * th + 1], s->stream));
+            s->gev_used[th] = 1;
+        }
         tune |= Tune::kPushConsume;
     }
     s->push_valid = -1;  // the planes of `colour` are about to change
@@ -721,11 +732,16 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     // plane-keyed propagation (pm_group.h) after the pushed half-sweeps: box 11 / 15, gray
     s->group_ok = s->push_ok && s->ch == 1 && (s->box == 11 || s->box == 15);
     if (s->push_launches <= 0) s->push_ok = false;
-    // OPT-IN (GIPUMA_HIP_GROUP_FROM=<first half-sweep>): measured on config C it halves the propagation stage's
-    // instructions (6.4e8 instead of 13.5e8 per late half-sweep) but runs them at a third of the fused kernel's issue
-    // rate (strips of 8-15 samples, an LDS-bound chain phase): 4.1-4.2 ms against 3.3 ms per late half-sweep
-    s->group_from = -1;
-    if (const char *t = exp_env("GROUP_FROM")) s->group_from = atoi(t);  // < 0 = never
+    // Default: from the fifth half-sweep on (the first four read pm::push_kernel's costs) for box 15 on frames of
+    // >= 1024 tiles: config C 90.6 -> 80.8 ms per view, any start between the third and the fifth half-sweep within
+    // 0.5 %; on config B's 300 tiles (one wave of workgroups) it loses 1.5 % (scripts/gpu_r04_sched.sh).
+    // GIPUMA_HIP_GROUP_FROM=<first half-sweep> (experiments): < 0 = never.
+    {
+        const size_t tiles = (size_t)((d->cols + pm::kTileW - 1) / pm::kTileW) *
+                             (size_t)((d->rows + pm::kSweepTileH - 1) / pm::kSweepTileH);
+        s->group_from = (s->box == 15 && tiles >= 1024) ? 4 : -1;
+    }
+    if (const char *t = exp_env("GROUP_FROM")) s->group_from = atoi(t);
     if (s->group_from < 0) s->group_ok = false;
     if (s->push_ok || s->group_ok) {
         // performance-only state too: without it every half-sweep evaluates its own propagation candidates
@@ -779,6 +795,7 @@ int gipuma_hip_destroy(gipuma_hip_session *s)
     for (auto &e : s->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto &e : s->lev) (void)hipEventDestroy(e);
+    for (auto &e : s->gev) (void)hipEventDestroy(e);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
     return 0;
@@ -915,11 +932,23 @@ int gipuma_hip_solve(gipuma_hip_session *s, gipuma_hip_timing *timing)
         s->lev.push_back(e);
     }
     s->n_push_consumed = 0;
-    if (n_lev) HIP_OK(hipEventRecord(s->lev[0], s->stream));
+    if (n_lev) {
+        while (s->gev.size() < 2 * (n_lev - 1)) {
+            hipEvent_t e;
+            HIP_OK(hipEventCreate(&e));
+            s->gev.push_back(e);
+        }
+        s->gev_used.assign(n_lev - 1, 0);
+        HIP_OK(hipEventRecord(s->lev[0], s->stream));
+    }
     for (int it = 0; it < s->iterations; it++) {  // gipuma.cu:1911-1941
-        if ((rc = gipuma_hip_sweep(s, it, GIPUMA_BLACK, GIPUMA_STAGE_ALL))) return rc;
-        if (n_lev) HIP_OK(hipEventRecord(s->lev[2 * it + 1], s->stream));
-        if ((rc = gipuma_hip_sweep(s, it, GIPUMA_RED, GIPUMA_STAGE_ALL))) return rc;
+        s->timed_half_sweep = n_lev ? 2 * it : -1;
+        rc = gipuma_hip_sweep(s, it, GIPUMA_BLACK, GIPUMA_STAGE_ALL);
+        if (!rc && n_lev) HIP_OK(hipEventRecord(s->lev[2 * it + 1], s->stream));
+        s->timed_half_sweep = n_lev ? 2 * it + 1 : -1;
+        if (!rc) rc = gipuma_hip_sweep(s, it, GIPUMA_RED, GIPUMA_STAGE_ALL);
+        s->timed_half_sweep = -1;
+        if (rc) return rc;
         if (n_lev) HIP_OK(hipEventRecord(s->lev[2 * it + 2], s->stream));
         launches += s->unfused ? 6 : 2;
     }
@@ -939,6 +968,9 @@ int gipuma_hip_solve(gipuma_hip_session *s, gipuma_hip_timing *timing)
         HIP_OK(hipEventSynchronize(s->ev[3]));
         s->half_sweep_ms.assign(n_lev - 1, 0.0f);
         for (size_t i = 1; i < n_lev; i++) HIP_OK(hipEventElapsedTime(&s->half_sweep_ms[i - 1], s->lev[i - 1], s->lev[i]));
+        s->group_ms.assign(n_lev - 1, 0.0f);
+        for (size_t i = 0; i + 1 < n_lev; i++)
+            if (s->gev_used[i]) HIP_OK(hipEventElapsedTime(&s->group_ms[i], s->gev[2 * i], s->gev[2 * i + 1]));
         s->n_pushed = s->n_push_consumed;
         if (s->launch_times) {
             fprintf(stderr, "gipuma_hip launch_ms:");
@@ -982,6 +1014,16 @@ int gipuma_hip_launch_times(gipuma_hip_session *s, float *ms_half_sweep, int cap
         for (int i = 0; i < n && i < capacity; i++) ms_half_sweep[i] = s->half_sweep_ms[i];
     if (n_half_sweeps) *n_half_sweeps = n;
     if (n_pushed) *n_pushed = s->n_pushed;
+    return 0;
+}
+
+int gipuma_hip_group_times(gipuma_hip_session *s, float *ms_group, int capacity, int *n_half_sweeps)
+{
+    if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
+    const int n = (int)s->group_ms.size();
+    if (ms_group)
+        for (int i = 0; i < n && i < capacity; i++) ms_group[i] = s->group_ms[i];
+    if (n_half_sweeps) *n_half_sweeps = n;
     return 0;
 }
 

@@ -254,6 +254,14 @@ class Session:
                   "gipuma_hip_launch_times")
         return [float(buf[i]) for i in range(min(cap, n.value))], npush.value
 
+    def group_times(self):
+        """ms of the pm::group_kernel launch of every half-sweep of the last timed solve (0 where it had none)"""
+        n = C.c_int(0)
+        cap = 2 * max(1, int(self.gs.params.iterations))
+        buf = (C.c_float * cap)()
+        abi.check(self.lib, self.lib.gipuma_hip_group_times(self.h, buf, cap, C.byref(n)), "gipuma_hip_group_times")
+        return [float(buf[i]) for i in range(min(cap, n.value))]
+
     def eval_cost(self, planes):
         planes = np.ascontiguousarray(planes, dtype=np.float32)
         out = np.empty((self.gs.rows, self.gs.cols), dtype=np.float32)

@@ -182,6 +182,11 @@ int gipuma_hip_solve(gipuma_hip_session *s, gipuma_hip_timing *timing);
  * with one cudaEvent pair, gipuma.cu:1908-1952.)  Pointers may be NULL. */
 int gipuma_hip_launch_times(gipuma_hip_session *s, float *ms_half_sweep, int capacity, int *n_half_sweeps,
                             int *n_pushed);
+/* Of the same solve: per half-sweep the device time of the pm::group_kernel launch that evaluated its propagation
+ * costs (0 where the half-sweep had none: the pushed ones and every half-sweep of a problem the kernel does not
+ * serve), so that the fused sweep launch's own time is ms_half_sweep[i] - ms_group[i].  These launches replace the
+ * cost evaluations of gipuma.cu:1437-1462 / :1571-1582.  Pointers may be NULL. */
+int gipuma_hip_group_times(gipuma_hip_session *s, float *ms_group, int capacity, int *n_half_sweeps);
 
 /* ---- one-shot: the whole of runcuda() ---- */
 /* norm4_out: rows*cols*4 host floats, cost_out: rows*cols host floats (either may be NULL).

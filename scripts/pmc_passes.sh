@@ -22,11 +22,14 @@ TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 FETCH_SIZE
 WRITE_SIZE
 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT
+SQ_INST_CYCLES_VALU SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU
+SQ_CYCLES SQ_THREAD_CYCLES_VALU
 LIST
 # per half-sweep of a view (16: a sweep kernel each + pm::push_kernel where the costs are pushed), then
 # each kernel on its own (mean per dispatch)
-python $R/scripts/rocprof_summary.py pmcunits $OUT ${PMC_UNITS:-16} sweep_ push_kernel > $OUT/pmc_summary.json
+python $R/scripts/rocprof_summary.py pmcunits $OUT ${PMC_UNITS:-16} sweep_ push_kernel group_kernel > $OUT/pmc_summary.json
 python $R/scripts/rocprof_summary.py pmc $OUT push_kernel > $OUT/pmc_summary_push.json
+python $R/scripts/rocprof_summary.py pmc $OUT group_kernel > $OUT/pmc_summary_group.json
 python $R/scripts/rocprof_summary.py pmc $OUT sweep_kernel > $OUT/pmc_summary_pixel_per_lane.json
 python $R/scripts/rocprof_summary.py pmc $OUT sweep_cols_kernel > $OUT/pmc_summary_column_per_lane.json
 python $R/scripts/rocprof_summary.py pmc $OUT init_kernel > $OUT/pmc_summary_init.json
