@@ -244,8 +244,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C", help="workload: A, B, C (default, the metric's config) or D")
-    ap.add_argument("--scene", default="smooth", choices=["smooth", "steps"],
-                    help="synthetic scene: smooth height field (default) or depth steps + occluder + sensor noise")
+    ap.add_argument("--scene", default="smooth", choices=["smooth", "steps", "patchy"],
+                    help="synthetic scene: smooth height field (default), depth steps + occluder + sensor noise, or the "
+                         "smooth surface with 30 %% flat albedo and a periodic texture band")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (exhaustive schedule, "
                     "second scene, host boundary)")
@@ -599,6 +600,22 @@ def main():
                                             "what": "same cameras and parameters, scene with +-30 mm depth steps, a raised "
                                                     "disc (occlusions) and sigma=2 sensor noise"}
                 del gs3, info3
+            # (c) the smooth geometry with the texture taken away where real scans lose it: 30 % of the surface
+            #     with a flat albedo (costs tie, bounds hold less often) and a periodic stripe band
+            if args.scene == "smooth" and not args.colour:
+                gs4, info4 = synth.build_problem(args.config, ref_view=ref_view, device=dev, keep_on_device=True,
+                                                 scene="patchy", **over)
+                gs4.desc.device_id = dev_index
+                with Session(gs4) as s4:
+                    s4.solve(timing=True)
+                    t4 = s4.solve(timing=True)
+                    q4 = quality_of(s4, info4)
+                out["value_scene_patchy"] = {"value": n_pix / (t4.ms_total * 1e-3) / 1e6, "unit": "Mpix/s",
+                                             "ms_per_step": float(t4.ms_total), "quality": q4,
+                                             "what": "same cameras, parameters and geometry; about 30 % of the surface "
+                                                     "with a flat albedo, a diagonal band with a periodic stripe texture "
+                                                     "(period 6 px), sigma=1 sensor noise"}
+                del gs4, info4
             # (d) throughput of a batch runner that keeps several reference views in flight on one GPU: one
             #     session (= one HIP stream) per view, whole solves enqueued back to back, one host wait
             #     at the end.  Launch tails of one view fill with workgroups of another, and kernels bound

@@ -101,6 +101,41 @@ class SteppedSurface(Surface):
         return torch.where(inside, z - lift, z)
 
 
+class PatchySurface(Surface):
+    """the smooth surface with the texture taken away where real scans lose it: about 30 % of the surface -- smooth
+    blobs -- carries a FLAT albedo (after the sensor noise of +-1 grey level every window sample there looks like
+    every other, so patch costs tie and bounds hold less often), and a diagonal band carries a PERIODIC stripe
+    texture (period about 6 pixels: many planes match equally well).  The geometry is the smooth surface's."""
+
+    def __init__(self, *a, flat_fraction=0.30, band=(0.25, 40.0), **k):
+        super().__init__(*a, **k)
+        self.flat_fraction = float(flat_fraction)
+        self.band = band  # (centre offset as a fraction of the wavelength, half-width in scene units)
+
+    def albedo(self, x, y):
+        tex = super().albedo(x, y)
+        # blobs: low-frequency noise thresholded so that `flat_fraction` of the area falls below the level
+        cell = self.wl * 0.18  # blobs of about a hundred pixels
+        blob = 0.6 * _value_noise(x / cell, y / cell, self.seed + 7001) + \
+            0.4 * _value_noise(x / (0.5 * cell), y / (0.5 * cell), self.seed + 7002)
+        # (value noise is a smoothed uniform field around 0.5: this level cuts off about the wanted share;
+        #  build_problem reports the share that was really rendered)
+        level = 0.5 + (self.flat_fraction - 0.5) * 0.62
+        flat = blob < level
+        tex = torch.where(flat, torch.full_like(tex, 0.45), tex)
+        # stripes across a diagonal band, period 6 pixel footprints, perpendicular to the band
+        d = (x + 0.6 * y) / math.sqrt(1.36) - self.band[0] * self.wl
+        stripes = 0.5 + 0.35 * torch.sin(2.0 * math.pi * (x - 0.6 * y) / math.sqrt(1.36) / (6.0 * self.fp))
+        return torch.where(torch.abs(d) < self.band[1], stripes, tex)
+
+    def flat_mask(self, x, y):
+        cell = self.wl * 0.18  # blobs of about a hundred pixels
+        blob = 0.6 * _value_noise(x / cell, y / cell, self.seed + 7001) + \
+            0.4 * _value_noise(x / (0.5 * cell), y / (0.5 * cell), self.seed + 7002)
+        d = (x + 0.6 * y) / math.sqrt(1.36) - self.band[0] * self.wl
+        return (blob < 0.5 + (self.flat_fraction - 0.5) * 0.62) & ~(torch.abs(d) < self.band[1])
+
+
 def render_march(surface, K, R, t, rows, cols, device="cpu", zspan=(380.0, 760.0), noise_sigma=0.0,
                  noise_seed=0):
     """render() for surfaces with discontinuities: first hit of each ray with z = h(x, y) by
@@ -290,11 +325,18 @@ def build_problem(cfg, ref_view=15, scene_seed=1234, solver_seed=1, device="cpu"
         u = z0 / 600.0
         surf = SteppedSurface(z0, amp, wl, tilt=tilt, pixel_footprint=footprint, seed=scene_seed, step=30.0 * u,
                               period=(300.0 * u, 260.0 * u), disc=(40.0 * u, -30.0 * u, 80.0 * u, 90.0 * u))
+    elif scene == "patchy":
+        # 30 % flat albedo + a periodic band, sensor noise sigma 1 (gray only)
+        u = z0 / 600.0
+        surf = PatchySurface(z0, amp, wl, tilt=tilt, pixel_footprint=footprint, seed=scene_seed, band=(0.25, 40.0 * u))
     else:
         surf = Surface(z0, amp, wl, tilt=tilt, pixel_footprint=footprint, seed=scene_seed)
     imgs, gt = [], None
     for i in range(cs.n):
-        if scene == "steps":
+        if scene == "patchy":
+            img, depth = render_march(surf, cs.K[i], cs.R[i], cs.t[i], rows, cols, device=device,
+                                      zspan=(z0 * 0.63, z0 * 1.27), noise_sigma=1.0, noise_seed=scene_seed + i)
+        elif scene == "steps":
             img, depth = render_march(surf, cs.K[i], cs.R[i], cs.t[i], rows, cols, device=device,
                                       zspan=(z0 * 0.63, z0 * 1.27), noise_sigma=2.0, noise_seed=scene_seed + i)
         else:

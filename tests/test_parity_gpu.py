@@ -765,9 +765,10 @@ def test_config_d_and_colour_default_equals_exhaustive(hip):
 def test_stepped_noisy_scene_whole_run_against_the_oracle(hip):
     """the scene bench.py reports as value_scene_steps -- depth steps of +-30 mm, an occluding disc, sigma = 2 sensor
     noise: candidates are accepted far more often, bounds hold less often, whole regions lose their best views --
-    with config C's cameras and parameters on an 800x600 frame: the whole free-running solve against the oracle's,
-    and the shipped schedule against the exhaustive one"""
-    gs, info = synth.build_problem("C", cols=800, rows=600, scene="steps")
+    with config C's cameras and parameters on an 832x640 frame (1040 tiles: bounded evaluation and the plane-keyed
+    propagation kernel run as on the full frame): the whole free-running solve against the oracle's, and the shipped
+    schedule against the exhaustive one"""
+    gs, info = synth.build_problem("C", cols=832, rows=640, scene="steps")
     a = _default_equals_exhaustive(gs, "stepped scene")
     o_n4, o_c = OracleState(gs).run()
     assert_same(a[0], o_n4, "stepped scene norm4")
@@ -776,22 +777,40 @@ def test_stepped_noisy_scene_whole_run_against_the_oracle(hip):
     assert (np.abs(a[0][..., 3] - gt) / gt < 0.01).mean() > 0.9  # (and it reconstructs the scene)
 
 
-@pytest.mark.parametrize("cfg,colour,iterations", [("D", False, 2), ("C", True, 2)])
-def test_config_d_and_colour_whole_frame_against_the_oracle(hip, cfg, colour, iterations):
-    """config D (20 views, box 25; scripts/dtu_accurate.sh) and the colour variant of config C's geometry, two
-    iterations each (push launches, column-per-lane launches, the first fused launch): the whole free-running
-    solve against the oracle's, every pixel of the 1600x1200 frame bit for bit.  (The oracle needs ~70 s per
-    config-D iteration and ~30 s per colour iteration on the box's 16 cores; with 3 iterations config D was
-    checked the same way once, 211 s.  All 8 iterations are covered launch by launch on bands and by
-    default == exhaustive on whole frames.)"""
+def test_patchy_scene_whole_run_against_the_oracle(hip):
+    """the scene bench.py reports as value_scene_patchy -- 30 % of the surface with a flat albedo (patch costs tie:
+    more near-ties for the argmin chain, fewer bounds that hold, more groups of one plane), a band with a periodic
+    texture, sigma = 1 sensor noise -- with config C's cameras and parameters on an 832x640 frame: the whole
+    free-running solve against the oracle's, and the shipped schedule against the exhaustive one"""
+    gs, info = synth.build_problem("C", cols=832, rows=640, scene="patchy")
+    ref = np.asarray(gs.images[0])
+    flat_share = float((np.abs(ref - np.round(20.0 + 215.0 * 0.45)) <= 3.0).mean())
+    assert 0.15 < flat_share < 0.5, flat_share   # the scenario bites: a large flat share was rendered
+    a = _default_equals_exhaustive(gs, "patchy scene")
+    o_n4, o_c = OracleState(gs).run()
+    assert_same(a[0], o_n4, "patchy scene norm4")
+    assert_same(a[1], o_c, "patchy scene cost")
+
+
+@pytest.mark.parametrize("cfg,colour", [("D", False), ("C", True)])
+def test_config_d_and_colour_all_iterations_against_the_oracle(hip, cfg, colour):
+    """config D's parameters (20 views, box 25, 8 iterations; scripts/dtu_accurate.sh) and the colour variant of
+    config C's (10 views, box 15, 8 iterations, T = float4), free-running through ALL their iterations -- every push
+    launch, every column-per-lane launch, every fused launch with the prefilter, bounded items and their redo
+    paths -- on an 832x640 frame of the DTU cameras (1040 tiles: the smallest 800x600-class frame that keeps the
+    schedule of the full frame -- bounded evaluation needs >= 1024 tiles): final maps and costs of every pixel
+    against the oracle's, bit for bit, and the shipped schedule against the exhaustive one.  (At 1600x1200 the same
+    configurations are covered launch by launch on bands and by default == exhaustive on whole frames; the oracle's
+    free-running solve of a full config-D frame takes ten minutes.)"""
     import time
-    gs, info = full_problem(cfg, colour=colour, iterations=iterations)
-    a = runcuda(gs)
+    gs, info = synth.build_problem(cfg, cols=832, rows=640, colour=colour)
+    assert gs.params.iterations == 8
+    a = _default_equals_exhaustive(gs, "config %s%s 832x640" % (cfg, " colour" if colour else ""))
     t0 = time.time()
     o_n4, o_c = OracleState(gs).run()
-    print("config %s%s, %d iterations: oracle free-running solve %.1f s" % (cfg, " colour" if colour else "", iterations, time.time() - t0))
-    assert_same(a[0], o_n4, "config %s colour=%r whole frame norm4" % (cfg, colour))
-    assert_same(a[1], o_c, "config %s colour=%r whole frame cost" % (cfg, colour))
+    print("config %s%s, 832x640, 8 iterations: oracle free-running solve %.1f s" % (cfg, " colour" if colour else "", time.time() - t0))
+    assert_same(a[0], o_n4, "config %s colour=%r 832x640 norm4" % (cfg, colour))
+    assert_same(a[1], o_c, "config %s colour=%r 832x640 cost" % (cfg, colour))
 
 
 @pytest.mark.parametrize("cfg,kw,bands", [("C", {}, [(0, 6), (604, 612)]), ("D", dict(iterations=2), [(0, 3), (606, 610)]),
