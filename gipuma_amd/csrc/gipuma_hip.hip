@@ -119,6 +119,8 @@ struct gipuma_hip_session {
     bool group_ok = false;
     int group_from = 0;
     bool group_attr_set = false;
+    bool group_fused = true;   // one launch per half-sweep (pm::sweep_group_kernel) instead of group_kernel + sweep_kernel
+    bool fused_attr_set = false;
     int box = 0;             // specialised window size, 0 = runtime
     int ch = 1;              // 1 = gray (T=float), 4 = colour (T=float4)
     unsigned tune = 0;
@@ -310,7 +312,10 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
         s->n_push_consumed++;
     }
     // plane-keyed propagation for the later half-sweeps (any skip rule the sweep would apply is applied there)
-    if (!push_now && s->group_ok && qualifies && half_sweep >= s->group_from && !(tune & Tune::kNoSkip)) {
+    bool fused_group = false;
+    if (!push_now && s->group_ok && s->group_fused && qualifies && half_sweep >= s->group_from && !(tune & Tune::kNoSkip)) {
+        fused_group = true;
+    } else if (!push_now && s->group_ok && qualifies && half_sweep >= s->group_from && !(tune & Tune::kNoSkip)) {
         const int th = s->timed_half_sweep;
         const bool timed = th >= 0 && (size_t)(2 * th + 1) < s->gev.size();
         if (timed) HIP_OK(hipEventRecord(s->gev[2 * th], s->stream));
@@ -360,6 +365,21 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
                            s->worder);
         HIP_OK(hipGetLastError());
         s->worder_valid = true;
+    }
+    if (fused_group) {
+        // propagation costs per plane + accept replay + refinement in one launch (pm_group.h)
+        typedef void (*fused_fn)(const pm::Problem *, float4 *, float *, int, uint32_t, unsigned);
+        const fused_fn fk = s->box == 15 ? pm::sweep_group_kernel<15> : pm::sweep_group_kernel<11>;
+        const size_t glds = sizeof(float) * (size_t)(s->box == 15 ? pm::GroupLayout<15>::total : pm::GroupLayout<11>::total);
+        const size_t flds = std::max(glds, s->lds_sweep);
+        if (!s->fused_attr_set) {
+            HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+            s->fused_attr_set = true;
+        }
+        hipLaunchKernelGGL(fk, dim3(gx * gy), dim3(pm::kThreads), flds, s->stream, s->dp, s->norm4, s->cost, colour,
+                           phase, tune);
+        HIP_OK(hipGetLastError());
+        return 0;
     }
     hipLaunchKernelGGL(k, dim3(gx * gy), dim3(pm::kThreads), lds, s->stream, s->dp, s->norm4,
                        s->cost, colour, phase, stages, tune);
@@ -742,6 +762,7 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         s->group_from = (s->box == 15 && tiles >= 1024) ? 4 : -1;
     }
     if (const char *t = exp_env("GROUP_FROM")) s->group_from = atoi(t);
+    if (const char *t = exp_env("GROUP_FUSED")) s->group_fused = atoi(t) != 0;  // 0: group_kernel + sweep_kernel, two launches
     if (s->group_from < 0) s->group_ok = false;
     if (s->push_ok || s->group_ok) {
         // performance-only state too: without it every half-sweep evaluates its own propagation candidates

@@ -270,15 +270,15 @@ struct GroupWalk {
     }
 };
 
-// grid = tiles of the sweep kernels; `colour`: the colour about to be swept (the consumers); `hist`: rule (H) is
-// valid for that half-sweep (the consumer replays only the slots whose producer changed)
+// The propagation costs of the tile whose state sweep_read_state<BOX, 1, 0, true> has just put into `L` (tile plane
+// at lds + kLutSize, L.needmask = the candidate slots that must be evaluated): Problem::push_cost[slot][pixel] for
+// every such slot.  All 256 lanes of the workgroup call it; it ends without a barrier (the wavefronts leave their
+// batch loops one by one).  `write_skipped`: slots the consumer will replay although a skip rule removed them get
+// MAXCOST (the stand-alone kernel: its consumer replays by rule (H) alone).
 template <int BOX>
-__global__ __launch_bounds__(kThreads, PM_GROUP_WG) void group_kernel(const Problem *__restrict__ P,
-                                                                      const float4 *__restrict__ norm4,
-                                                                      const float *__restrict__ cost, int colour,
-                                                                      int hist, unsigned tune)
+__device__ __forceinline__ void group_costs(const Problem *__restrict__ P, SweepLane &L, float *lds,
+                                            const float4 *__restrict__ norm4, int colour, int hist, bool write_skipped)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     using LY = GroupLayout<BOX>;
     constexpr int R = LY::R, N = LY::N, tw = LY::tw, NH = N / kGrpTaskLanes;  // window columns per chain lane
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -295,14 +295,6 @@ __global__ __launch_bounds__(kThreads, PM_GROUP_WG) void group_kernel(const Prob
             tick = now;
         }
     };
-    // ---- tile, state, skip rules: what sweep_setup does for the half-sweep itself ----
-    SweepLane L;
-    {
-        // rule (H) comes in through `hist`, like in pm::push_kernel; the other rules exactly as the sweep applies them
-        const unsigned t2 = (tune & ~(Tune::kPushConsume | Tune::kHistorySkip)) | (hist ? Tune::kHistorySkip : 0u);
-        sweep_read_state<BOX, 1, 0, true>(L, P, lds, norm4, cost, colour, 3u, t2, true);
-    }
-    lap(0);  // tile + state
     unsigned short *sbt = reinterpret_cast<unsigned short *>(lds + LY::sbt);
     unsigned short *gorder = reinterpret_cast<unsigned short *>(lds + LY::gorder);
     uint32_t *meta = reinterpret_cast<uint32_t *>(lds + LY::meta);
@@ -315,7 +307,7 @@ __global__ __launch_bounds__(kThreads, PM_GROUP_WG) void group_kernel(const Prob
     const char *lut_magic = (const char *)lds - kMagicBits;
 
     // every slot the consumer will replay gets a cost: MAXCOST where a skip rule says "cannot be accepted"
-    if (L.active) {
+    if (write_skipped && L.active) {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             int nb;
@@ -696,6 +688,76 @@ __global__ __launch_bounds__(kThreads, PM_GROUP_WG) void group_kernel(const Prob
         }
     }
     lap(3);  // batches (this workgroup's first wavefront)
+}
+
+// grid = tiles of the sweep kernels; `colour`: the colour about to be swept (the consumers); `hist`: rule (H) is
+// valid for that half-sweep (the consumer replays only the slots whose producer changed).  The stand-alone form:
+// the half-sweep itself is a sweep launch with Tune::kPushConsume.
+template <int BOX>
+__global__ __launch_bounds__(kThreads, PM_GROUP_WG) void group_kernel(const Problem *__restrict__ P,
+                                                                      const float4 *__restrict__ norm4,
+                                                                      const float *__restrict__ cost, int colour,
+                                                                      int hist, unsigned tune)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    SweepLane L;
+    // rule (H) comes in through `hist`, like in pm::push_kernel; the other rules exactly as the sweep applies them
+    const unsigned t2 = (tune & ~(Tune::kPushConsume | Tune::kHistorySkip)) | (hist ? Tune::kHistorySkip : 0u);
+    sweep_read_state<BOX, 1, 0, true>(L, P, lds, norm4, cost, colour, 3u, t2, true);
+    group_costs<BOX>(P, L, lds, norm4, colour, hist, true);
+}
+
+// One colour of one iteration (gipuma.cu:1353-1711, the three launches of sweep_kernel) with the propagation costs
+// evaluated per PLANE: set-up and skip rules of sweep_kernel, group_costs, then sweep_kernel's own accept replay,
+// refinement and write-back (sweep_body).  One launch instead of group_kernel + sweep_kernel: the tile and the state
+// are read once, and the workgroups of a CU are in different stages at any time -- the refinement stage waits on
+// scattered window loads, the strips of the propagation stage are bound by instruction issue.
+// Gray window-packed planes with float-encoded offsets, register combiner, box 11 / 15.
+template <int BOX>
+__global__ __launch_bounds__(kThreads, PM_GROUP_WG) void sweep_group_kernel(const Problem *__restrict__ P,
+                                                                            float4 *__restrict__ norm4,
+                                                                            float *__restrict__ cost, int colour,
+                                                                            uint32_t phase, unsigned tune)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using LY = GroupLayout<BOX>;
+    constexpr int tw = LY::tw, th = LY::th;
+    SweepLane L;
+    sweep_read_state<BOX, 1, 0, true>(L, P, lds, norm4, cost, colour, 7u, tune & ~Tune::kPushConsume, true);
+    group_costs<BOX>(P, L, lds, norm4, colour, (tune & Tune::kHistorySkip) != 0, false);
+    // The costs were written by other lanes of this workgroup: all its wavefronts share the CU's vector L1
+    // (write-through), so a workgroup-scope fence and the barrier make them visible to the replay below.
+    __threadfence_block();
+    __syncthreads();
+    // the float4 tile {I, gx1, gy1, I} the refinement loops read (stage_tile's second pass), from the plane:
+    // the plane lies where the tile goes, so it moves behind it first (where stage_tile stages it)
+    {
+        float *tile = lds + kLutSize, *plane = tile + 4 * tw * th;
+        float v[(tw * th + kThreads - 1) / kThreads];
+#pragma unroll
+        for (int e = 0; e < (tw * th + kThreads - 1) / kThreads; e++) {
+            const int k = (int)threadIdx.x + e * kThreads;
+            v[e] = k < tw * th ? tile[k] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < (tw * th + kThreads - 1) / kThreads; e++) {
+            const int k = (int)threadIdx.x + e * kThreads;
+            if (k < tw * th) plane[k] = v[e];
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < tw * th; k += kThreads) {
+            const int ty = k / tw, tx = k - ty * tw;
+            float gx1 = 0.0f, gy1 = 0.0f;
+            if (tx > 0 && tx < tw - 1 && ty > 0 && ty < th - 1) {
+                gx1 = plane[k + 1] - plane[k - 1];
+                gy1 = plane[k + tw] - plane[k - tw];
+            }
+            *reinterpret_cast<float4 *>(tile + 4 * k) = make_float4(plane[k], gx1, gy1, plane[k]);
+        }
+        __syncthreads();
+    }
+    sweep_body<BOX, true, true, true, 1>(P, L, lds, norm4, cost, colour, phase, 7u, tune & ~Tune::kPushConsume, true);
 }
 
 }  // namespace pm

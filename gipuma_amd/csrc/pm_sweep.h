@@ -856,17 +856,16 @@ __device__ __forceinline__ bool refine_step_items(const Problem *__restrict__ P,
 #ifndef PM_SWEEP_WG_C4
 #define PM_SWEEP_WG_C4 4  // ... and the colour one (4: 128 VGPRs)
 #endif
+// Everything of a fused half-sweep after its set-up (sweep_setup, or pm::sweep_group_kernel's own): the propagation
+// rounds over the workgroup's task list, the accept replay, the refinement steps, the write-back.  `pushed`: the
+// costs of the candidates in L.needmask are in Problem::push_cost (there is no task list).
 template <int BOX, bool U8, bool COMBINE_REG, bool INTERIOR, int CH>
-__global__ __launch_bounds__(kThreads, U8 ? (CH == 4 ? PM_SWEEP_WG_C4 : PM_SWEEP_WG) : 1) void sweep_kernel(const Problem *__restrict__ P,
-                                                         float4 *__restrict__ norm4, float *__restrict__ cost,
-                                                         int colour, uint32_t phase, unsigned stages,
-                                                         unsigned tune)
+__device__ __forceinline__ void sweep_body(const Problem *__restrict__ P, SweepLane &L, float *lds,
+                                           float4 *__restrict__ norm4, float *__restrict__ cost, int colour,
+                                           uint32_t phase, unsigned stages, unsigned tune, bool pushed)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     const Win<BOX> win(P);
     const int rows = P->rows, cols = P->cols;
-    SweepLane L;
-    sweep_setup<BOX, CH>(L, P, lds, norm4, cost, colour, stages, tune, U8);
     const int prop_rounds = (L.n_tasks + kThreads - 1) / kThreads;
     if (P->dbg != nullptr) {
         unsigned long long *d = P->dbg + (size_t)(phase & 63u) * kDbgSlots;
@@ -887,7 +886,7 @@ __global__ __launch_bounds__(kThreads, U8 ? (CH == 4 ? PM_SWEEP_WG_C4 : PM_SWEEP
     for (int r = 0; r <= prop_rounds + R.nref; r++) {
         if (r == prop_rounds) {
             __syncthreads();  // every wavefront runs the same number of rounds, so this is uniform
-            sweep_replay(L, P, norm4, (tune & Tune::kPushConsume) != 0);
+            sweep_replay(L, P, norm4, pushed);
             refine_begin(R, L, P, phase);
             if constexpr (ET && BOX > 0)
                 if (et_on) __syncthreads();  // refine_two_phase reuses the candidate costs the replay has just read
@@ -1011,6 +1010,19 @@ __global__ __launch_bounds__(kThreads, U8 ? (CH == 4 ? PM_SWEEP_WG_C4 : PM_SWEEP
         norm4[L.center] = L.pl;
         P->changed[L.center] = (unsigned char)(L.chg | ((tune & Tune::kAccumChanged) ? P->changed[L.center] : 0u));
     }
+}
+
+template <int BOX, bool U8, bool COMBINE_REG, bool INTERIOR, int CH>
+__global__ __launch_bounds__(kThreads, U8 ? (CH == 4 ? PM_SWEEP_WG_C4 : PM_SWEEP_WG) : 1) void sweep_kernel(const Problem *__restrict__ P,
+                                                         float4 *__restrict__ norm4, float *__restrict__ cost,
+                                                         int colour, uint32_t phase, unsigned stages,
+                                                         unsigned tune)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    SweepLane L;
+    sweep_setup<BOX, CH>(L, P, lds, norm4, cost, colour, stages, tune, U8);
+    sweep_body<BOX, U8, COMBINE_REG, INTERIOR, CH>(P, L, lds, norm4, cost, colour, phase, stages, tune,
+                                                   (tune & Tune::kPushConsume) != 0);
 }
 
 // The same half-sweep with the column-per-lane evaluation (see view_cost_cols): state, candidate
