@@ -265,8 +265,10 @@ int launch_group(gipuma_hip_session *s, int colour, bool hist, unsigned tune)
     const int gx = (s->cols + pm::kTileW - 1) / pm::kTileW;
     const int gy = (s->rows + pm::kSweepTileH - 1) / pm::kSweepTileH;
     typedef void (*group_fn)(const pm::Problem *, const float4 *, const float *, int, int, unsigned);
-    const group_fn k = s->box == 15 ? pm::group_kernel<15> : pm::group_kernel<11>;
-    const size_t lds = sizeof(float) * (size_t)(s->box == 15 ? pm::GroupLayout<15>::total : pm::GroupLayout<11>::total);
+    const group_fn k = s->box == 15 ? pm::group_kernel<15> : s->box == 25 ? pm::group_kernel<25> : pm::group_kernel<11>;
+    const size_t lds = sizeof(float) * (size_t)(s->box == 15   ? pm::GroupLayout<15>::total
+                                                : s->box == 25 ? pm::GroupLayout<25>::total
+                                                               : pm::GroupLayout<11>::total);
     if (!s->group_attr_set) {
         HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         s->group_attr_set = true;
@@ -369,8 +371,12 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
     if (fused_group) {
         // propagation costs per plane + accept replay + refinement in one launch (pm_group.h)
         typedef void (*fused_fn)(const pm::Problem *, float4 *, float *, int, uint32_t, unsigned);
-        const fused_fn fk = s->box == 15 ? pm::sweep_group_kernel<15> : pm::sweep_group_kernel<11>;
-        const size_t glds = sizeof(float) * (size_t)(s->box == 15 ? pm::GroupLayout<15>::total : pm::GroupLayout<11>::total);
+        const fused_fn fk = s->box == 15   ? pm::sweep_group_kernel<15>
+                            : s->box == 25 ? pm::sweep_group_kernel<25>
+                                           : pm::sweep_group_kernel<11>;
+        const size_t glds = sizeof(float) * (size_t)(s->box == 15   ? pm::GroupLayout<15>::total
+                                                     : s->box == 25 ? pm::GroupLayout<25>::total
+                                                                    : pm::GroupLayout<11>::total);
         const size_t flds = std::max(glds, s->lds_sweep);
         if (!s->fused_attr_set) {
             HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
@@ -684,6 +690,13 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     if (hp.box_h == hp.box_v && !(s->tune & Tune::kGenericBox) &&
         (hp.box_h == 11 || hp.box_h == 15 || hp.box_h == 25))
         s->box = hp.box_h;
+    {
+        // the specialised loops fold the gradient term's 1/16 into alpha and tau_gradient (dis_fold, pm_cost.h): exact
+        // unless alpha / 16 is subnormal or 16 tau_gradient overflows -- such parameters take the literal generic loop
+        const float a16 = hp.alpha * 0.0625f, tg16 = hp.tau_gradient * 16.0f;
+        const bool fold_exact = a16 * 16.0f == hp.alpha && (std::isfinite(tg16) || !std::isfinite(hp.tau_gradient));
+        if (!fold_exact) s->box = 0;
+    }
     s->combine_reg = hp.cost_comb == GIPUMA_COMB_BEST_N && hp.n_best >= 1 && hp.n_best <= 4 &&
                      !(s->tune & Tune::kGenericCombine);
     if ((s->tune & Tune::kNoInterior) && !(s->box == 15 && s->u8 && s->combine_reg)) {
@@ -750,7 +763,7 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     s->push_launches = s->ch == 4 ? 6 : s->box == 15 ? 4 : s->box == 25 ? 3 : 2;
     if (const char *t = exp_env("PUSH_LAUNCHES")) s->push_launches = atoi(t);  // A/B runs: 0 = never
     // plane-keyed propagation (pm_group.h) after the pushed half-sweeps: box 11 / 15, gray
-    s->group_ok = s->push_ok && s->ch == 1 && (s->box == 11 || s->box == 15);
+    s->group_ok = s->push_ok && s->ch == 1 && (s->box == 11 || s->box == 15 || s->box == 25);
     if (s->push_launches <= 0) s->push_ok = false;
     // Default: from the fifth half-sweep on (the first four read pm::push_kernel's costs) for box 15 on frames of
     // >= 1024 tiles: config C 90.6 -> 80.8 ms per view, any start between the third and the fifth half-sweep within
@@ -759,7 +772,7 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     {
         const size_t tiles = (size_t)((d->cols + pm::kTileW - 1) / pm::kTileW) *
                              (size_t)((d->rows + pm::kSweepTileH - 1) / pm::kSweepTileH);
-        s->group_from = (s->box == 15 && tiles >= 1024) ? 4 : -1;
+        s->group_from = tiles < 1024 ? -1 : s->box == 15 ? 4 : s->box == 25 ? 3 : -1;  // (right after the pushed half-sweeps)
     }
     if (const char *t = exp_env("GROUP_FROM")) s->group_from = atoi(t);
     if (const char *t = exp_env("GROUP_FUSED")) s->group_fused = atoi(t) != 0;  // 0: group_kernel + sweep_kernel, two launches

@@ -140,6 +140,13 @@ __device__ __forceinline__ float view_cost_loop(const Problem *__restrict__ P, c
 // instead of waiting for the one it has just issued.  Per sample the arithmetic and the order of
 // the cost accumulation are those of view_cost_loop -- the results are bit-identical.  (The two
 // requests past the last sample fetch clamped, valid addresses and are dropped.)
+// dis_fold.  pmCostComputation_shared (gipuma.cu:263-274): gradDis = min((|dgx| + |dgy|) * 0.0625, tau_g) and
+// dis = fmaf(alpha, gradDis, (1 - alpha) * colDis).  Scaling by a power of two is exact, so with s = |dgx| + |dgy|
+//     min(s / 16, tau_g) = min(s, 16 tau_g) / 16      and      fmaf(alpha, m / 16, c) = fmaf(alpha / 16, m, c)
+// (the same real number is rounded once): the specialised loops take alpha / 16 and 16 tau_g as their constants and
+// save the multiplication.  Exact unless alpha / 16 is subnormal or 16 tau_g overflows -- the host checks and falls
+// back to the literal loop (view_cost_loop, BOX == 0) -- or s / 16 itself is subnormal (s < 2^-122: a gradient
+// difference that small needs a sample within 2^-97 pixels of x = 0; the literal form rounds it, this one does not).
 struct WinReq {
     float a, b;
     u32x4_a4 w;
@@ -153,8 +160,8 @@ __device__ __forceinline__ float view_cost_pipe(const Problem *__restrict__ P, c
     static_assert(BOX > 0, "compile-time window only");
     constexpr int R = (BOX - 1) / 2, N = R + 1;  // offsets -R, -R+2, ..., R
     const float colsf = (float)P->cols, rowsf = (float)P->rows;
-    const float alpha = P->alpha, oma = 1.f - P->alpha;
-    const float tau_color = P->tau_color, tau_gradient = P->tau_gradient;
+    const float alpha16 = P->alpha * 0.0625f, oma = 1.f - P->alpha;  // (dis_term: the 1/16 of the gradient term folded in)
+    const float tau_color = P->tau_color, taug16 = P->tau_gradient * 16.0f;
     const float centre = tp0[0];
     const float pwf = (float)P->pw;
     const float magic_c = kMagicF + (float)(2 * P->pw + 2);
@@ -213,9 +220,9 @@ __device__ __forceinline__ float view_cost_pipe(const Problem *__restrict__ P, c
             const float colDiff = t4.w - tp5.sc;
             const float gradX = t4.y - tp5.gx2;
             const float gradY = t4.z - tp5.gy2;
-            const float gradDis = min_nc((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
+            const float gradDis = min_nc(__builtin_fabsf(gradX) + __builtin_fabsf(gradY), taug16);
             const float colDis = min_abs_nc(colDiff, tau_color);
-            const float dis = __builtin_fmaf(alpha, gradDis, oma * colDis);
+            const float dis = __builtin_fmaf(alpha16, gradDis, oma * colDis);
             cost = __builtin_fmaf(w, dis, cost);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -249,8 +256,8 @@ __device__ __forceinline__ float view_cost_pipe_range(const Problem *__restrict_
     static_assert(BOX > 0, "compile-time window only");
     constexpr int R = (BOX - 1) / 2, N = R + 1;
     const float colsf = (float)P->cols, rowsf = (float)P->rows;
-    const float alpha = P->alpha, oma = 1.f - P->alpha;
-    const float tau_color = P->tau_color, tau_gradient = P->tau_gradient;
+    const float alpha16 = P->alpha * 0.0625f, oma = 1.f - P->alpha;  // (dis_term: the 1/16 of the gradient term folded in)
+    const float tau_color = P->tau_color, taug16 = P->tau_gradient * 16.0f;
     const float centre = tp0[0];
     const float pwf = (float)P->pw;
     const float magic_c = kMagicF + (float)(2 * P->pw + 2);
@@ -303,9 +310,9 @@ __device__ __forceinline__ float view_cost_pipe_range(const Problem *__restrict_
             const float colDiff = t4.w - tp5.sc;
             const float gradX = t4.y - tp5.gx2;
             const float gradY = t4.z - tp5.gy2;
-            const float gradDis = min_nc((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
+            const float gradDis = min_nc(__builtin_fabsf(gradX) + __builtin_fabsf(gradY), taug16);
             const float colDis = min_abs_nc(colDiff, tau_color);
-            const float dis = __builtin_fmaf(alpha, gradDis, oma * colDis);
+            const float dis = __builtin_fmaf(alpha16, gradDis, oma * colDis);
             cost = __builtin_fmaf(w, dis, cost);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -373,8 +380,11 @@ __device__ __forceinline__ float view_cost_c4_loop(const Problem *__restrict__ P
     const uint32_t xmax = (uint32_t)(P->cols + 2), ymax = (uint32_t)(P->rows + 2);
     const int rows = P->rows, cols = P->cols, pitch = P->pitch;
     const float colsf = (float)cols, rowsf = (float)rows;
-    const float alpha = P->alpha, oma = 1.f - P->alpha;
-    const float tau_color = P->tau_color, tau_gradient = P->tau_gradient, gamma = P->gamma;
+    // (compile-time boxes: the 1/16 of the gradient term folded into the constants, see dis_fold; BOX == 0 is the
+    //  literal fallback the host selects when the folding would not be exact)
+    constexpr bool kFold = BOX > 0;
+    const float alpha16 = kFold ? P->alpha * 0.0625f : P->alpha, oma = 1.f - P->alpha;
+    const float tau_color = P->tau_color, taug16 = kFold ? P->tau_gradient * 16.0f : P->tau_gradient, gamma = P->gamma;
     const float4 centre = *reinterpret_cast<const float4 *>(tp0);
     const int hr = win.hrad(), vr = win.vrad();
     float cost = cost0;
@@ -436,9 +446,9 @@ __device__ __forceinline__ float view_cost_c4_loop(const Problem *__restrict__ P
                                   (right.z - left.z) - t[2].gx2);
             const float gY = l1_3((down.x - up.x) - t[0].gy2, (down.y - up.y) - t[1].gy2,
                                   (down.z - up.z) - t[2].gy2);
-            const float gradDis = min_nc((gX + gY) * 0.0625f, tau_gradient);
+            const float gradDis = min_nc(kFold ? gX + gY : (gX + gY) * 0.0625f, taug16);
             const float colDis = min_nc(colDiff, tau_color);
-            const float dis = __builtin_fmaf(alpha, gradDis, oma * colDis);
+            const float dis = __builtin_fmaf(alpha16, gradDis, oma * colDis);
             cost = __builtin_fmaf(w, dis, cost);
         }
         col++;
@@ -619,8 +629,8 @@ __device__ __forceinline__ float view_cost_cols(const Problem *__restrict__ P, c
     constexpr int R = (BOX - 1) / 2, N = R + 1;
     static_assert(BOX > 0 && N <= col_group<BOX>(), "one lane per window column");
     const float colsf = (float)P->cols, rowsf = (float)P->rows;
-    const float alpha = P->alpha, oma = 1.f - P->alpha;
-    const float tau_color = P->tau_color, tau_gradient = P->tau_gradient;
+    const float alpha16 = P->alpha * 0.0625f, oma = 1.f - P->alpha;  // (dis_term: the 1/16 of the gradient term folded in)
+    const float tau_color = P->tau_color, taug16 = P->tau_gradient * 16.0f;
     const float centre = tp0[0];
     const float pwf = (float)P->pw;
     const float magic_c = kMagicF + (float)(2 * P->pw + 2);
@@ -671,9 +681,9 @@ __device__ __forceinline__ float view_cost_cols(const Problem *__restrict__ P, c
         const float colDiff = t4.w - tp5.sc;
         const float gradX = t4.y - tp5.gx2;
         const float gradY = t4.z - tp5.gy2;
-        const float gradDis = min_nc((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
+        const float gradDis = min_nc(__builtin_fabsf(gradX) + __builtin_fabsf(gradY), taug16);
         const float colDis = min_abs_nc(colDiff, tau_color);
-        dis[k] = __builtin_fmaf(alpha, gradDis, oma * colDis);
+        dis[k] = __builtin_fmaf(alpha16, gradDis, oma * colDis);
     }
     // relay: after step c, lane c of the group holds the sum over columns 0..c in reference order
     float out = 0.0f;
@@ -707,8 +717,8 @@ __device__ __forceinline__ float view_cost_cols_c4(const Problem *__restrict__ P
     const gptr_bytes packed = (gptr_bytes)vc.packed;
     const uint32_t pw = (uint32_t)P->pw;
     const uint32_t xmax = (uint32_t)(P->cols + 2), ymax = (uint32_t)(P->rows + 2);
-    const float alpha = P->alpha, oma = 1.f - P->alpha;
-    const float tau_color = P->tau_color, tau_gradient = P->tau_gradient;
+    const float alpha16 = P->alpha * 0.0625f, oma = 1.f - P->alpha;  // (dis_term: the 1/16 of the gradient term folded in)
+    const float tau_color = P->tau_color, taug16 = P->tau_gradient * 16.0f;
     const float4 centre = *reinterpret_cast<const float4 *>(tp0);
     const float H1 = H[1], H4 = H[4], H7 = H[7];
     const int mycol = col < N ? col : N - 1;
@@ -768,9 +778,9 @@ __device__ __forceinline__ float view_cost_cols_c4(const Problem *__restrict__ P
                               (right.z - left.z) - t[2].gx2);
         const float gY = l1_3((down.x - up.x) - t[0].gy2, (down.y - up.y) - t[1].gy2,
                               (down.z - up.z) - t[2].gy2);
-        const float gradDis = min_nc((gX + gY) * 0.0625f, tau_gradient);
+        const float gradDis = min_nc(gX + gY, taug16);
         const float colDis = min_nc(colDiff, tau_color);
-        dis[k] = __builtin_fmaf(alpha, gradDis, oma * colDis);
+        dis[k] = __builtin_fmaf(alpha16, gradDis, oma * colDis);
     }
     // relay: after step c, lane c of the group holds the sum over columns 0..c in reference order
     float out = 0.0f;

@@ -29,8 +29,8 @@
 // issue rate; its chain phase was bound by three dependent LDS reads per term).  This version has NO workgroup
 // barrier after the set-up:
 //   * the groups are sorted by strip length, so the strips a wavefront walks together are equally long;
-//   * a BATCH -- a run of consecutive groups: at most kGrpBatchGroups groups, 64 strips, 32 tasks, kGrpBatchSamples
-//     samples per view -- belongs to ONE wavefront, which takes it from a shared cursor; strips
+//   * a BATCH -- a run of consecutive groups: at most kGrpBatchGroups groups, 64 strips, 64 tasks and as many
+//     samples per view as a wavefront's slice of LDS holds -- belongs to ONE wavefront, which takes it from a shared cursor; strips
 //     and chains of a batch only meet inside that wavefront (LDS operations of a wavefront complete in order);
 //   * per view a lane walks its strips in one continuous software pipeline (the windows of sample s+2 requested
 //     before sample s is reduced, across strip boundaries), and the first two windows of the NEXT view are requested
@@ -38,7 +38,7 @@
 //   * the 64 support weights of a task depend on its pixel alone: they are computed once per batch and stay in
 //     registers, half a window per lane (two lanes per task: the first sums the left window columns and hands its
 //     partial sum to the second); a chain term is one LDS read and one fmaf;
-//   * the homographies of a batch's (group, view) pairs are computed eight views at a time, one pair per lane;
+//   * the homographies of a batch's (group, view) pairs are computed four views at a time, one pair per lane;
 //   * 50 KB of LDS and at most 168 registers: three workgroups per CU.
 // The aggregate goes to Problem::push_cost[slot][pixel], where the half-sweep finds it (Tune::kPushConsume);
 // candidates the skip rules removed get MAXCOST there, which the strict < of the accept test (gipuma.cu:868)
@@ -62,17 +62,35 @@ constexpr int kGrpBatchStrips = 64;    // one strip per lane
 constexpr int kGrpTaskLanes = PM_GROUP_TASK_LANES;   // lanes per task in the chains: 1 (64 weights per lane) or 2 (32)
 constexpr int kGrpBatchTasks = 64 / kGrpTaskLanes;
 constexpr int kGrpBatchGroups = 8;     // (a group has at least 6 strips)
-constexpr int kGrpBatchSamples = 768;  // dis values of one view a wavefront's LDS slice holds
-constexpr int kGrpViewsPerH = 8;       // homographies are prepared this many views at a time: 8 groups x 8 views = 64 lanes
+// dis values of one view a wavefront's LDS slice holds: 64 strips of 16 (boxes 11, 15: three workgroups per CU) or of
+// 20 (box 25: two workgroups per CU) rows
+template <int BOX>
+__host__ __device__ constexpr int group_batch_samples()
+{
+    return BOX == 25 ? 1280 : 1024;
+}
+constexpr int kGrpViewsPerH = 4;       // homographies are prepared this many views at a time (8 groups x 4 views = 32 lanes;
+                                       // 8 views: 6 KB more LDS per workgroup, which the sample buffers use better)
 #ifndef PM_GROUP_WG
-#define PM_GROUP_WG 3  // workgroups per CU the kernel is compiled for (3: 168 VGPRs)
+#define PM_GROUP_WG 3  // workgroups per CU the kernels are compiled for (3: 168 VGPRs)
 #endif
+#ifndef PM_GROUP_WG25
+#define PM_GROUP_WG25 2  // ... box 25 (43 registers of weight indices, 13 samples per chain column; 3: spills)
+#endif
+template <int BOX>
+__host__ __device__ constexpr int group_wg()
+{
+    return BOX == 25 ? PM_GROUP_WG25 : PM_GROUP_WG;
+}
 
 template <int BOX>
 struct GroupLayout {  // offsets in 32-bit words into the dynamic LDS array
-    static_assert(BOX == 11 || BOX == 15, "instantiated window sizes");
+    static_assert(BOX == 11 || BOX == 15 || BOX == 25, "instantiated window sizes");
     static constexpr int R = (BOX - 1) / 2, N = R + 1;
-    static_assert(N % 2 == 0, "a task's window columns are split between two lanes");
+    static_assert(kGrpTaskLanes == 1 || N % 2 == 0, "a task's window columns are split between two lanes");
+    // the support weights of a chain lane's window columns stay in registers: as floats while they are at most 64,
+    // else (box 25: 169) as their table indices |dI|, four per register -- a chain term then costs a table read more
+    static constexpr bool byte_weights = (N / kGrpTaskLanes) * N > 64;
     static constexpr int tw = kTileW + 2 * N, th = kSweepTileH + 2 * N;
     static constexpr int max_rows = N + (kSweepTileH - 1) / 2;  // samples per strip: 8 + 7 = 15 for box 15
     static constexpr int max_cols = N + (kTileW - 1) / 2;       // strips per group: 8 + 15 = 23
@@ -89,17 +107,17 @@ struct GroupLayout {  // offsets in 32-bit words into the dynamic LDS array
     static constexpr int w_tgroup = w_sgroup + kGrpBatchStrips / 4;   // [kGrpBatchTasks] u8: ... of a task
     static constexpr int w_gplane = w_tgroup + 16;                    // [kGrpBatchGroups] float4  (64 bytes for tgroup)
     static constexpr int w_hbuf = w_gplane + 4 * kGrpBatchGroups;     // [kGrpViewsPerH][kGrpBatchGroups][12]: H, fast flag
-    static constexpr int w_dis = w_hbuf + kGrpViewsPerH * kGrpBatchGroups * 12;  // [kGrpBatchSamples]
-    static constexpr int w_stride = w_dis + kGrpBatchSamples;
+    static constexpr int batch_samples = group_batch_samples<BOX>();
+    static constexpr int w_dis = w_hbuf + kGrpViewsPerH * kGrpBatchGroups * 12;  // [batch_samples]
+    static constexpr int w_stride = w_dis + batch_samples;
     static constexpr int waves = gorder + kGrpMaxTasks / 2;  // [4] of the above
-    static constexpr int total = waves + 4 * w_stride;
     // while grouping, the wavefronts' areas hold: hash table | group id of a task (u16) | task list (u16) | counters
     static constexpr int g_hash = waves, g_gid = g_hash + kGrpHashSize, g_btask = g_gid + kGrpMaxTasks / 2,
                          g_cnt = g_btask + kGrpMaxTasks / 2;
-    static_assert(g_cnt + kGrpMaxTasks <= total, "the grouping tables alias the per-wavefront areas");
-    static_assert(kGrpBatchSamples >= max_cols * ((max_rows + 1) & ~1), "the largest possible group fits a wavefront's sample buffer");
+    static constexpr int total = waves + (4 * w_stride > g_cnt + kGrpMaxTasks - waves ? 4 * w_stride : g_cnt + kGrpMaxTasks - waves);
+    static_assert(batch_samples >= max_cols * ((max_rows + 1) & ~1), "the largest possible group fits a wavefront's sample buffer");
     static_assert(kGrpBatchStrips >= max_cols, "the strips of the largest possible group fit the lanes");
-    static_assert(total * 4 * PM_GROUP_WG <= 160 * 1024, "workgroups per CU");
+    static_assert(total * 4 * group_wg<BOX>() <= 160 * 1024, "workgroups per CU");
     static_assert((w_gplane % 4) == 0 && (w_hbuf % 4) == 0 && (waves % 4) == 0 && (w_stride % 4) == 0, "16-byte aligned float4 tables");
 };
 
@@ -158,10 +176,10 @@ struct GroupWalk {
         rowsf = (float)P->rows;
         pwf = (float)P->pw;
         magic_c = kMagicF + (float)(2 * P->pw + 2);
-        alpha = P->alpha;
+        alpha = P->alpha * 0.0625f;  // (dis_fold, pm_cost.h: alpha / 16 and 16 tau_g)
         oma = 1.f - P->alpha;
         tau_color = P->tau_color;
-        tau_gradient = P->tau_gradient;
+        tau_gradient = P->tau_gradient * 16.0f;
     }
     __device__ __forceinline__ StripView view_of(const float *__restrict__ hb) const
     {
@@ -216,7 +234,7 @@ struct GroupWalk {
         const float colDiff = I - tp5.sc;
         const float gradX = gx1 - tp5.gx2;
         const float gradY = gy1 - tp5.gy2;
-        const float gradDis = min_nc((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
+        const float gradDis = min_nc(__builtin_fabsf(gradX) + __builtin_fabsf(gradY), tau_gradient);
         const float colDis = min_abs_nc(colDiff, tau_color);
         *o = __builtin_fmaf(alpha, gradDis, oma * colDis);
     }
@@ -517,7 +535,7 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
         }
         // (strip lengths do not decrease along gorder: a group's own nr is the largest of the run up to it; rows are
         //  walked in pairs: a batch's strips get an even number of them)
-        const bool fits = g >= 0 && ic <= kGrpBatchStrips && it <= kGrpBatchTasks && ic * ((nr + 1) & ~1) <= kGrpBatchSamples;
+        const bool fits = g >= 0 && ic <= kGrpBatchStrips && it <= kGrpBatchTasks && ic * ((nr + 1) & ~1) <= LY::batch_samples;
         const unsigned long long fb = __ballot(fits);
         int cnt = fb == ~0ull ? 64 : (int)__builtin_ctzll(~fb);
         if (cnt == 0) cnt = 1;  // a single group always fits the strips and the buffer; more than 32 tasks: several rounds
@@ -606,18 +624,37 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
             }
             // support weights (weight_cu, gipuma.cu:186-193: 256 possible weights) of this lane's window columns,
             // column outer, row inner -- the order of the chain
-            float wgt[NH * N];
+            constexpr bool kByteW = LY::byte_weights;
+            float wgt[kByteW ? 1 : NH * N];
+            uint32_t widx[kByteW ? (NH * N + 3) / 4 : 1];
             {
                 const float centre = t_tp[0];
                 const float *tc = t_tp + (-R * tw - R + 2 * half * NH);
+                if constexpr (kByteW) {
+#pragma unroll
+                    for (int q = 0; q < (NH * N + 3) / 4; q++) widx[q] = 0u;
+                }
 #pragma unroll
                 for (int i = 0; i < NH; i++)
 #pragma unroll
                     for (int jj = 0; jj < N; jj++) {
-                        const float colorDis = __builtin_fabsf(tc[2 * jj * tw + 2 * i] - centre);
-                        wgt[i * N + jj] = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
+                        const float colorDis = __builtin_fabsf(tc[2 * jj * tw + 2 * i] - centre);  // an integer 0..255
+                        if constexpr (kByteW)
+                            widx[(i * N + jj) >> 2] |= ((__float_as_uint(colorDis + kMagicF) >> 2) & 0xffu) << (8 * ((i * N + jj) & 3));
+                        else
+                            wgt[i * N + jj] = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
                     }
             }
+            // the weight of window sample e of this lane's columns
+            auto weight = [&](int e) -> float {
+                if constexpr (kByteW) {
+                    // (byte e & 3 of its word, times four: the byte offset of the table entry)
+                    const uint32_t off = (e & 3) == 0 ? (widx[e >> 2] << 2) & 0x3fcu : (widx[e >> 2] >> (8 * (e & 3) - 2)) & 0x3fcu;
+                    return *(const float *)((const char *)lds + off);
+                } else {
+                    return wgt[e];
+                }
+            };
             ViewCombiner<true> comb;
 
             h_block(0);
@@ -654,6 +691,12 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
                 // are read while the column before is summed.
                 const float *dcol = dbuf + t_off;
                 float cst = 0.0f;
+                if constexpr (kByteW) {
+                    // (the table reads depend on the pixel alone: left to itself the compiler hoists all 169 of them
+                    //  out of the view loop and spills; the empty asm makes the indices opaque per view)
+#pragma unroll
+                    for (int q = 0; q < (NH * N + 3) / 4; q++) asm volatile("" : "+v"(widx[q]));
+                }
                 auto half_chain = [&]() {
                     float dv[2][N];
 #pragma unroll
@@ -666,7 +709,7 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int jj = 0; jj < N; jj++) cst = __builtin_fmaf(wgt[i * N + jj], dv[i & 1][jj], cst);
+                        for (int jj = 0; jj < N; jj++) cst = __builtin_fmaf(weight(i * N + jj), dv[i & 1][jj], cst);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 };
@@ -694,7 +737,7 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
 // valid for that half-sweep (the consumer replays only the slots whose producer changed).  The stand-alone form:
 // the half-sweep itself is a sweep launch with Tune::kPushConsume.
 template <int BOX>
-__global__ __launch_bounds__(kThreads, PM_GROUP_WG) void group_kernel(const Problem *__restrict__ P,
+__global__ __launch_bounds__(kThreads, group_wg<BOX>()) void group_kernel(const Problem *__restrict__ P,
                                                                       const float4 *__restrict__ norm4,
                                                                       const float *__restrict__ cost, int colour,
                                                                       int hist, unsigned tune)
@@ -714,7 +757,7 @@ __global__ __launch_bounds__(kThreads, PM_GROUP_WG) void group_kernel(const Prob
 // scattered window loads, the strips of the propagation stage are bound by instruction issue.
 // Gray window-packed planes with float-encoded offsets, register combiner, box 11 / 15.
 template <int BOX>
-__global__ __launch_bounds__(kThreads, PM_GROUP_WG) void sweep_group_kernel(const Problem *__restrict__ P,
+__global__ __launch_bounds__(kThreads, group_wg<BOX>()) void sweep_group_kernel(const Problem *__restrict__ P,
                                                                             float4 *__restrict__ norm4,
                                                                             float *__restrict__ cost, int colour,
                                                                             uint32_t phase, unsigned tune)

@@ -114,8 +114,8 @@ __device__ __forceinline__ float lb_item(const Problem *__restrict__ P, gptr_byt
     static_assert(BOX > 0, "compile-time window only");
     constexpr int R = (BOX - 1) / 2;
     const float colsf = (float)P->cols, rowsf = (float)P->rows;
-    const float alpha = P->alpha, oma = 1.f - P->alpha;
-    const float tau_color = P->tau_color, tau_gradient = P->tau_gradient;
+    const float alpha16 = P->alpha * 0.0625f, oma = 1.f - P->alpha;  // (dis_fold, pm_cost.h)
+    const float tau_color = P->tau_color, taug16 = P->tau_gradient * 16.0f;
     const float centre = tp0[0];
     const float pwf = (float)P->pw;
     const float magic_c = kMagicF + (float)(2 * P->pw + 2);
@@ -160,9 +160,9 @@ __device__ __forceinline__ float lb_item(const Problem *__restrict__ P, gptr_byt
         const float colDiff = t4.w - tp5.sc;
         const float gradX = t4.y - tp5.gx2;
         const float gradY = t4.z - tp5.gy2;
-        const float gradDis = min_nc((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
+        const float gradDis = min_nc(__builtin_fabsf(gradX) + __builtin_fabsf(gradY), taug16);
         const float colDis = min_abs_nc(colDiff, tau_color);
-        const float dis = __builtin_fmaf(alpha, gradDis, oma * colDis);
+        const float dis = __builtin_fmaf(alpha16, gradDis, oma * colDis);
         return __builtin_fmaf(w, dis, acc);
     };
 
@@ -234,8 +234,8 @@ __device__ __forceinline__ float lb_item_c4(const Problem *__restrict__ P, const
     const gptr_bytes packed = (gptr_bytes)vc.packed;
     const uint32_t pw = (uint32_t)P->pw;
     const uint32_t xmax = (uint32_t)(P->cols + 2), ymax = (uint32_t)(P->rows + 2);
-    const float alpha = P->alpha, oma = 1.f - P->alpha;
-    const float tau_color = P->tau_color, tau_gradient = P->tau_gradient;
+    const float alpha16 = P->alpha * 0.0625f, oma = 1.f - P->alpha;  // (dis_fold, pm_cost.h)
+    const float tau_color = P->tau_color, taug16 = P->tau_gradient * 16.0f;
     const float4 centre = *reinterpret_cast<const float4 *>(tp0);
     typedef const __attribute__((address_space(1))) uint32_t *gptr_u32;
     const gptr_u32 op = (gptr_u32)ordp;
@@ -288,9 +288,9 @@ __device__ __forceinline__ float lb_item_c4(const Problem *__restrict__ P, const
                               (right.z - left.z) - t[2].gx2);
         const float gY = l1_3((down.x - up.x) - t[0].gy2, (down.y - up.y) - t[1].gy2,
                               (down.z - up.z) - t[2].gy2);
-        const float gradDis = min_nc((gX + gY) * 0.0625f, tau_gradient);
+        const float gradDis = min_nc(gX + gY, taug16);
         const float colDis = min_nc(colDiff, tau_color);
-        const float dis = __builtin_fmaf(alpha, gradDis, oma * colDis);
+        const float dis = __builtin_fmaf(alpha16, gradDis, oma * colDis);
         return __builtin_fmaf(w, dis, acc);
     };
     float lb = 0.0f, prev = 0.0f;

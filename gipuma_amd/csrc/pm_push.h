@@ -133,10 +133,10 @@ struct PushEval {
         rowsf = (float)P->rows;
         pwf = (float)P->pw;
         magic_c = kMagicF + (float)(2 * P->pw + 2);
-        alpha = P->alpha;
+        alpha = P->alpha * 0.0625f;  // (dis_fold, pm_cost.h: alpha / 16 and 16 tau_g)
         oma = 1.f - P->alpha;
         tau_color = P->tau_color;
-        tau_gradient = P->tau_gradient;
+        tau_gradient = P->tau_gradient * 16.0f;
         l = lane_in_group;
     }
     __device__ __forceinline__ void producer(float nxf, float nyf_, int tnx, int tny)
@@ -221,7 +221,7 @@ struct PushEval {
             const float colDiff = t4.w - tp5.sc;
             const float gradX = t4.y - tp5.gx2;
             const float gradY = t4.z - tp5.gy2;
-            const float gradDis = min_nc((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
+            const float gradDis = min_nc(__builtin_fabsf(gradX) + __builtin_fabsf(gradY), tau_gradient);
             const float colDis = min_abs_nc(colDiff, tau_color);
             dgrp[slot(s)] = __builtin_fmaf(alpha, gradDis, oma * colDis);
 #ifndef PM_PUSH_NO_SCHED_BARRIER
@@ -299,7 +299,7 @@ struct PushEval {
                     const float colDiff = t4.w - tp5.sc;
                     const float gradX = t4.y - tp5.gx2;
                     const float gradY = t4.z - tp5.gy2;
-                    const float gradDis = min_nc((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
+                    const float gradDis = min_nc(__builtin_fabsf(gradX) + __builtin_fabsf(gradY), tau_gradient);
                     const float colDis = min_abs_nc(colDiff, tau_color);
                     const int e = kPushLanes * s + l;
                     if (e < NFp) dfam[e] = __builtin_fmaf(alpha, gradDis, oma * colDis);
@@ -588,10 +588,10 @@ struct PushEvalC4 {
 
     __device__ __forceinline__ void init(const Problem *__restrict__ P, int lane_in_group)
     {
-        alpha = P->alpha;
+        alpha = P->alpha * 0.0625f;  // (dis_fold, pm_cost.h: alpha / 16 and 16 tau_g)
         oma = 1.f - P->alpha;
         tau_color = P->tau_color;
-        tau_gradient = P->tau_gradient;
+        tau_gradient = P->tau_gradient * 16.0f;
         pw = (uint32_t)P->pw;
         xmax = (uint32_t)(P->cols + 2);
         ymax = (uint32_t)(P->rows + 2);
@@ -677,7 +677,7 @@ struct PushEvalC4 {
                     const float colDiff = l1_3(ta.x - t[0].sc, ta.y - t[1].sc, ta.z - t[2].sc);
                     const float gX = l1_3(ta.w - t[0].gx2, tb.x - t[1].gx2, tb.y - t[2].gx2);
                     const float gY = l1_3(tb.z - t[0].gy2, tb.w - t[1].gy2, tc - t[2].gy2);
-                    const float gradDis = min_nc((gX + gY) * 0.0625f, tau_gradient);
+                    const float gradDis = min_nc(gX + gY, tau_gradient);
                     const float colDis = min_nc(colDiff, tau_color);
                     const int e = kPushLanes * s + l;
                     if (e < NFp) dfam[e] = __builtin_fmaf(alpha, gradDis, oma * colDis);

@@ -470,18 +470,22 @@ def test_push_propagation_other_boxes(hip, cfg):
     assert_same(c, o_c, "push box %d cost" % cfg["blocksize"])
 
 
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("push,group_from", [(0, 0), (2, 2), (4, 5), (3, -1)])
 @pytest.mark.parametrize("cfg", [dict(cols=160, rows=112, n_src=4, blocksize=15, iterations=4, n_best=3),
                                  dict(cols=150, rows=100, n_src=7, blocksize=11, iterations=3, n_best=2),
-                                 dict(cols=64, rows=48, n_src=2, blocksize=15, iterations=3, n_best=4)])
-def test_plane_keyed_propagation_is_bit_identical(hip, cfg, push, group_from):
-    """pm::group_kernel: the candidates of a tile grouped by plane bits, dis evaluated once per group on the
-    bounding box of its windows, the reference's chain per task; from half-sweep `group_from` on (after `push`
-    pushed ones; -1: never) -- always the oracle's bits, on frames that are not multiples of the tile too"""
+                                 dict(cols=64, rows=48, n_src=2, blocksize=15, iterations=3, n_best=4),
+                                 dict(cols=150, rows=100, n_src=5, blocksize=25, iterations=3, n_best=3)])
+def test_plane_keyed_propagation_is_bit_identical(hip, cfg, push, group_from, fused):
+    """pm::sweep_group_kernel / pm::group_kernel (pm_group.h): the candidates of a tile grouped by plane bits, dis
+    evaluated once per group on the bounding box of its windows, the reference's chain per task; from half-sweep
+    `group_from` on (after `push` pushed ones; -1: never), fused with the sweep (one launch per half-sweep) or as a
+    launch of its own in front of it -- always the oracle's bits, on frames that are not multiples of the tile too;
+    boxes 11, 15 (chain weights in registers) and 25 (their table indices in registers)"""
     gs, _ = synth.build_problem(synth.tiny_config(**cfg))
     o = OracleState(gs).run()
-    a = _with_env({"GIPUMA_HIP_PUSH_LAUNCHES": push, "GIPUMA_HIP_GROUP_FROM": group_from, "GIPUMA_HIP_ET_FORCE": 1},
-                  lambda: runcuda(gs))
+    a = _with_env({"GIPUMA_HIP_PUSH_LAUNCHES": push, "GIPUMA_HIP_GROUP_FROM": group_from, "GIPUMA_HIP_ET_FORCE": 1,
+                   "GIPUMA_HIP_GROUP_FUSED": fused}, lambda: runcuda(gs))
     assert_same(a[0], o[0], "grouped propagation push %d from %d norm4" % (push, group_from))
     assert_same(a[1], o[1], "grouped propagation push %d from %d cost" % (push, group_from))
 
