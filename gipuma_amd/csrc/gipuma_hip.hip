@@ -103,6 +103,8 @@ struct gipuma_hip_session {
     // pixel, listed by pm::weight_order_kernel at the start of every solve (init_planes) or before the
     // first sweep that needs them
     unsigned long long *dbg = nullptr;  // device, Problem::dbg (GIPUMA_HIP_COUNTS=1)
+    float4 *seen_ring = nullptr;        // device, Problem::seen_ring (skip rule (S), colour sessions)
+    unsigned char *seen_pos = nullptr;  // device, Problem::seen_pos
     uint32_t *worder = nullptr;  // device, Problem::worder
     bool worder_valid = false;
     size_t et_hint_bytes = 0;
@@ -670,6 +672,24 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         CREATE_OK(hipMemsetAsync(s->et_stat, 0, 3 * pm::kEtSlot * sizeof(unsigned), s->stream));
         hp.et_stat = s->et_stat;
     }
+    // Skip rule (S) -- a ring of the last 8 planes a pixel's propagation evaluated, 129 B per pixel -- only where a
+    // propagation candidate is expensive and nothing else shares its evaluation: colour sessions (their images are four
+    // times the gray ones; measured with the round-3 library: late half-sweeps 6-9 % fewer tasks).  Gray sessions run
+    // the plane-keyed propagation kernel instead and keep their footprint (config C: 0.3 % for 248 MB).
+    // Performance only: without the memory the rule is off.
+    if (s->ch == 4 && !(s->tune & (Tune::kNoSeen | Tune::kNoSkip))) {
+        if (hipMalloc(&s->seen_ring, (size_t)pm::kSeenRing * np * sizeof(float4)) == hipSuccess &&
+            hipMalloc(&s->seen_pos, np) == hipSuccess) {
+            CREATE_OK(hipMemsetAsync(s->seen_pos, 0, np, s->stream));
+            hp.seen_ring = s->seen_ring;
+            hp.seen_pos = s->seen_pos;
+        } else {
+            (void)hipGetLastError();
+            if (s->seen_ring) (void)hipFree(s->seen_ring);
+            s->seen_ring = nullptr;
+            s->seen_pos = nullptr;
+        }
+    }
     if (exp_env("COUNTS") && atoi(exp_env("COUNTS"))) {  // experiment aid
         CREATE_OK(hipMalloc(&s->dbg, 64 * pm::kDbgSlots * sizeof(unsigned long long)));
         CREATE_OK(hipMemsetAsync(s->dbg, 0, 64 * pm::kDbgSlots * sizeof(unsigned long long), s->stream));
@@ -823,6 +843,8 @@ int gipuma_hip_destroy(gipuma_hip_session *s)
     if (s->et_hint) (void)hipFree(s->et_hint);
     if (s->worder) (void)hipFree(s->worder);
     if (s->dbg) (void)hipFree(s->dbg);
+    if (s->seen_ring) (void)hipFree(s->seen_ring);
+    if (s->seen_pos) (void)hipFree(s->seen_pos);
     if (s->et_stat) (void)hipFree(s->et_stat);
     if (s->norm4) (void)hipFree(s->norm4);
     if (s->cost) (void)hipFree(s->cost);
@@ -843,6 +865,7 @@ int gipuma_hip_init_planes(gipuma_hip_session *s)
     HIP_OK(hipMemsetAsync(s->et_hint, 0, s->et_hint_bytes, s->stream));
     HIP_OK(hipMemsetAsync(s->et_stat, 0, 3 * pm::kEtSlot * sizeof(unsigned), s->stream));
     s->worder_valid = false;  // (listed again by the first sweep: part of every solve)
+    if (s->seen_pos) HIP_OK(hipMemsetAsync(s->seen_pos, 0, (size_t)s->rows * s->cols, s->stream));  // rule (S): new planes
     const int rc = launch_dense(s, true, s->norm4, s->cost);
     if (!rc) s->costs_trusted = true;
     s->finalized = false;
@@ -934,6 +957,7 @@ int gipuma_hip_set_state(gipuma_hip_session *s, const float *norm4_host, const f
         HIP_OK(hipMemcpyAsync(s->norm4, norm4_host, np * sizeof(float4), hipMemcpyHostToDevice, s->stream));
     if (cost_host)
         HIP_OK(hipMemcpyAsync(s->cost, cost_host, np * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    if (s->seen_pos) HIP_OK(hipMemsetAsync(s->seen_pos, 0, np, s->stream));  // rule (S): a cost may have gone up
     HIP_OK(hipStreamSynchronize(s->stream));
     s->costs_trusted = false;
     s->prev1 = s->prev2 = -1;

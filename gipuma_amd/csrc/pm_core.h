@@ -61,6 +61,11 @@ struct Problem {  // lives in device memory, read through scalar loads (wave-uni
     // statistics, < 0: prefilter off.  Performance only: ANY list gives the same results.
     const uint32_t *worder;
     int lb_k;
+    // rule (S) of the sweep kernels' exact skipping (colour sessions only, see gipuma_hip_create): per pixel a ring
+    // of the last kSeenRing planes its propagation evaluated ([kSeenRing][rows*cols] float4) and one byte of ring
+    // state (next slot | 8 once full); nullptr: rule off.  Cleared by the host whenever planes are (re-)installed.
+    float4 *seen_ring;
+    unsigned char *seen_pos;
     // experiment aid (GIPUMA_HIP_COUNTS=1): [64 phases][kDbgSlots] event counters, or nullptr
     unsigned long long *dbg;
     RefCam rc;
@@ -256,7 +261,8 @@ __host__ __device__ constexpr int lb_max()  // samples listed per pixel: a quart
     constexpr int S = ((BOX + 1) / 2) * ((BOX + 1) / 2);
     return S / 4 >= kLbMax ? kLbMax : ((S / 4) & ~1);
 }
-// Problem::dbg slots: propagation tasks, (unused), refinement items, items the
+constexpr int kSeenRing = 8;
+// Problem::dbg slots: propagation tasks, candidates removed by rule (S), refinement items, items the
 // prefilter / phase 1 left open, refinement candidates redone, refinement candidates
 constexpr int kDbgSlots = 8;
 enum { kDbgTasks = 0, kDbgSeen = 1, kDbgItems = 2, kDbgItemsOpen = 3, kDbgRedo = 4, kDbgCands = 5 };
@@ -306,6 +312,7 @@ struct Tune {  // experiment switches (GIPUMA_HIP_TUNE), all default off
                               kGenericCombine = 16, kRowMajorTiles = 32, kNoSkip = 64,
                               kUntrustedCosts = 128,  // set by the host after gipuma_hip_set_state
                               kPushConsume = 1u << 18,   // host-internal: propagation costs come from Problem::push_cost
+                              kNoSeen = 1u << 22,        // no skip rule (S) (planes this pixel evaluated before)
                               kNoTwoPhase = 1u << 19,    // refinement bounded per wavefront (v11) instead of two-phase (refine_two_phase)
                               kNoMagicAddr = 1u << 30,  // integer window addressing (bits 8..17: band height)
                               kOwnerMajorTasks = 1u << 29,   // always owner-major task lists

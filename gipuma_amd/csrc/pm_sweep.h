@@ -239,6 +239,13 @@ __global__ __launch_bounds__(kThreads) void init_cols_kernel(const Problem *__re
 //         (Problem::changed), then this pixel met exactly that plane one half-sweep ago and did
 //         not end up with it at a lower cost -- it was rejected against a cost that has only
 //         decreased since, or accepted and improved upon
+//     (S) (where the host gives the pixels a ring, Problem::seen_ring: colour sessions) a plane this pixel's
+//         propagation evaluated before -- one of its last kSeenRing evaluated candidates: its cost F is a pure
+//         function of (pixel, plane); it was then rejected against a cost that has only decreased since (or for its
+//         depth, which is a pure function too), or accepted -- and the pixel's cost has been <= F ever since.  This
+//         does not need the state invariant, only that the pixel's cost never increases between the two
+//         half-sweeps: the host clears the rings whenever planes are (re-)installed.  A plane that spreads over a
+//         patch reaches a pixel that turned it down again and again, through every neighbour that adopts it
 //   can never be accepted (strict <, gipuma.cu:868) and is not evaluated.  On config C the
 //   evaluated candidates drop from 8 to 2.7 per pixel by the last half-sweep.  Because the
 //   per-wavefront MAXIMUM stays near 8, the surviving (pixel, candidate) pairs of the whole
@@ -371,6 +378,30 @@ __device__ __forceinline__ void sweep_read_state(SweepLane &L, const Problem *__
                 for (int j = 0; j < k; j++)
                     if (fresh && ((valid >> j) & 1u) && same_bits(cands[k], cands[j])) fresh = false;  // (D)
                 if (fresh) needmask |= 1u << k;
+            }
+            if (P->seen_ring != nullptr && !(tune & Tune::kNoSeen)) {  // (S)
+                const size_t np = (size_t)rows * (size_t)cols;
+                const unsigned st = P->seen_pos[L.center];
+                const int cnt = (st & 8u) ? kSeenRing : (int)(st & 7u);
+#pragma unroll
+                for (int a = 0; a < kSeenRing; a++) {
+                    if (a < cnt && needmask != 0u) {
+                        const float4 e = P->seen_ring[(size_t)a * np + (size_t)L.center];
+#pragma unroll
+                        for (int k = 0; k < 8; k++)
+                            if (((needmask >> k) & 1u) && same_bits(cands[k], e)) needmask &= ~(1u << k);
+                    }
+                }
+                unsigned pos = st & 7u, full = st & 8u;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if ((needmask >> k) & 1u) {
+                        P->seen_ring[(size_t)pos * np + (size_t)L.center] = cands[k];
+                        pos = (pos + 1u) & 7u;
+                        if (pos == 0u) full = 8u;
+                    }
+                }
+                P->seen_pos[L.center] = (unsigned char)(pos | full);
             }
         }
         L.needmask = needmask;

@@ -1115,6 +1115,38 @@ def test_inconsistent_installed_costs_are_not_trusted(hip, tiny_problem):
                     assert (kept & (before_c != o.cost)).sum() > 50
 
 
+def test_seen_rule_is_reset_when_planes_are_installed(hip):
+    """skip rule (S) (colour sessions) -- a plane a pixel's propagation evaluated before can never be accepted,
+    because the pixel's cost only decreases -- must forget its rings when the caller installs state: after two
+    iterations every stored cost is RAISED through gipuma_hip_set_state (planes unchanged), so planes
+    turned down before are acceptable again; the oracle, which always evaluates, adopts many of them."""
+    gs, _ = synth.build_problem(synth.tiny_config(cols=96, rows=64, n_src=3, blocksize=11, iterations=4, n_best=2),
+                                colour=True)
+    o = OracleState(gs)
+    o.init_planes()
+    with Session(gs) as s:
+        s.init_planes()
+        for it in range(2):
+            for colour in (abi.BLACK, abi.RED):
+                s.sweep(it, colour)
+                o.sweep(it, colour)
+        n4, c = s.get_state()
+        assert_same(n4, o.norm4, "before the install, norm4")
+        o.cost[:] = o.cost * np.float32(4.0) + np.float32(1.0)
+        s.set_state(o.norm4, o.cost)
+        changed = 0
+        for it in range(2, 4):
+            for colour in (abi.BLACK, abi.RED):
+                before = o.norm4.copy()
+                s.sweep(it, colour, abi.STAGE_CLOSE | abi.STAGE_FAR)
+                o.sweep(it, colour, abi.STAGE_CLOSE | abi.STAGE_FAR)
+                n4, c = s.get_state()
+                assert_same(n4, o.norm4, "after the install, it %d colour %d norm4" % (it, colour))
+                assert_same(c, o.cost, "after the install, it %d colour %d cost" % (it, colour))
+                changed += int((bits(before) != bits(o.norm4)).any(-1).sum())
+        assert changed > 500  # the scenario bites: propagation alone re-adopts planes
+
+
 def test_shared_planes_with_consistent_costs(hip, tiny_problem):
     """the opposite corner: after init_planes the invariant holds, force many identical neighbour
     planes through the kernels' own state by running sweeps to convergence and compare each"""
