@@ -475,8 +475,7 @@ def main():
         cols_l = int(_exp_env("GIPUMA_HIP_COLS_LAUNCHES", {15: "4", 25: "3"}.get(box, "0"))) if not args.colour else 0
         n_launch = 2 * iterations
         # leading half-sweeps whose propagation costs are pushed by pm::push_kernel (pm_push.h: boxes 11 / 15 / 25, gray, best-N <= 4)
-        push_l = int(_exp_env("GIPUMA_HIP_PUSH_LAUNCHES", "6" if args.colour else {15: "4", 25: "3", 11: "2"}.get(box, "0"))) \
-            if ((box in (11, 15, 25) and not args.colour) or (box == 15 and args.colour)) and gs.params.n_best <= 4 and n_views > 0 else 0
+        push_l = int(hs_pushed)  # (what the library reports for the timed solve: gipuma_hip_launch_times)
         push_l = max(0, min(push_l, n_launch))
         out = {
             "metric": "Mpixels/sec/GPU (1600x1200, 10 src views, 8 iters)"

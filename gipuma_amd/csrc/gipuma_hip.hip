@@ -267,8 +267,12 @@ int launch_group(gipuma_hip_session *s, int colour, bool hist, unsigned tune)
     const int gx = (s->cols + pm::kTileW - 1) / pm::kTileW;
     const int gy = (s->rows + pm::kSweepTileH - 1) / pm::kSweepTileH;
     typedef void (*group_fn)(const pm::Problem *, const float4 *, const float *, int, int, unsigned);
-    const group_fn k = s->box == 15 ? pm::group_kernel<15> : s->box == 25 ? pm::group_kernel<25> : pm::group_kernel<11>;
-    const size_t lds = sizeof(float) * (size_t)(s->box == 15   ? pm::GroupLayout<15>::total
+    const group_fn k = s->ch == 4     ? pm::group_kernel<15, 4>
+                       : s->box == 15 ? pm::group_kernel<15>
+                       : s->box == 25 ? pm::group_kernel<25>
+                                      : pm::group_kernel<11>;
+    const size_t lds = sizeof(float) * (size_t)(s->ch == 4     ? pm::GroupLayout<15, 4>::total
+                                                : s->box == 15 ? pm::GroupLayout<15>::total
                                                 : s->box == 25 ? pm::GroupLayout<25>::total
                                                                : pm::GroupLayout<11>::total);
     if (!s->group_attr_set) {
@@ -373,10 +377,12 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
     if (fused_group) {
         // propagation costs per plane + accept replay + refinement in one launch (pm_group.h)
         typedef void (*fused_fn)(const pm::Problem *, float4 *, float *, int, uint32_t, unsigned);
-        const fused_fn fk = s->box == 15   ? pm::sweep_group_kernel<15>
+        const fused_fn fk = s->ch == 4     ? pm::sweep_group_kernel<15, 4>
+                            : s->box == 15 ? pm::sweep_group_kernel<15>
                             : s->box == 25 ? pm::sweep_group_kernel<25>
                                            : pm::sweep_group_kernel<11>;
-        const size_t glds = sizeof(float) * (size_t)(s->box == 15   ? pm::GroupLayout<15>::total
+        const size_t glds = sizeof(float) * (size_t)(s->ch == 4     ? pm::GroupLayout<15, 4>::total
+                                                     : s->box == 15 ? pm::GroupLayout<15>::total
                                                      : s->box == 25 ? pm::GroupLayout<25>::total
                                                                     : pm::GroupLayout<11>::total);
         const size_t flds = std::max(glds, s->lds_sweep);
@@ -779,11 +785,14 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
                  ((s->ch == 1 && hp.magic_addr && (s->box == 11 || s->box == 15 || s->box == 25)) ||
                   (s->ch == 4 && s->box == 15));
     // measured: config C 4 (5 and 6 level), config D 3 (4 level, 6 loses), config B 2 (+1 %)
-    // colour (config C geometry): 6 (4: -1.3 %, 8: -0.7 %, 16: -7 %)
-    s->push_launches = s->ch == 4 ? 6 : s->box == 15 ? 4 : s->box == 25 ? 3 : 2;
+    // colour (config C geometry): 3 where the plane-keyed kernel takes over afterwards (frames of >= 1024 tiles:
+    // 2 / 3 / 4 / 6 pushed half-sweeps 195.5 / 195.7 / 197.7 / 205.9 ms per view), else 6 (4: -1.3 %, 8: -0.7 %, 16: -7 %)
+    const size_t sweep_tiles = (size_t)((d->cols + pm::kTileW - 1) / pm::kTileW) *
+                               (size_t)((d->rows + pm::kSweepTileH - 1) / pm::kSweepTileH);
+    s->push_launches = s->ch == 4 ? (sweep_tiles >= 1024 ? 3 : 6) : s->box == 15 ? 4 : s->box == 25 ? 3 : 2;
     if (const char *t = exp_env("PUSH_LAUNCHES")) s->push_launches = atoi(t);  // A/B runs: 0 = never
     // plane-keyed propagation (pm_group.h) after the pushed half-sweeps: box 11 / 15, gray
-    s->group_ok = s->push_ok && s->ch == 1 && (s->box == 11 || s->box == 15 || s->box == 25);
+    s->group_ok = s->push_ok && ((s->ch == 1 && (s->box == 11 || s->box == 15 || s->box == 25)) || (s->ch == 4 && s->box == 15));
     if (s->push_launches <= 0) s->push_ok = false;
     // Default: from the fifth half-sweep on (the first four read pm::push_kernel's costs) for box 15 on frames of
     // >= 1024 tiles: config C 90.6 -> 80.8 ms per view, any start between the third and the fifth half-sweep within
@@ -792,9 +801,12 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     {
         const size_t tiles = (size_t)((d->cols + pm::kTileW - 1) / pm::kTileW) *
                              (size_t)((d->rows + pm::kSweepTileH - 1) / pm::kSweepTileH);
-        s->group_from = tiles < 1024 ? -1 : s->box == 15 ? 4 : s->box == 25 ? 3 : -1;  // (right after the pushed half-sweeps)
+        s->group_from = tiles < 1024 ? -1 : s->ch == 4 ? 3 : s->box == 15 ? 4 : s->box == 25 ? 3 : -1;  // (right after the pushed half-sweeps)
     }
     if (const char *t = exp_env("GROUP_FROM")) s->group_from = atoi(t);
+    // one launch per half-sweep (pm::sweep_group_kernel) for gray; colour: two (its sweep kernel is compiled for four
+    // workgroups per CU, the fused one holds two: 219 ms fused against 205 ms per view, config C's geometry in colour)
+    s->group_fused = s->ch == 1;
     if (const char *t = exp_env("GROUP_FUSED")) s->group_fused = atoi(t) != 0;  // 0: group_kernel + sweep_kernel, two launches
     if (s->group_from < 0) s->group_ok = false;
     if (s->push_ok || s->group_ok) {

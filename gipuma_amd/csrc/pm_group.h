@@ -48,6 +48,7 @@
 // Supported: gray window-packed planes with float-encoded offsets, box 11 / 15, best-N with n_best <= 4.
 // GIPUMA_HIP_COUNTS=1 reports its phase clocks.
 #pragma once
+#include <type_traits>
 #include "pm_device.h"
 
 namespace pm {
@@ -77,15 +78,16 @@ constexpr int kGrpViewsPerH = 4;       // homographies are prepared this many vi
 #ifndef PM_GROUP_WG25
 #define PM_GROUP_WG25 2  // ... box 25 (43 registers of weight indices, 13 samples per chain column; 3: spills)
 #endif
-template <int BOX>
+template <int BOX, int CH = 1>
 __host__ __device__ constexpr int group_wg()
 {
-    return BOX == 25 ? PM_GROUP_WG25 : PM_GROUP_WG;
+    return (BOX == 25 || CH == 4) ? PM_GROUP_WG25 : PM_GROUP_WG;  // (colour: a 24 KB float4 tile, three windows per sample)
 }
 
-template <int BOX>
+template <int BOX, int CH = 1>
 struct GroupLayout {  // offsets in 32-bit words into the dynamic LDS array
     static_assert(BOX == 11 || BOX == 15 || BOX == 25, "instantiated window sizes");
+    static_assert(CH == 1 || BOX == 15, "colour: box 15");
     static constexpr int R = (BOX - 1) / 2, N = R + 1;
     static_assert(kGrpTaskLanes == 1 || N % 2 == 0, "a task's window columns are split between two lanes");
     // the support weights of a chain lane's window columns stay in registers: as floats while they are at most 64,
@@ -95,9 +97,10 @@ struct GroupLayout {  // offsets in 32-bit words into the dynamic LDS array
     static constexpr int max_rows = N + (kSweepTileH - 1) / 2;  // samples per strip: 8 + 7 = 15 for box 15
     static constexpr int max_cols = N + (kTileW - 1) / 2;       // strips per group: 8 + 15 = 23
     // sweep_read_state<.., PLANE_ONLY> stages the scalar plane of reference texels -- clamp-to-edge point samples --
-    // right behind the weight table; the gradients are two subtractions per sample, the ones stage_tile does
-    static constexpr int plane = kLutSize;                  // [th][tw]
-    static constexpr int misc = plane + tw * th;            // counters
+    // right behind the weight table; the gradients are two subtractions per sample, the ones stage_tile does.
+    // Colour: the float4 {B, G, R, 0} tile of the sweep kernels, which the refinement stage of the fused kernel reads too.
+    static constexpr int plane = lut_size<CH>();            // [th][tw] (x CH)
+    static constexpr int misc = plane + CH * tw * th;       // counters
     static constexpr int meta = misc + 128;                 // [2048] per group: first task | min lx << 11 | min ly << 16 | (ncols - N) << 20 | (nrows - N) << 24
     static constexpr int sbt = meta + kGrpMaxTasks + 4;     // [2048] u16: the tasks (owner | slot << 8) ordered by group
     static constexpr int gorder = sbt + kGrpMaxTasks / 2;   // [2048] u16: group ids ordered by strip length
@@ -115,9 +118,9 @@ struct GroupLayout {  // offsets in 32-bit words into the dynamic LDS array
     static constexpr int g_hash = waves, g_gid = g_hash + kGrpHashSize, g_btask = g_gid + kGrpMaxTasks / 2,
                          g_cnt = g_btask + kGrpMaxTasks / 2;
     static constexpr int total = waves + (4 * w_stride > g_cnt + kGrpMaxTasks - waves ? 4 * w_stride : g_cnt + kGrpMaxTasks - waves);
-    static_assert(batch_samples >= max_cols * ((max_rows + 1) & ~1), "the largest possible group fits a wavefront's sample buffer");
+    static_assert(batch_samples >= max_cols * max_rows, "the largest possible group fits a wavefront's sample buffer");
     static_assert(kGrpBatchStrips >= max_cols, "the strips of the largest possible group fit the lanes");
-    static_assert(total * 4 * group_wg<BOX>() <= 160 * 1024, "workgroups per CU");
+    static_assert(total * 4 * group_wg<BOX, CH>() <= 160 * 1024, "workgroups per CU");
     static_assert((w_gplane % 4) == 0 && (w_hbuf % 4) == 0 && (waves % 4) == 0 && (w_stride % 4) == 0, "16-byte aligned float4 tables");
 };
 
@@ -274,17 +277,161 @@ struct GroupWalk {
         reduce(t, a, b, I, xr, xl, yd, yu, o);
         __builtin_amdgcn_sched_barrier(0);
     }
-    // the nr rows (even, wave-uniform) of this lane's strip for the view whose first two requests are in (A, B):
+    // the nr rows (wave-uniform, >= 3) of this lane's strip for the view whose first two requests are in (A, B):
     // A walks the even rows, B the odd ones; nothing is in flight at the end
     template <bool FAST>
     __device__ __forceinline__ void body(gptr_bytes magic_base, int nr, const StripView &sv, Set &A, Set &B) const
     {
-        for (int r = 0; r < nr - 2; r += 2) {
+        const int n_pairs = (nr - 2) >> 1;  // pairs of rows both of which request (rows r, r + 1 with r + 3 < nr)
+        for (int r = 0; r < n_pairs; r++) {
             step<FAST, false>(magic_base, sv, A);
             step<FAST, false>(magic_base, sv, B);
         }
-        step<FAST, true>(magic_base, sv, A);
-        step<FAST, true>(magic_base, sv, B);
+        if (nr & 1) {  // (wave-uniform) rows nr - 3 (requests the last one), nr - 2, nr - 1
+            step<FAST, false>(magic_base, sv, A);
+            step<FAST, true>(magic_base, sv, B);
+            step<FAST, true>(magic_base, sv, A);
+        } else {
+            step<FAST, true>(magic_base, sv, A);
+            step<FAST, true>(magic_base, sv, B);
+        }
+    }
+};
+
+// The same walk for -color_processing (T = float4; view_cost_c4_loop in pm_cost.h): three 16-byte window loads and
+// three tap sets per sample (integer window addressing: three words per texel do not fit the float-encoded offsets),
+// l1_norm(float4) reductions in the reference's order (gipuma.cu:174-179), the reference-side terms from the float4
+// {B, G, R, 0} tile: the texel and its four neighbours.
+template <int BOX>
+struct GroupWalkC4 {
+    using LY = GroupLayout<BOX, 4>;
+    static constexpr int tw = LY::tw;
+    float alpha, oma, tau_color, tau_gradient;  // wave-uniform (alpha / 16 and 16 tau_g: dis_fold, pm_cost.h)
+    uint32_t pw, xmax, ymax;
+    float qx, qy0;
+    const float *tcol;  // the float4 texel of the strip's first sample point
+    float *out;
+    int grp;
+
+    struct Req {
+        float a, b;
+        u32x4_a4 q0, q1, q2;
+    };
+    struct Set {
+        float qy;
+        const float *tq;
+        float *o;
+        Req req;
+    };
+
+    __device__ __forceinline__ void init(const Problem *__restrict__ P)
+    {
+        alpha = P->alpha * 0.0625f;
+        oma = 1.f - P->alpha;
+        tau_color = P->tau_color;
+        tau_gradient = P->tau_gradient * 16.0f;
+        pw = (uint32_t)P->pw;
+        xmax = (uint32_t)(P->cols + 2);
+        ymax = (uint32_t)(P->rows + 2);
+    }
+    __device__ __forceinline__ StripView view_of(const float *__restrict__ hb) const
+    {
+        const float4 a = *reinterpret_cast<const float4 *>(hb + 12 * grp);
+        const float4 b = *reinterpret_cast<const float4 *>(hb + 12 * grp + 4);
+        const float4 c = *reinterpret_cast<const float4 *>(hb + 12 * grp + 8);
+        StripView s;
+        s.X0 = __builtin_fmaf(a.x, qx, a.z);
+        s.Y0 = __builtin_fmaf(a.w, qx, b.y);
+        s.Z0 = __builtin_fmaf(b.z, qx, c.x);
+        s.H1 = a.y;
+        s.H4 = b.x;
+        s.H7 = b.w;
+        return s;
+    }
+    template <bool FAST>
+    __device__ __forceinline__ Req request(gptr_bytes packed, const StripView &s, float qy) const
+    {
+        const float X = __builtin_fmaf(s.H1, qy, s.X0);
+        const float Y = __builtin_fmaf(s.H4, qy, s.Y0);
+        const float Z = __builtin_fmaf(s.H7, qy, s.Z0);
+        const float rz = recip<FAST>(Z);
+        const float sx = X * rz, sy = Y * rz;
+        const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
+        Req r;
+        r.a = sx - fx0;
+        r.b = sy - fy0;
+        const uint32_t Xw = min(cvt_u32_sat(fx0 + 2.0f), xmax);
+        const uint32_t Yw = min(cvt_u32_sat(fy0 + 2.0f), ymax);
+        const gptr_bytes base = packed + (Yw * pw + Xw) * 12u;
+        r.q0 = *(gptr_u32x4)(base);
+        r.q1 = *(gptr_u32x4)(base + 16);
+        r.q2 = *(gptr_u32x4)(base + 32);
+        return r;
+    }
+    template <bool FAST>
+    __device__ __forceinline__ void first(gptr_bytes packed, const float *__restrict__ hb, StripView &sv, Set &A, Set &B) const
+    {
+        sv = view_of(hb);
+        A.req = request<FAST>(packed, sv, qy0);
+        B.req = request<FAST>(packed, sv, qy0 + 2.0f);
+        A.qy = qy0 + 4.0f;
+        B.qy = qy0 + 6.0f;
+        A.tq = tcol;
+        B.tq = tcol + 4 * 2 * tw;
+        A.o = out;
+        B.o = out + 1;
+    }
+    template <bool FAST, bool LAST>
+    __device__ __forceinline__ void step(gptr_bytes packed, const StripView &sv, Set &S) const
+    {
+        const float *tq = S.tq;
+        float *o = S.o;
+        const float4 lv = *reinterpret_cast<const float4 *>(tq);
+        const float4 left = *reinterpret_cast<const float4 *>(tq - 4), right = *reinterpret_cast<const float4 *>(tq + 4);
+        const float4 up = *reinterpret_cast<const float4 *>(tq - 4 * tw), down = *reinterpret_cast<const float4 *>(tq + 4 * tw);
+        // word 3k+c = column k, channel c (view_cost_c4_loop)
+        const Req &q = S.req;
+        const Tex12 tb = GroupWalk<BOX>::unpack(u32x4_a4{q.q0.x, q.q0.w, q.q1.z, q.q2.y});
+        const Tex12 tg = GroupWalk<BOX>::unpack(u32x4_a4{q.q0.y, q.q1.x, q.q1.w, q.q2.z});
+        const Tex12 tr = GroupWalk<BOX>::unpack(u32x4_a4{q.q0.z, q.q1.y, q.q2.x, q.q2.w});
+        const float a = q.a, b = q.b;
+        __builtin_amdgcn_sched_barrier(0);
+        if (!LAST) {
+            S.req = request<FAST>(packed, sv, S.qy);
+            S.qy += 4.0f;
+            S.tq = tq + 4 * 4 * tw;
+            S.o = o + 2;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        auto taps = [&](const Tex12 &t) -> Taps {
+            return taps12(a, b, t.t01, t.t02, t.t10, t.t11, t.t12, t.t13, t.t20, t.t21, t.t22, t.t23, t.t31, t.t32);
+        };
+        const Taps t0 = taps(tb), t1 = taps(tg), t2 = taps(tr);
+        // pmCostComputation_shared for T = float4, gipuma.cu:251-274
+        const float colDiff = l1_3(lv.x - t0.sc, lv.y - t1.sc, lv.z - t2.sc);
+        const float gX = l1_3((right.x - left.x) - t0.gx2, (right.y - left.y) - t1.gx2, (right.z - left.z) - t2.gx2);
+        const float gY = l1_3((down.x - up.x) - t0.gy2, (down.y - up.y) - t1.gy2, (down.z - up.z) - t2.gy2);
+        const float gradDis = min_nc(gX + gY, tau_gradient);
+        const float colDis = min_nc(colDiff, tau_color);
+        *o = __builtin_fmaf(alpha, gradDis, oma * colDis);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <bool FAST>
+    __device__ __forceinline__ void body(gptr_bytes packed, int nr, const StripView &sv, Set &A, Set &B) const
+    {
+        const int n_pairs = (nr - 2) >> 1;
+        for (int r = 0; r < n_pairs; r++) {
+            step<FAST, false>(packed, sv, A);
+            step<FAST, false>(packed, sv, B);
+        }
+        if (nr & 1) {
+            step<FAST, false>(packed, sv, A);
+            step<FAST, true>(packed, sv, B);
+            step<FAST, true>(packed, sv, A);
+        } else {
+            step<FAST, true>(packed, sv, A);
+            step<FAST, true>(packed, sv, B);
+        }
     }
 };
 
@@ -293,11 +440,11 @@ struct GroupWalk {
 // every such slot.  All 256 lanes of the workgroup call it; it ends without a barrier (the wavefronts leave their
 // batch loops one by one).  `write_skipped`: slots the consumer will replay although a skip rule removed them get
 // MAXCOST (the stand-alone kernel: its consumer replays by rule (H) alone).
-template <int BOX>
+template <int BOX, int CH = 1>
 __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, SweepLane &L, float *lds,
                                             const float4 *__restrict__ norm4, int colour, int hist, bool write_skipped)
 {
-    using LY = GroupLayout<BOX>;
+    using LY = GroupLayout<BOX, CH>;
     constexpr int R = LY::R, N = LY::N, tw = LY::tw, NH = N / kGrpTaskLanes;  // window columns per chain lane
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rows = P->rows, cols = P->cols, n = P->n_sel;
@@ -502,7 +649,7 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
     float4 *gplane = reinterpret_cast<float4 *>(wbase + LY::w_gplane);
     float *hbuf = wbase + LY::w_hbuf;
     float *dbuf = wbase + LY::w_dis;
-    GroupWalk<BOX> W;
+    typename std::conditional<CH == 4, GroupWalkC4<BOX>, GroupWalk<BOX> >::type W;
     W.init(P);
     // chains: one lane per task, or (kGrpTaskLanes == 2) lane tl sums the left window columns of task tl and lane
     // 32 + tl the right ones
@@ -533,9 +680,8 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
                 it += ut;
             }
         }
-        // (strip lengths do not decrease along gorder: a group's own nr is the largest of the run up to it; rows are
-        //  walked in pairs: a batch's strips get an even number of them)
-        const bool fits = g >= 0 && ic <= kGrpBatchStrips && it <= kGrpBatchTasks && ic * ((nr + 1) & ~1) <= LY::batch_samples;
+        // (strip lengths do not decrease along gorder: a group's own nr is the largest of the run up to it)
+        const bool fits = g >= 0 && ic <= kGrpBatchStrips && it <= kGrpBatchTasks && ic * nr <= LY::batch_samples;
         const unsigned long long fb = __ballot(fits);
         int cnt = fb == ~0ull ? 64 : (int)__builtin_ctzll(~fb);
         if (cnt == 0) cnt = 1;  // a single group always fits the strips and the buffer; more than 32 tasks: several rounds
@@ -545,7 +691,7 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
         // (wave-uniform, in scalar registers: they steer the loops below)
         const int n_strips = __builtin_amdgcn_readfirstlane(__shfl(ic, cnt - 1));
         const int n_alltasks = __builtin_amdgcn_readfirstlane(__shfl(it, cnt - 1));
-        const int nr_b = (__builtin_amdgcn_readfirstlane(__shfl(nr, cnt - 1)) + 1) & ~1;
+        const int nr_b = __builtin_amdgcn_readfirstlane(__shfl(nr, cnt - 1));
         if (lane < cnt) {
             const int sp = ic - nc, tp = it - nt;
             wtab[4 * lane + 0] = (unsigned short)g;
@@ -576,7 +722,7 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
             const int s_lx = (int)((gm >> 11) & 31u) - R + 2 * c, s_ly = (int)((gm >> 16) & 15u) - R;
             W.qx = (float)(L.x0 + s_lx);
             W.qy0 = (float)(L.y0 + s_ly);
-            W.tcol = plane + ((s_ly + L.hh) * tw + (s_lx + L.hw));
+            W.tcol = plane + CH * ((s_ly + L.hh) * tw + (s_lx + L.hw));
             W.out = dbuf + s * nr_b;
             W.grp = j;
         }
@@ -598,8 +744,8 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
             }
         };
         auto view_fast = [&](const float *hb) -> bool { return __all(hb[12 * W.grp + 9] != 0.0f); };
-        auto view_base = [&](int v) -> gptr_bytes {
-            return (gptr_bytes)((uintptr_t)P->view[v].packed - (uintptr_t)kMagicBits);
+        auto view_base = [&](int v) -> gptr_bytes {  // gray: the base of the float-encoded offsets; colour: the packed plane
+            return CH == 4 ? (gptr_bytes)P->view[v].packed : (gptr_bytes)((uintptr_t)P->view[v].packed - (uintptr_t)kMagicBits);
         };
 
         // -- rounds of at most kGrpBatchTasks tasks (more than one only for a single group offered to more pixels) --
@@ -607,7 +753,7 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
             const int n_bt = min(kGrpBatchTasks, n_alltasks - t_lo);
             // this lane's task: sample-buffer offset of its half window, slot, pixel, support weights of its columns
             int t_off = 0, t_slot = 0, t_center = 0;
-            const float *t_tp = plane + (L.hh * tw + L.hw);
+            const float *t_tp = plane + CH * (L.hh * tw + L.hw);
             const bool has = tl < n_bt;
             if (has) {
                 const int j = n_alltasks <= kGrpBatchTasks ? (int)tgroup[tl] : 0;
@@ -620,14 +766,27 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
                         ((oly - (int)((gm >> 16) & 15u)) >> 1);
                 t_slot = (int)(bt >> 8);
                 t_center = (L.y0 + oly) * cols + (L.x0 + olx);
-                t_tp = plane + ((oly + L.hh) * tw + (olx + L.hw));
+                t_tp = plane + CH * ((oly + L.hh) * tw + (olx + L.hw));
             }
             // support weights (weight_cu, gipuma.cu:186-193: 256 possible weights) of this lane's window columns,
             // column outer, row inner -- the order of the chain
             constexpr bool kByteW = LY::byte_weights;
             float wgt[kByteW ? 1 : NH * N];
             uint32_t widx[kByteW ? (NH * N + 3) / 4 : 1];
-            {
+            if constexpr (CH == 4) {
+                // colour: the table is indexed by the integer |dB| + |dG| + |dR| (0..765), view_cost_c4_loop
+                const float4 centre = *reinterpret_cast<const float4 *>(t_tp);
+                const float *tc = t_tp + 4 * (-R * tw - R + 2 * half * NH);
+#pragma unroll
+                for (int i = 0; i < NH; i++)
+#pragma unroll
+                    for (int jj = 0; jj < N; jj++) {
+                        const float4 lv = *reinterpret_cast<const float4 *>(tc + 4 * (2 * jj * tw + 2 * i));
+                        const float S = __builtin_fabsf(lv.x - centre.x) + __builtin_fabsf(lv.y - centre.y) +
+                                        __builtin_fabsf(lv.z - centre.z);
+                        wgt[i * N + jj] = lds[(int)S];
+                    }
+            } else {
                 const float centre = t_tp[0];
                 const float *tc = t_tp + (-R * tw - R + 2 * half * NH);
                 if constexpr (kByteW) {
@@ -660,7 +819,7 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
             h_block(0);
             __builtin_amdgcn_wave_barrier();
             StripView sv;
-            typename GroupWalk<BOX>::Set SA, SB;
+            typename decltype(W)::Set SA, SB;
             bool fast = view_fast(hbuf);
             if (fast)
                 W.template first<true>(view_base(0), hbuf, sv, SA, SB);
@@ -736,18 +895,18 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
 // grid = tiles of the sweep kernels; `colour`: the colour about to be swept (the consumers); `hist`: rule (H) is
 // valid for that half-sweep (the consumer replays only the slots whose producer changed).  The stand-alone form:
 // the half-sweep itself is a sweep launch with Tune::kPushConsume.
-template <int BOX>
-__global__ __launch_bounds__(kThreads, group_wg<BOX>()) void group_kernel(const Problem *__restrict__ P,
-                                                                      const float4 *__restrict__ norm4,
-                                                                      const float *__restrict__ cost, int colour,
-                                                                      int hist, unsigned tune)
+template <int BOX, int CH = 1>
+__global__ __launch_bounds__(kThreads, (group_wg<BOX, CH>())) void group_kernel(const Problem *__restrict__ P,
+                                                                              const float4 *__restrict__ norm4,
+                                                                              const float *__restrict__ cost, int colour,
+                                                                              int hist, unsigned tune)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     SweepLane L;
     // rule (H) comes in through `hist`, like in pm::push_kernel; the other rules exactly as the sweep applies them
     const unsigned t2 = (tune & ~(Tune::kPushConsume | Tune::kHistorySkip)) | (hist ? Tune::kHistorySkip : 0u);
-    sweep_read_state<BOX, 1, 0, true>(L, P, lds, norm4, cost, colour, 3u, t2, true);
-    group_costs<BOX>(P, L, lds, norm4, colour, hist, true);
+    sweep_read_state<BOX, CH, 0, CH == 1>(L, P, lds, norm4, cost, colour, 3u, t2, true);
+    group_costs<BOX, CH>(P, L, lds, norm4, colour, hist, true);
 }
 
 // One colour of one iteration (gipuma.cu:1353-1711, the three launches of sweep_kernel) with the propagation costs
@@ -755,26 +914,27 @@ __global__ __launch_bounds__(kThreads, group_wg<BOX>()) void group_kernel(const 
 // refinement and write-back (sweep_body).  One launch instead of group_kernel + sweep_kernel: the tile and the state
 // are read once, and the workgroups of a CU are in different stages at any time -- the refinement stage waits on
 // scattered window loads, the strips of the propagation stage are bound by instruction issue.
-// Gray window-packed planes with float-encoded offsets, register combiner, box 11 / 15.
-template <int BOX>
-__global__ __launch_bounds__(kThreads, group_wg<BOX>()) void sweep_group_kernel(const Problem *__restrict__ P,
-                                                                            float4 *__restrict__ norm4,
-                                                                            float *__restrict__ cost, int colour,
-                                                                            uint32_t phase, unsigned tune)
+// Window-packed planes (gray: float-encoded offsets), register combiner, box 11 / 15 / 25; colour: box 15.
+template <int BOX, int CH = 1>
+__global__ __launch_bounds__(kThreads, (group_wg<BOX, CH>())) void sweep_group_kernel(const Problem *__restrict__ P,
+                                                                                    float4 *__restrict__ norm4,
+                                                                                    float *__restrict__ cost, int colour,
+                                                                                    uint32_t phase, unsigned tune)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    using LY = GroupLayout<BOX>;
+    using LY = GroupLayout<BOX, CH>;
     constexpr int tw = LY::tw, th = LY::th;
     SweepLane L;
-    sweep_read_state<BOX, 1, 0, true>(L, P, lds, norm4, cost, colour, 7u, tune & ~Tune::kPushConsume, true);
-    group_costs<BOX>(P, L, lds, norm4, colour, (tune & Tune::kHistorySkip) != 0, false);
+    sweep_read_state<BOX, CH, 0, CH == 1>(L, P, lds, norm4, cost, colour, 7u, tune & ~Tune::kPushConsume, true);
+    group_costs<BOX, CH>(P, L, lds, norm4, colour, (tune & Tune::kHistorySkip) != 0, false);
     // The costs were written by other lanes of this workgroup: all its wavefronts share the CU's vector L1
     // (write-through), so a workgroup-scope fence and the barrier make them visible to the replay below.
     __threadfence_block();
     __syncthreads();
-    // the float4 tile {I, gx1, gy1, I} the refinement loops read (stage_tile's second pass), from the plane:
-    // the plane lies where the tile goes, so it moves behind it first (where stage_tile stages it)
-    {
+    // gray: the float4 tile {I, gx1, gy1, I} the refinement loops read (stage_tile's second pass), from the plane:
+    // the plane lies where the tile goes, so it moves behind it first (where stage_tile stages it).  (Colour: the
+    // float4 {B, G, R, 0} tile has been there all along.)
+    if constexpr (CH == 1) {
         float *tile = lds + kLutSize, *plane = tile + 4 * tw * th;
         float v[(tw * th + kThreads - 1) / kThreads];
 #pragma unroll
@@ -800,7 +960,7 @@ __global__ __launch_bounds__(kThreads, group_wg<BOX>()) void sweep_group_kernel(
         }
         __syncthreads();
     }
-    sweep_body<BOX, true, true, true, 1>(P, L, lds, norm4, cost, colour, phase, 7u, tune & ~Tune::kPushConsume, true);
+    sweep_body<BOX, true, true, true, CH>(P, L, lds, norm4, cost, colour, phase, 7u, tune & ~Tune::kPushConsume, true);
 }
 
 }  // namespace pm

@@ -1115,6 +1115,21 @@ def test_inconsistent_installed_costs_are_not_trusted(hip, tiny_problem):
                     assert (kept & (before_c != o.cost)).sum() > 50
 
 
+@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("push,group_from", [(0, 0), (2, 3), (6, 6)])
+def test_plane_keyed_propagation_colour(hip, push, group_from, fused):
+    """pm::sweep_group_kernel<15, 4> / pm::group_kernel<15, 4>: the plane-keyed propagation for -color_processing (three
+    window loads and tap sets per sample, l1_norm(float4) reductions, weights from the 766-entry table), ragged frame,
+    rule (S) on -- the oracle's bits"""
+    gs, _ = synth.build_problem(synth.tiny_config(cols=150, rows=100, n_src=4, blocksize=15, iterations=4, n_best=3),
+                                colour=True)
+    o = OracleState(gs).run()
+    a = _with_env({"GIPUMA_HIP_PUSH_LAUNCHES": push, "GIPUMA_HIP_GROUP_FROM": group_from, "GIPUMA_HIP_ET_FORCE": 1,
+                   "GIPUMA_HIP_GROUP_FUSED": fused}, lambda: runcuda(gs))
+    assert_same(a[0], o[0], "colour grouped propagation push %d from %d norm4" % (push, group_from))
+    assert_same(a[1], o[1], "colour grouped propagation push %d from %d cost" % (push, group_from))
+
+
 def test_seen_rule_is_reset_when_planes_are_installed(hip):
     """skip rule (S) (colour sessions) -- a plane a pixel's propagation evaluated before can never be accepted,
     because the pixel's cost only decreases -- must forget its rings when the caller installs state: after two
