@@ -344,6 +344,7 @@ def main():
     iterations = gs.params.iterations
 
     sess = Session(gs)
+    sched = sess.schedule()
     sweep_ms, total_ms, init_ms, half_sweeps, hs_pushed, group_ms = [], [], [], [], 0, []
     for _ in range(args.warmup):
         sess.solve(timing=True)
@@ -392,9 +393,10 @@ def main():
         hs = np.asarray(half_sweeps, dtype=np.float64)  # [steps][2 * iterations]
         first_plain = 0
         if hs.size:
-            cols_first = int(_exp_env("GIPUMA_HIP_COLS_LAUNCHES", {15: "4", 25: "3"}.get(gs.params.box_hsize, "0"))) \
-                if not args.colour else 0
+            cols_first = int(sched["cols_launches"])
             first_plain = min(hs.shape[1], max(cols_first, hs_pushed))
+            if sched["group_from"] >= 0:  # the dominant kernel's half-sweeps: those of the plane-keyed propagation
+                first_plain = min(hs.shape[1], max(first_plain, sched["group_from"]))
         dominant = hs[:, first_plain:] if hs.size and first_plain < hs.shape[1] else None
         ms_launch = float(dominant.mean()) if dominant is not None else ms_half_sweep
         # Where the propagation costs of a half-sweep come from pm::group_kernel (pm_group.h: box 15 on frames of
@@ -406,6 +408,9 @@ def main():
         gm = np.asarray(group_ms, dtype=np.float64) if group_ms and len(group_ms[0]) else np.zeros((0, 0))
         dom_is_group = bool(gm.size and (gm > 0).any())
         dom_name, dom_pmc_file = "pm::sweep_kernel", "pmc_latest_sweep_kernel.json"
+        dom_is_fused = bool(sched["group_from"] >= 0 and sched["group_fused"])
+        if dom_is_fused:  # one launch per half-sweep: propagation per plane + accept replay + refinement
+            dom_name, dom_pmc_file = "pm::sweep_group_kernel", "pmc_latest_sweep_group_kernel.json"
         ms_sweep_launch = ms_launch
         if dom_is_group:
             used = gm > 0
@@ -472,7 +477,7 @@ def main():
             r_ref += 1
             dz /= 10.0
         samples_per_frame = n_pix * (1 + iterations * (8 + r_ref)) * n_views * S
-        cols_l = int(_exp_env("GIPUMA_HIP_COLS_LAUNCHES", {15: "4", 25: "3"}.get(box, "0"))) if not args.colour else 0
+        cols_l = int(sched["cols_launches"])
         n_launch = 2 * iterations
         # leading half-sweeps whose propagation costs are pushed by pm::push_kernel (pm_push.h: boxes 11 / 15 / 25, gray, best-N <= 4)
         push_l = int(hs_pushed)  # (what the library reports for the timed solve: gipuma_hip_launch_times)
@@ -513,6 +518,12 @@ def main():
                                     "them: pm::sweep_cols_kernel x%d and pm::push_kernel x%d"
                                     % (int((gm[0] > 0).sum()), n_launch, first_plain, min(cols_l, n_launch), push_l))
                                    if dom_is_group else
+                                   ("pm::sweep_group_kernel: one fused launch per half-sweep (one colour: close+far+refine; the "
+                                    "propagation costs evaluated once per PLANE, pm_group.h), %d of the %d half-sweeps of a view "
+                                    "(the %d before them: pm::sweep_cols_kernel x%d, and pm::push_kernel x%d, which evaluates "
+                                    "the propagation costs of the first %d half-sweeps once per plane)"
+                                    % (n_launch - first_plain, n_launch, first_plain, min(cols_l, n_launch), push_l, push_l))
+                                   if dom_is_fused else
                                    ("pm::sweep_kernel: one fused launch per half-sweep (one colour: close+far+refine), "
                                     "%d of the %d half-sweeps of a view (the %d before them: pm::sweep_cols_kernel x%d, "
                                     "and pm::push_kernel x%d, which evaluates the propagation costs of the first %d "
@@ -538,6 +549,7 @@ def main():
                          "note": "compute/gather bound by construction (SURVEY F5): "
                                  "%.3g patch samples/s" % (samples_per_frame / (np.mean(total_ms) * 1e-3))},
             "quality": quality,
+            "schedule": sched,
         }
         # The roof that actually binds: vector-ALU issue.  SQ_INSTS_VALU comes from
         # the committed PMC pass (see `source`), only the launch time is this run's.

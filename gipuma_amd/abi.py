@@ -89,6 +89,7 @@ SYMBOLS = [
     ("gipuma_hip_solve", C.c_int, [C.c_void_p, C.POINTER(Timing)]),
     ("gipuma_hip_launch_times", C.c_int, [C.c_void_p, _FP, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("gipuma_hip_group_times", C.c_int, [C.c_void_p, _FP, C.c_int, C.POINTER(C.c_int)]),
+    ("gipuma_hip_schedule", C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     ("gipuma_hip_run", C.c_int, [C.POINTER(Desc), _FP, _FP, C.POINTER(Timing)]),
 ]
 

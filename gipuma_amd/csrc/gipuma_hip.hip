@@ -1087,6 +1087,18 @@ int gipuma_hip_launch_times(gipuma_hip_session *s, float *ms_half_sweep, int cap
     return 0;
 }
 
+int gipuma_hip_schedule(gipuma_hip_session *s, int info[4])
+{
+    if (!s || !info) return fail(GIPUMA_HIP_ERR_ARG, "null argument");
+    info[0] = s->push_ok ? s->push_launches : 0;
+    info[1] = s->group_ok ? s->group_from : -1;
+    info[2] = s->group_ok && s->group_fused ? 1 : 0;
+    const bool cols_ok = s->u8 && ((s->ch == 1 && s->hp.magic_addr && (s->box == 15 || s->box == 25)) || (s->ch == 4 && s->box == 15)) &&
+                         !(s->tune & (Tune::kNoColsKernel | Tune::kNoInterior));
+    info[3] = cols_ok ? (s->cols_launches >= 0 ? s->cols_launches : (s->box == 25 ? 3 : 4)) : 0;
+    return 0;
+}
+
 int gipuma_hip_group_times(gipuma_hip_session *s, float *ms_group, int capacity, int *n_half_sweeps)
 {
     if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");

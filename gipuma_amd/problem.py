@@ -254,6 +254,12 @@ class Session:
                   "gipuma_hip_launch_times")
         return [float(buf[i]) for i in range(min(cap, n.value))], npush.value
 
+    def schedule(self):
+        """dict(push_launches, group_from, group_fused, cols_launches): which kernels a solve launches per half-sweep"""
+        info = (C.c_int * 4)()
+        abi.check(self.lib, self.lib.gipuma_hip_schedule(self.h, info), "gipuma_hip_schedule")
+        return dict(push_launches=info[0], group_from=info[1], group_fused=bool(info[2]), cols_launches=info[3])
+
     def group_times(self):
         """ms of the pm::group_kernel launch of every half-sweep of the last timed solve (0 where it had none)"""
         n = C.c_int(0)

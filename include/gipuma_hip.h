@@ -187,6 +187,13 @@ int gipuma_hip_launch_times(gipuma_hip_session *s, float *ms_half_sweep, int cap
  * serve), so that the fused sweep launch's own time is ms_half_sweep[i] - ms_group[i].  These launches replace the
  * cost evaluations of gipuma.cu:1437-1462 / :1571-1582.  Pointers may be NULL. */
 int gipuma_hip_group_times(gipuma_hip_session *s, float *ms_group, int capacity, int *n_half_sweeps);
+/* Which kernels a full solve of this session launches per half-sweep h = 2 * iteration + colour (performance only; the
+ * results do not depend on it):  info[0] = half-sweeps h < info[0] read propagation costs pushed by pm::push_kernel;
+ * info[1] = from half-sweep info[1] on the costs come from the plane-keyed evaluation (pm_group.h), -1: never;
+ * info[2] = 1: that evaluation is fused with the sweep (one pm::sweep_group_kernel launch per half-sweep), 0: a
+ * pm::group_kernel launch in front of the sweep launch;  info[3] = half-sweeps h < info[3] run the column-per-lane
+ * sweep kernel, 0: none. */
+int gipuma_hip_schedule(gipuma_hip_session *s, int info[4]);
 
 /* ---- one-shot: the whole of runcuda() ---- */
 /* norm4_out: rows*cols*4 host floats, cost_out: rows*cols host floats (either may be NULL).

@@ -12,6 +12,7 @@ cp $R/gpurun_out/final_pmc/pmc_summary*.json $O/ 2>/dev/null
 # the bench line imports these counters: hand it the ones just collected (the same files are then committed)
 cp $O/pmc_summary.json $R/profiles/pmc_latest.json
 cp $O/pmc_summary_pixel_per_lane.json $R/profiles/pmc_latest_sweep_kernel.json
+cp $O/pmc_summary_sweep_group.json $R/profiles/pmc_latest_sweep_group_kernel.json
 cd $R
 GIPUMA_HIP_LAUNCH_TIMES=1 python bench.py > $O/bench_C.json 2> $O/bench_C.err
 ls -la $O

@@ -29,7 +29,8 @@ LIST
 # each kernel on its own (mean per dispatch)
 python $R/scripts/rocprof_summary.py pmcunits $OUT ${PMC_UNITS:-16} sweep_ push_kernel group_kernel > $OUT/pmc_summary.json
 python $R/scripts/rocprof_summary.py pmc $OUT push_kernel > $OUT/pmc_summary_push.json
-python $R/scripts/rocprof_summary.py pmc $OUT group_kernel > $OUT/pmc_summary_group.json
+python $R/scripts/rocprof_summary.py pmc $OUT "pm::group_kernel" > $OUT/pmc_summary_group.json
+python $R/scripts/rocprof_summary.py pmc $OUT sweep_group_kernel > $OUT/pmc_summary_sweep_group.json
 python $R/scripts/rocprof_summary.py pmc $OUT sweep_kernel > $OUT/pmc_summary_pixel_per_lane.json
 python $R/scripts/rocprof_summary.py pmc $OUT sweep_cols_kernel > $OUT/pmc_summary_column_per_lane.json
 python $R/scripts/rocprof_summary.py pmc $OUT init_kernel > $OUT/pmc_summary_init.json
