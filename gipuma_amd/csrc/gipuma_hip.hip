@@ -377,12 +377,8 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
     if (fused_group) {
         // propagation costs per plane + accept replay + refinement in one launch (pm_group.h)
         typedef void (*fused_fn)(const pm::Problem *, float4 *, float *, int, uint32_t, unsigned);
-        const fused_fn fk = s->ch == 4     ? pm::sweep_group_kernel<15, 4>
-                            : s->box == 15 ? pm::sweep_group_kernel<15>
-                            : s->box == 25 ? pm::sweep_group_kernel<25>
-                                           : pm::sweep_group_kernel<11>;
-        const size_t glds = sizeof(float) * (size_t)(s->ch == 4     ? pm::GroupLayout<15, 4>::total
-                                                     : s->box == 15 ? pm::GroupLayout<15>::total
+        const fused_fn fk = s->box == 15 ? pm::sweep_group_kernel<15> : s->box == 25 ? pm::sweep_group_kernel<25> : pm::sweep_group_kernel<11>;
+        const size_t glds = sizeof(float) * (size_t)(s->box == 15   ? pm::GroupLayout<15>::total
                                                      : s->box == 25 ? pm::GroupLayout<25>::total
                                                                     : pm::GroupLayout<11>::total);
         const size_t flds = std::max(glds, s->lds_sweep);
@@ -569,8 +565,8 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         return hipMemcpy2DAsync(p, row_bytes, d->images[idx], (size_t)d->pitch * sizeof(float), row_bytes,
                                 (size_t)d->rows, hipMemcpyHostToDevice, s->stream);
     };
-    CREATE_OK(resident(0, &hp.ref));
-    for (int i = 0; i < d->n_selected; i++) CREATE_OK(resident(d->selected[i], &hp.view[i].img));
+    CREATE_OK(resident(0, &hp.ref.raw));
+    for (int i = 0; i < d->n_selected; i++) CREATE_OK(resident(d->selected[i], &hp.view[i].img.raw));
 
     // U8 mode (weight table + window-packed source views) if every image handed to the path is
     // integer valued in [0,255] -- 8-bit input converted to float, main.cpp:941
@@ -806,8 +802,10 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     if (const char *t = exp_env("GROUP_FROM")) s->group_from = atoi(t);
     // one launch per half-sweep (pm::sweep_group_kernel) for gray; colour: two (its sweep kernel is compiled for four
     // workgroups per CU, the fused one holds two: 219 ms fused against 205 ms per view, config C's geometry in colour)
+    // gray: one launch per half-sweep; colour: pm::group_kernel<15, 4> + the sweep kernel (the fused colour kernel was
+    // slower -- 256 registers, 121 of them spilled -- and is not built: DESIGN.md 5, round 4)
     s->group_fused = s->ch == 1;
-    if (const char *t = exp_env("GROUP_FUSED")) s->group_fused = atoi(t) != 0;  // 0: group_kernel + sweep_kernel, two launches
+    if (const char *t = exp_env("GROUP_FUSED")) s->group_fused = s->ch == 1 && atoi(t) != 0;  // 0: group_kernel + sweep_kernel, two launches
     if (s->group_from < 0) s->group_ok = false;
     if (s->push_ok || s->group_ok) {
         // performance-only state too: without it every half-sweep evaluates its own propagation candidates
@@ -1053,9 +1051,10 @@ int gipuma_hip_solve(gipuma_hip_session *s, gipuma_hip_timing *timing)
             HIP_OK(hipMemset(s->dbg, 0, h.size() * sizeof(unsigned long long)));
             const double px = 0.5 * (double)s->rows * (double)s->cols;
             static const char *names[] = {"tasks/px", "-", "items/px", "open items/px", "redone cands/px", "cands/px"};
-            if (h[62 * pm::kDbgSlots + 0]) {  // pm::group_kernel's phase clocks (100 MHz ticks summed over workgroups -> ms per workgroup-slot)
-                fprintf(stderr, "gipuma_hip group_kernel phase ticks (state, tasks, grouping, cut, strips, chains):");
-                for (int k = 0; k < 6; k++) fprintf(stderr, " %llu", h[62 * pm::kDbgSlots + k]);
+            if (h[62 * pm::kDbgSlots + 1]) {  // the plane-keyed kernels' phase clocks: 100 MHz ticks of each workgroup's first wavefront, summed
+                fprintf(stderr, "gipuma_hip plane-keyed phase ticks (state, task list, grouping, batches, wait for the last batch, tile, "
+                                "replay + refinement):");
+                for (int k = 0; k < 7; k++) fprintf(stderr, " %llu", h[62 * pm::kDbgSlots + k]);
                 fprintf(stderr, "\n");
             }
             if (h[61 * pm::kDbgSlots + 0]) {  // pm::group_kernel's batches, summed over the solve's launches

@@ -15,6 +15,28 @@ constexpr int kTileW = 32;           // pixels per tile row (both colours)
 constexpr int kSweepTileH = 16;      // 32x16 tile, 256 pixels of one colour
 constexpr int kDenseTileH = 8;       // 32x8 tile, all 256 pixels (init / eval / finalize)
 
+// A pointer into device global memory that lives in the problem block.  Loaded from memory, a plain pointer is a GENERIC
+// one to the compiler: every access becomes a flat_load / flat_store, which counts on lgkmcnt as well as vmcnt and -- a
+// store or atomic is never waited for -- turns every later LDS wait of the kernel into lgkmcnt(0) (round 4: one counter
+// atomic anywhere in the box-25 fused kernel serialised the 338 LDS reads of every chain, config D 17 % slower).  On the
+// device the wrapper converts to an address_space(1) pointer, so the accesses are global_load / global_store; on the
+// host it is the plain pointer.  Same size and layout either way.
+template <class T>
+struct DevPtr {
+    T *raw;
+    using G = __attribute__((address_space(1))) T *;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PM_DEVPTR_GENERIC)  // (-DPM_DEVPTR_GENERIC: the flat accesses, for A/B runs)
+    __device__ __forceinline__ operator G() const { return (G)raw; }
+#else
+    __host__ __device__ operator T *() const { return raw; }
+#endif
+    __host__ __device__ DevPtr &operator=(T *q)
+    {
+        raw = q;
+        return *this;
+    }
+};
+
 struct RefCam {  // Camera_cu of view 0, camera.h:7-62
     float K_inv[9], M_inv[9], R_orig_inv[9];
     float P_col34[3], C[3];
@@ -23,8 +45,8 @@ struct RefCam {  // Camera_cu of view 0, camera.h:7-62
 struct ViewCam {  // Camera_cu of a selected source view + its image plane
     float K[9], R[9], t[3];
     int pad;
-    const float *img;        // float plane (row-major, Problem::pitch)
-    const uint32_t *packed;  // window-packed u8 copy (see pack_kernel), or nullptr
+    DevPtr<const float> img;        // float plane (row-major, Problem::pitch)
+    DevPtr<const uint32_t> packed;  // window-packed u8 copy (see pack_kernel), or nullptr
 };
 struct Problem {  // lives in device memory, read through scalar loads (wave-uniform)
     int rows, cols, pitch, n_sel;
@@ -32,42 +54,42 @@ struct Problem {  // lives in device memory, read through scalar loads (wave-uni
     float alpha, tau_color, tau_gradient, gamma;
     float min_disp, max_disp, good_factor;
     uint32_t seed;
-    const float *ref;
+    DevPtr<const float> ref;
     int pw, channels;  // packed layout: texels per row of V (cols + 8); 1 = gray, 4 = colour
     int magic_addr;    // gray packed planes small enough (< 2^21 words) for float-encoded offsets
-    unsigned char *changed;  // per pixel: did its plane change in its colour's last half-sweep (history rule)
+    DevPtr<unsigned char> changed;  // per pixel: did its plane change in its colour's last half-sweep (history rule)
     // early termination of refinement evaluations (see multiview_cost): enabled by the host when every
     // view cost is provably finite and below MAXCOST; theta of refinement step 0, 1, 2+
     int et_enable;
     float et_theta[3];
     // per (tile, wavefront, refinement step): > 0 while bounding the evaluation recently did not pay
     // there (a wavefront had to redo lanes); performance only, any content gives the same results
-    unsigned char *et_hint;
+    DevPtr<unsigned char> et_hint;
     // [3 rotating slots][kEtSlot words]: what the probe workgroups (every 16th) measured per bounded
     // refinement step -- window columns a full evaluation takes, columns evaluated with the bound incl.
     // redos, (candidate, view) items left after phase 1 of refine_two_phase, items, phase-1 length used;
     // the other workgroups bound a step only if that paid for the previous half-sweep's probes.
     // Half-sweep k (= phase) writes slot k % 3, reads slot (k-1) % 3 and clears slot (k+1) % 3.
     // Performance only: any content gives the same results.
-    unsigned *et_stat;
+    DevPtr<unsigned> et_stat;
     int tp_g0;  // window columns of phase 1 of refine_two_phase (0: default, 3/8 of the window)
     // [8][rows*cols]: cost of neighbour slot k's plane at the pixel, left by pm::push_kernel (pm_push.h)
     // after the previous half-sweep for the pixels of the other colour; read instead of evaluated
     // when the host sets Tune::kPushConsume
-    float *push_cost;
+    DevPtr<float> push_cost;
     // lower-bound prefilter of refinement candidates (lb_item): per pixel the kLbMax window samples with the
     // largest support weights, two bytes each (window column, window row), as kLbDwords planes of
     // rows*cols words (weight_order_kernel); lb_k > 0: samples to use (even), 0: chosen from the probes'
     // statistics, < 0: prefilter off.  Performance only: ANY list gives the same results.
-    const uint32_t *worder;
+    DevPtr<const uint32_t> worder;
     int lb_k;
     // rule (S) of the sweep kernels' exact skipping (colour sessions only, see gipuma_hip_create): per pixel a ring
     // of the last kSeenRing planes its propagation evaluated ([kSeenRing][rows*cols] float4) and one byte of ring
     // state (next slot | 8 once full); nullptr: rule off.  Cleared by the host whenever planes are (re-)installed.
-    float4 *seen_ring;
-    unsigned char *seen_pos;
+    DevPtr<float4> seen_ring;
+    DevPtr<unsigned char> seen_pos;
     // experiment aid (GIPUMA_HIP_COUNTS=1): [64 phases][kDbgSlots] event counters, or nullptr
-    unsigned long long *dbg;
+    DevPtr<unsigned long long> dbg;
     RefCam rc;
     ViewCam view[kMaxViews];
 };
@@ -350,6 +372,13 @@ typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef const __attribute__((address_space(1))) u32x4_a4 *gptr_u32x4;
 typedef const __attribute__((address_space(1))) float *gptr_f32;
 typedef const __attribute__((address_space(1))) char *gptr_bytes;
+// Event counters (Problem::dbg) are bumped through a GLOBAL-address-space atomic: through the generic pointer the compiler
+// emits flat_atomic, which counts on lgkmcnt as well as vmcnt and, never being waited for, turns every later LDS wait of
+// the kernel into lgkmcnt(0) (measured in round 4: config D 17 % slower with one such atomic anywhere in the kernel).
+__device__ __forceinline__ void dbg_add(unsigned long long *p, unsigned long long v)
+{
+    __hip_atomic_fetch_add((__attribute__((address_space(1))) unsigned long long *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // byte -> float.  Spelled as the hardware instruction so that the compiler keeps ONE half-rate
 // conversion per texel (it otherwise rewrites (float)b1 - (float)b0 into a byte-select

@@ -38,7 +38,7 @@ __device__ __forceinline__ float view_cost_loop(const Problem *__restrict__ P, c
                                                 int tw, const float *__restrict__ lut, int px, int py,
                                                 const Win<BOX> &win)
 {
-    const gptr_f32 img = (gptr_f32)vc.img;
+    const gptr_f32 img = (gptr_f32)vc.img.raw;
     const uint32_t *__restrict__ packed = vc.packed;
     const uint32_t pw = (uint32_t)P->pw;
     const uint32_t xmax = (uint32_t)(P->cols + 2), ymax = (uint32_t)(P->rows + 2);
@@ -165,7 +165,7 @@ __device__ __forceinline__ float view_cost_pipe(const Problem *__restrict__ P, c
     const float centre = tp0[0];
     const float pwf = (float)P->pw;
     const float magic_c = kMagicF + (float)(2 * P->pw + 2);
-    const gptr_bytes magic_base = (gptr_bytes)((uintptr_t)vc.packed - (uintptr_t)kMagicBits);
+    const gptr_bytes magic_base = (gptr_bytes)((uintptr_t)vc.packed.raw - (uintptr_t)kMagicBits);
     const char *lut_magic = (const char *)lut - kMagicBits;
     const float H1 = H[1], H4 = H[4], H7 = H[7];
 
@@ -374,7 +374,7 @@ __device__ __forceinline__ float view_cost_c4_loop(const Problem *__restrict__ P
 {
     // (c0, c1, cost0: window columns [c0, c1) only, continuing from the partial sum cost0 -- see
     //  view_cost_pipe_range / refine_two_phase)
-    const gptr_f32 img = (gptr_f32)vc.img;
+    const gptr_f32 img = (gptr_f32)vc.img.raw;
     const uint32_t *__restrict__ packed = vc.packed;
     const uint32_t pw = (uint32_t)P->pw;
     const uint32_t xmax = (uint32_t)(P->cols + 2), ymax = (uint32_t)(P->rows + 2);
@@ -634,7 +634,7 @@ __device__ __forceinline__ float view_cost_cols(const Problem *__restrict__ P, c
     const float centre = tp0[0];
     const float pwf = (float)P->pw;
     const float magic_c = kMagicF + (float)(2 * P->pw + 2);
-    const gptr_bytes magic_base = (gptr_bytes)((uintptr_t)vc.packed - (uintptr_t)kMagicBits);
+    const gptr_bytes magic_base = (gptr_bytes)((uintptr_t)vc.packed.raw - (uintptr_t)kMagicBits);
     const char *lut_magic = (const char *)lut - kMagicBits;
     const float H1 = H[1], H4 = H[4], H7 = H[7];
     const int mycol = col < N ? col : N - 1;  // spare lanes of a smaller box shadow the last column
@@ -714,7 +714,7 @@ __device__ __forceinline__ float view_cost_cols_c4(const Problem *__restrict__ P
 {
     constexpr int R = (BOX - 1) / 2, N = R + 1;
     static_assert(BOX > 0 && N <= col_group<BOX>(), "one lane per window column");
-    const gptr_bytes packed = (gptr_bytes)vc.packed;
+    const gptr_bytes packed = (gptr_bytes)vc.packed.raw;
     const uint32_t pw = (uint32_t)P->pw;
     const uint32_t xmax = (uint32_t)(P->cols + 2), ymax = (uint32_t)(P->rows + 2);
     const float alpha16 = P->alpha * 0.0625f, oma = 1.f - P->alpha;  // (dis_term: the 1/16 of the gradient term folded in)

@@ -57,11 +57,22 @@ constexpr int kGrpMaxTasks = 8 * kThreads;  // 2048
 constexpr int kGrpHashSize = 2048;
 
 constexpr int kGrpBatchStrips = 64;    // one strip per lane
+// Lanes per task in the chains.  One lane holds the support weights of its window columns in registers, as floats: 64 for
+// box 15, 36 for box 11.  Box 25 has 169: two lanes per task, the first sums window columns 0..6 (91 weights) and hands
+// its partial sum to the second, which continues with columns 7..12 -- the reference's order.  (One lane with the weights
+// as byte indices into the table, four per register, costs a table read, a bit-field extract and an address per term:
+// 3 VALU + 1.5 LDS instructions instead of 1 + 0.5, on 31 % of the lanes.  -DPM_GROUP_TASK_LANES25=1 builds that.)
 #ifndef PM_GROUP_TASK_LANES
 #define PM_GROUP_TASK_LANES 1
 #endif
-constexpr int kGrpTaskLanes = PM_GROUP_TASK_LANES;   // lanes per task in the chains: 1 (64 weights per lane) or 2 (32)
-constexpr int kGrpBatchTasks = 64 / kGrpTaskLanes;
+#ifndef PM_GROUP_TASK_LANES25
+#define PM_GROUP_TASK_LANES25 2
+#endif
+template <int BOX>
+__host__ __device__ constexpr int group_task_lanes()
+{
+    return BOX == 25 ? PM_GROUP_TASK_LANES25 : PM_GROUP_TASK_LANES;
+}
 constexpr int kGrpBatchGroups = 8;     // (a group has at least 6 strips)
 // dis values of one view a wavefront's LDS slice holds: 64 strips of 16 (boxes 11, 15: three workgroups per CU) or of
 // 20 (box 25: two workgroups per CU) rows
@@ -72,6 +83,9 @@ __host__ __device__ constexpr int group_batch_samples()
 }
 constexpr int kGrpViewsPerH = 4;       // homographies are prepared this many views at a time (8 groups x 4 views = 32 lanes;
                                        // 8 views: 6 KB more LDS per workgroup, which the sample buffers use better)
+#ifndef PM_GROUP_LAPS
+#define PM_GROUP_LAPS 0x7f  // which of the fused kernel's phase clocks are compiled in (bit = slot)
+#endif
 #ifndef PM_GROUP_WG
 #define PM_GROUP_WG 3  // workgroups per CU the kernels are compiled for (3: 168 VGPRs)
 #endif
@@ -89,10 +103,13 @@ struct GroupLayout {  // offsets in 32-bit words into the dynamic LDS array
     static_assert(BOX == 11 || BOX == 15 || BOX == 25, "instantiated window sizes");
     static_assert(CH == 1 || BOX == 15, "colour: box 15");
     static constexpr int R = (BOX - 1) / 2, N = R + 1;
-    static_assert(kGrpTaskLanes == 1 || N % 2 == 0, "a task's window columns are split between two lanes");
+    static constexpr int task_lanes = group_task_lanes<BOX>();
+    static_assert(task_lanes == 1 || task_lanes == 2, "one lane per task, or two that split its window columns");
+    static constexpr int batch_tasks = 64 / task_lanes;   // tasks whose chains run together
+    static constexpr int NH = (N + task_lanes - 1) / task_lanes;  // window columns of a chain lane (the second of two: N - NH)
     // the support weights of a chain lane's window columns stay in registers: as floats while they are at most 64,
     // else (box 25: 169) as their table indices |dI|, four per register -- a chain term then costs a table read more
-    static constexpr bool byte_weights = (N / kGrpTaskLanes) * N > 64;
+    static constexpr bool byte_weights = NH * N > 96;
     static constexpr int tw = kTileW + 2 * N, th = kSweepTileH + 2 * N;
     static constexpr int max_rows = N + (kSweepTileH - 1) / 2;  // samples per strip: 8 + 7 = 15 for box 15
     static constexpr int max_cols = N + (kTileW - 1) / 2;       // strips per group: 8 + 15 = 23
@@ -107,7 +124,7 @@ struct GroupLayout {  // offsets in 32-bit words into the dynamic LDS array
     // per wavefront: the tables, homographies and samples of the batch it is working on
     static constexpr int w_tab = 0;                                   // [kGrpBatchGroups][4] u16: group id, first strip, first task
     static constexpr int w_sgroup = w_tab + 2 * kGrpBatchGroups;      // [kGrpBatchStrips] u8: group (in the batch) of a strip
-    static constexpr int w_tgroup = w_sgroup + kGrpBatchStrips / 4;   // [kGrpBatchTasks] u8: ... of a task
+    static constexpr int w_tgroup = w_sgroup + kGrpBatchStrips / 4;   // [64] u8: ... of a task
     static constexpr int w_gplane = w_tgroup + 16;                    // [kGrpBatchGroups] float4  (64 bytes for tgroup)
     static constexpr int w_hbuf = w_gplane + 4 * kGrpBatchGroups;     // [kGrpViewsPerH][kGrpBatchGroups][12]: H, fast flag
     static constexpr int batch_samples = group_batch_samples<BOX>();
@@ -123,6 +140,18 @@ struct GroupLayout {  // offsets in 32-bit words into the dynamic LDS array
     static_assert(total * 4 * group_wg<BOX, CH>() <= 160 * 1024, "workgroups per CU");
     static_assert((w_gplane % 4) == 0 && (w_hbuf % 4) == 0 && (waves % 4) == 0 && (w_stride % 4) == 0, "16-byte aligned float4 tables");
 };
+
+// The 100 MHz clock for the phase counters.  s_memrealtime returns through the scalar memory path, whose results come back
+// out of order: while one is outstanding every LDS wait the compiler inserts must be lgkmcnt(0) instead of a graded count,
+// and a clock value that is only needed at the NEXT lap stays outstanding through whatever lies in between (measured: the
+// box-25 chains, 169 table reads + 169 sample reads per view, each waited for on its own -- config D 17 % slower with
+// one lap anywhere in the kernel).  The empty asm consumes the value on the spot.
+__device__ __forceinline__ unsigned long long lap_clock()
+{
+    unsigned long long t = wall_clock64();
+    asm volatile("" : "+s"(t));
+    return t;
+}
 
 __device__ __forceinline__ uint32_t plane_hash(float4 pl, int cls)
 {
@@ -445,18 +474,19 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
                                             const float4 *__restrict__ norm4, int colour, int hist, bool write_skipped)
 {
     using LY = GroupLayout<BOX, CH>;
-    constexpr int R = LY::R, N = LY::N, tw = LY::tw, NH = N / kGrpTaskLanes;  // window columns per chain lane
+    constexpr int R = LY::R, N = LY::N, tw = LY::tw, NH = LY::NH, TL = LY::task_lanes, kBatchTasks = LY::batch_tasks;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rows = P->rows, cols = P->cols, n = P->n_sel;
     const size_t np = (size_t)rows * (size_t)cols;
 
     // (GIPUMA_HIP_COUNTS: 100 MHz wall-clock ticks per phase, summed over the workgroups, in row 62 of Problem::dbg)
-    const bool prof = P->dbg != nullptr && tid == 0;
-    unsigned long long tick = prof ? wall_clock64() : 0ull;
+    // (wave-uniform, so that the clock stays in scalar registers)
+    const bool prof = P->dbg != nullptr && __builtin_amdgcn_readfirstlane(tid) == 0;
+    unsigned long long tick = prof ? lap_clock() : 0ull;
     auto lap = [&](int slot) {
         if (prof) {
-            const unsigned long long now = wall_clock64();
-            atomicAdd(&P->dbg[62 * kDbgSlots + slot], now - tick);
+            const unsigned long long now = lap_clock();
+            if (lane == 0) dbg_add(&P->dbg[62 * kDbgSlots + slot], now - tick);
             tick = now;
         }
     };
@@ -631,9 +661,9 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
     __syncthreads();  // LAST workgroup barrier: the grouping tables' memory becomes the wavefronts' batch areas
     lap(2);  // grouping, sort, bounding boxes, order
     if (P->dbg != nullptr && tid == 0) {
-        atomicAdd(&P->dbg[61 * kDbgSlots + 5], (unsigned long long)n_groups);
-        atomicAdd(&P->dbg[61 * kDbgSlots + 6], (unsigned long long)n_tasks);
-        atomicAdd(&P->dbg[61 * kDbgSlots + 7], 1ull);
+        dbg_add(&P->dbg[61 * kDbgSlots + 5], (unsigned long long)n_groups);
+        dbg_add(&P->dbg[61 * kDbgSlots + 6], (unsigned long long)n_tasks);
+        dbg_add(&P->dbg[61 * kDbgSlots + 7], 1ull);
     }
     // members of group g: sbt[first .. first + count)
     auto group_tasks = [&](int g, int &first) -> int {
@@ -651,9 +681,9 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
     float *dbuf = wbase + LY::w_dis;
     typename std::conditional<CH == 4, GroupWalkC4<BOX>, GroupWalk<BOX> >::type W;
     W.init(P);
-    // chains: one lane per task, or (kGrpTaskLanes == 2) lane tl sums the left window columns of task tl and lane
+    // chains: one lane per task, or (two lanes per task) lane tl sums the left window columns of task tl and lane
     // 32 + tl the right ones
-    const int half = kGrpTaskLanes == 2 ? lane >> 5 : 0, tl = kGrpTaskLanes == 2 ? lane & 31 : lane;
+    const int half = TL == 2 ? lane >> 5 : 0, tl = TL == 2 ? lane & 31 : lane;
 
     for (;;) {
         // -- take the next run of groups from the cursor --
@@ -681,7 +711,7 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
             }
         }
         // (strip lengths do not decrease along gorder: a group's own nr is the largest of the run up to it)
-        const bool fits = g >= 0 && ic <= kGrpBatchStrips && it <= kGrpBatchTasks && ic * nr <= LY::batch_samples;
+        const bool fits = g >= 0 && ic <= kGrpBatchStrips && it <= kBatchTasks && ic * nr <= LY::batch_samples;
         const unsigned long long fb = __ballot(fits);
         int cnt = fb == ~0ull ? 64 : (int)__builtin_ctzll(~fb);
         if (cnt == 0) cnt = 1;  // a single group always fits the strips and the buffer; more than 32 tasks: several rounds
@@ -698,7 +728,7 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
             wtab[4 * lane + 1] = (unsigned short)sp;
             wtab[4 * lane + 2] = (unsigned short)tp;
             for (int k = 0; k < nc; k++) sgroup[sp + k] = (unsigned char)lane;
-            if (n_alltasks <= kGrpBatchTasks)
+            if (n_alltasks <= kBatchTasks)
                 for (int k = 0; k < nt; k++) tgroup[tp + k] = (unsigned char)lane;
             int rlx, rly, rnb;
             gplane[lane] = desc_plane(sbt[tfirst], rlx, rly, rnb);
@@ -706,11 +736,11 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
         __builtin_amdgcn_wave_barrier();
         if (P->dbg != nullptr && lane == 0) {  // (GIPUMA_HIP_COUNTS: batch statistics in row 61 of Problem::dbg)
             unsigned long long *d = P->dbg + 61 * kDbgSlots;
-            atomicAdd(&d[0], 1ull);
-            atomicAdd(&d[1], (unsigned long long)n_strips);
-            atomicAdd(&d[2], (unsigned long long)n_alltasks);
-            atomicAdd(&d[3], (unsigned long long)cnt);
-            atomicAdd(&d[4], (unsigned long long)nr_b);
+            dbg_add(&d[0], 1ull);
+            dbg_add(&d[1], (unsigned long long)n_strips);
+            dbg_add(&d[2], (unsigned long long)n_alltasks);
+            dbg_add(&d[3], (unsigned long long)cnt);
+            dbg_add(&d[4], (unsigned long long)nr_b);
         }
 
         // -- this lane's strip (spare lanes shadow strip 0: the same values into the same places) --
@@ -745,18 +775,18 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
         };
         auto view_fast = [&](const float *hb) -> bool { return __all(hb[12 * W.grp + 9] != 0.0f); };
         auto view_base = [&](int v) -> gptr_bytes {  // gray: the base of the float-encoded offsets; colour: the packed plane
-            return CH == 4 ? (gptr_bytes)P->view[v].packed : (gptr_bytes)((uintptr_t)P->view[v].packed - (uintptr_t)kMagicBits);
+            return CH == 4 ? (gptr_bytes)P->view[v].packed.raw : (gptr_bytes)((uintptr_t)P->view[v].packed.raw - (uintptr_t)kMagicBits);
         };
 
-        // -- rounds of at most kGrpBatchTasks tasks (more than one only for a single group offered to more pixels) --
-        for (int t_lo = 0; t_lo < n_alltasks; t_lo += kGrpBatchTasks) {
-            const int n_bt = min(kGrpBatchTasks, n_alltasks - t_lo);
+        // -- rounds of at most kBatchTasks tasks (more than one only for a single group offered to more pixels) --
+        for (int t_lo = 0; t_lo < n_alltasks; t_lo += kBatchTasks) {
+            const int n_bt = min(kBatchTasks, n_alltasks - t_lo);
             // this lane's task: sample-buffer offset of its half window, slot, pixel, support weights of its columns
             int t_off = 0, t_slot = 0, t_center = 0;
             const float *t_tp = plane + CH * (L.hh * tw + L.hw);
             const bool has = tl < n_bt;
             if (has) {
-                const int j = n_alltasks <= kGrpBatchTasks ? (int)tgroup[tl] : 0;
+                const int j = n_alltasks <= kBatchTasks ? (int)tgroup[tl] : 0;
                 const int gg = (int)wtab[4 * j];
                 const uint32_t gm = meta[gg];
                 const unsigned bt = sbt[(int)(gm & 2047u) + (t_lo + tl - (int)wtab[4 * j + 2])];
@@ -794,15 +824,18 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
                     for (int q = 0; q < (NH * N + 3) / 4; q++) widx[q] = 0u;
                 }
 #pragma unroll
-                for (int i = 0; i < NH; i++)
+                for (int i = 0; i < NH; i++) {
+                    // (two lanes, odd N: the second lane has one column less; its spare slot re-reads its first column)
+                    const int ci = (TL == 2 && N % 2 != 0 && i == NH - 1 && half != 0) ? 0 : i;
 #pragma unroll
                     for (int jj = 0; jj < N; jj++) {
-                        const float colorDis = __builtin_fabsf(tc[2 * jj * tw + 2 * i] - centre);  // an integer 0..255
+                        const float colorDis = __builtin_fabsf(tc[2 * jj * tw + 2 * ci] - centre);  // an integer 0..255
                         if constexpr (kByteW)
                             widx[(i * N + jj) >> 2] |= ((__float_as_uint(colorDis + kMagicF) >> 2) & 0xffu) << (8 * ((i * N + jj) & 3));
                         else
                             wgt[i * N + jj] = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
                     }
+                }
             }
             // the weight of window sample e of this lane's columns
             auto weight = [&](int e) -> float {
@@ -856,13 +889,14 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
 #pragma unroll
                     for (int q = 0; q < (NH * N + 3) / 4; q++) asm volatile("" : "+v"(widx[q]));
                 }
-                auto half_chain = [&]() {
+                auto half_chain = [&](auto ncols) {  // this lane's first ncols window columns
+                    constexpr int NC = decltype(ncols)::value;
                     float dv[2][N];
 #pragma unroll
                     for (int jj = 0; jj < N; jj++) dv[0][jj] = dcol[jj];
 #pragma unroll
-                    for (int i = 0; i < NH; i++) {
-                        if (i + 1 < NH) {
+                    for (int i = 0; i < NC; i++) {
+                        if (i + 1 < NC) {
 #pragma unroll
                             for (int jj = 0; jj < N; jj++) dv[(i + 1) & 1][jj] = dcol[(i + 1) * nr_b + jj];
                         }
@@ -872,21 +906,21 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 };
-                if (kGrpTaskLanes == 2) {
-                    if (half == 0 && has) half_chain();
+                if constexpr (TL == 2) {
+                    if (half == 0 && has) half_chain(std::integral_constant<int, NH>());
                     const float left = __shfl(cst, tl);
                     if (half == 1 && has) {
                         cst = left;
-                        half_chain();
+                        half_chain(std::integral_constant<int, N - NH>());
                         comb.add(cst, v, nullptr);
                     }
                 } else if (has) {
-                    half_chain();
+                    half_chain(std::integral_constant<int, NH>());
                     comb.add(cst, v, nullptr);
                 }
                 __builtin_amdgcn_wave_barrier();  // the next view's strips overwrite the samples
             }
-            if (half == kGrpTaskLanes - 1 && has) P->push_cost[(size_t)t_slot * np + (size_t)t_center] = comb.finish(P, n, nullptr);
+            if (half == TL - 1 && has) P->push_cost[(size_t)t_slot * np + (size_t)t_center] = comb.finish(P, n, nullptr);
         }
     }
     lap(3);  // batches (this workgroup's first wavefront)
@@ -921,16 +955,31 @@ __global__ __launch_bounds__(kThreads, (group_wg<BOX, CH>())) void sweep_group_k
                                                                                     float *__restrict__ cost, int colour,
                                                                                     uint32_t phase, unsigned tune)
 {
+    static_assert(CH == 1, "gray only: colour sessions run pm::group_kernel<15, 4> and the sweep kernel (gipuma_hip_create)");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using LY = GroupLayout<BOX, CH>;
     constexpr int tw = LY::tw, th = LY::th;
     SweepLane L;
+    // (GIPUMA_HIP_COUNTS: wall-clock ticks of the stages around group_costs, row 62 of Problem::dbg, slots 0, 4..6)
+    const bool prof = PM_GROUP_LAPS != 0 && P->dbg != nullptr && __builtin_amdgcn_readfirstlane((int)threadIdx.x) == 0;
+    unsigned long long tick = prof ? lap_clock() : 0ull;
+    auto lap = [&](int slot) {
+        if (!((PM_GROUP_LAPS >> slot) & 1)) return;
+        if (prof) {
+            const unsigned long long now = lap_clock();
+            if ((threadIdx.x & 63) == 0) dbg_add(&P->dbg[62 * kDbgSlots + slot], now - tick);
+            tick = now;
+        }
+    };
     sweep_read_state<BOX, CH, 0, CH == 1>(L, P, lds, norm4, cost, colour, 7u, tune & ~Tune::kPushConsume, true);
+    lap(0);
     group_costs<BOX, CH>(P, L, lds, norm4, colour, (tune & Tune::kHistorySkip) != 0, false);
+    if (PM_GROUP_LAPS && prof) tick = lap_clock();
     // The costs were written by other lanes of this workgroup: all its wavefronts share the CU's vector L1
     // (write-through), so a workgroup-scope fence and the barrier make them visible to the replay below.
     __threadfence_block();
     __syncthreads();
+    lap(4);  // the first wavefront waiting for the workgroup's last batch
     // gray: the float4 tile {I, gx1, gy1, I} the refinement loops read (stage_tile's second pass), from the plane:
     // the plane lies where the tile goes, so it moves behind it first (where stage_tile stages it).  (Colour: the
     // float4 {B, G, R, 0} tile has been there all along.)
@@ -960,7 +1009,9 @@ __global__ __launch_bounds__(kThreads, (group_wg<BOX, CH>())) void sweep_group_k
         }
         __syncthreads();
     }
+    lap(5);  // tile for the refinement loops
     sweep_body<BOX, true, true, true, CH>(P, L, lds, norm4, cost, colour, phase, 7u, tune & ~Tune::kPushConsume, true);
+    lap(6);  // accept replay, refinement, write-back (the first wavefront's)
 }
 
 }  // namespace pm

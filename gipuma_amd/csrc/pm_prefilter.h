@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kThreads) void weight_order_kernel(const Problem *_
     const int center = blockIdx.x * kThreads + threadIdx.x;
     if (center >= np) return;
     const int py = center / cols, px = center - py * cols;
-    const gptr_f32 ref = (gptr_f32)P->ref;
+    const gptr_f32 ref = (gptr_f32)P->ref.raw;
     // (colour: |dB| + |dG| + |dR|, the index of the colour weight table)
     auto texel_dist = [&](int x, int y) -> float {
         if (CH == 4) {
@@ -231,7 +231,7 @@ __device__ __forceinline__ float lb_item_c4(const Problem *__restrict__ P, const
 {
     static_assert(BOX > 0, "compile-time window only");
     constexpr int R = (BOX - 1) / 2;
-    const gptr_bytes packed = (gptr_bytes)vc.packed;
+    const gptr_bytes packed = (gptr_bytes)vc.packed.raw;
     const uint32_t pw = (uint32_t)P->pw;
     const uint32_t xmax = (uint32_t)(P->cols + 2), ymax = (uint32_t)(P->rows + 2);
     const float alpha16 = P->alpha * 0.0625f, oma = 1.f - P->alpha;  // (dis_fold, pm_cost.h)

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(kThreads, PM_PUSH_WAVES) void push_kernel(const Pro
     //      checkerboard-compressed, with the gradients of pmCostComputation_shared (:254-259) ----
     {
         constexpr int tw = LY::tw, th = LY::th;
-        const gptr_f32 ref = (gptr_f32)P->ref;
+        const gptr_f32 ref = (gptr_f32)P->ref.raw;
         float *plane = lds + LY::dis;
         for (int k = tid; k < tw * th; k += kThreads) {
             const int ty = k / tw, tx = k - ty * tw;
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(kThreads, PM_PUSH_WAVES) void push_kernel(const Pro
 #endif
             const float reach = (float)(R + kPushReach);
             fast = __all(window_z_safe(H, nxf - reach, nxf + reach, nyf - reach, nyf + reach));
-            magic_base = (gptr_bytes)((uintptr_t)P->view[v].packed - (uintptr_t)kMagicBits);
+            magic_base = (gptr_bytes)((uintptr_t)P->view[v].packed.raw - (uintptr_t)kMagicBits);
         };
 #ifdef PM_PUSH_GENERIC15
         if constexpr (false) {
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(kThreads, PM_PUSH_WAVES) void push_kernel_c4(const 
     // ---- reference tile: texels of the consumers' colour, clamp-to-edge point samples like the
     //      reference's (gipuma.cu:1393-1402), each with its channel-wise central differences ----
     {
-        const gptr_f32 ref = (gptr_f32)P->ref;
+        const gptr_f32 ref = (gptr_f32)P->ref.raw;
         const int pitch = P->pitch;
         const int cpar = 1 - colour;
         for (int k = tid; k < lut_size<4>(); k += kThreads) lds[k] = exp_model(-((float)k * 0.3333333f) / P->gamma);
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(kThreads, PM_PUSH_WAVES) void push_kernel_c4(const 
             for (int k = 0; k < 9; k++) H[k] = __shfl(Hl[k], grp_lane0 + (v & (kPushLanes - 1)));
             const float reach = (float)(R + kPushReach);
             const bool fast = __all(window_z_safe(H, nxf - reach, nxf + reach, nyf - reach, nyf + reach));
-            const gptr_bytes packed = (gptr_bytes)P->view[v].packed;
+            const gptr_bytes packed = (gptr_bytes)P->view[v].packed.raw;
             if (fast) {
                 E.template family<true, N, LY::FWH, R, R + kPushReach>(H, packed, lds, dgrp, nxf, tnx, tny);
                 E.template family<true, LY::FWH, N, R + kPushReach, R>(H, packed, lds, dgrp + LY::hbase, nxf, tnx, tny);

@@ -61,7 +61,7 @@ __device__ __forceinline__ void stage_tile(const Problem *__restrict__ P, float 
     const int hw = win.halo_w(), hh = win.halo_h();
     const int tw = kTileW + 2 * hw, th = tile_h + 2 * hh;
     const int tws = tw + PAD;  // row stride of the float4 tile
-    const gptr_f32 ref = (gptr_f32)P->ref;
+    const gptr_f32 ref = (gptr_f32)P->ref.raw;
     float *tile = lds + lut_size<CH>();  // float4 per texel
     // gray: the scalar image goes to a scratch plane behind the float4 tile first, so that the
     // central differences can be formed once per tile instead of once per sample
@@ -632,7 +632,7 @@ __device__ __forceinline__ float tp_item(const Problem *__restrict__ P, const Vi
         const Win<BOX> win(P);
         return view_cost_c4_loop<BOX, true, FAST, true>(P, vc, H, tp0, tw, lut, px, py, win, tau, c0, c1, a, cols_run);
     } else {
-        const gptr_bytes base = (gptr_bytes)((uintptr_t)vc.packed - (uintptr_t)kMagicBits);
+        const gptr_bytes base = (gptr_bytes)((uintptr_t)vc.packed.raw - (uintptr_t)kMagicBits);
         return view_cost_pipe_range<BOX, FAST>(P, base, H, tp0, tw, lut, px, py, c0, c1, a, tau, cols_run);
     }
 }
@@ -680,7 +680,7 @@ __device__ __forceinline__ float refine_two_phase(const Problem *__restrict__ P,
                     else
                         lb = lb_item_c4<BOX, false>(P, P->view[v], H, tp0, L.tw, lut, L.px, L.py, ordp, np, lbk >> 1, &lbs);
                 } else {
-                    const gptr_bytes base = (gptr_bytes)((uintptr_t)P->view[v].packed - (uintptr_t)kMagicBits);
+                    const gptr_bytes base = (gptr_bytes)((uintptr_t)P->view[v].packed.raw - (uintptr_t)kMagicBits);
                     if (__all(safe))
                         lb = lb_item<BOX, true>(P, base, H, tp0, L.tw, lut, L.px, L.py, ordp, np, ord, lbk >> 1, &lbs);
                     else
@@ -843,15 +843,15 @@ __device__ __forceinline__ bool refine_step_items(const Problem *__restrict__ P,
     }
     if (P->dbg != nullptr && threadIdx.x == 0) {
         unsigned long long *d = P->dbg + (size_t)(phase & 63u) * kDbgSlots;
-        atomicAdd(&d[kDbgItemsOpen], (unsigned long long)items_left);
-        atomicAdd(&d[kDbgRedo], (unsigned long long)n_redo);
+        dbg_add(&d[kDbgItemsOpen], (unsigned long long)items_left);
+        dbg_add(&d[kDbgRedo], (unsigned long long)n_redo);
     }
     if (P->dbg != nullptr) {
         const unsigned n_cand = (unsigned)__popcll(__ballot(do_eval));
         if ((threadIdx.x & 63u) == 0u) {
             unsigned long long *d = P->dbg + (size_t)(phase & 63u) * kDbgSlots;
-            atomicAdd(&d[kDbgCands], (unsigned long long)n_cand);
-            atomicAdd(&d[kDbgItems], (unsigned long long)n_cand * (unsigned)P->n_sel);
+            dbg_add(&d[kDbgCands], (unsigned long long)n_cand);
+            dbg_add(&d[kDbgItems], (unsigned long long)n_cand * (unsigned)P->n_sel);
         }
     }
     if (probe) {
@@ -900,7 +900,7 @@ __device__ __forceinline__ void sweep_body(const Problem *__restrict__ P, SweepL
     const int prop_rounds = (L.n_tasks + kThreads - 1) / kThreads;
     if (P->dbg != nullptr) {
         unsigned long long *d = P->dbg + (size_t)(phase & 63u) * kDbgSlots;
-        if (threadIdx.x == 0) atomicAdd(&d[kDbgTasks], (unsigned long long)L.n_tasks);
+        if (threadIdx.x == 0) dbg_add(&d[kDbgTasks], (unsigned long long)L.n_tasks);
     }
     RefineDraws R;
     refine_init(R, P, stages);

@@ -1115,12 +1115,12 @@ def test_inconsistent_installed_costs_are_not_trusted(hip, tiny_problem):
                     assert (kept & (before_c != o.cost)).sum() > 50
 
 
-@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("fused", [0, 1])  # (colour sessions always run unfused; the switch must not change that)
 @pytest.mark.parametrize("push,group_from", [(0, 0), (2, 3), (6, 6)])
 def test_plane_keyed_propagation_colour(hip, push, group_from, fused):
-    """pm::sweep_group_kernel<15, 4> / pm::group_kernel<15, 4>: the plane-keyed propagation for -color_processing (three
-    window loads and tap sets per sample, l1_norm(float4) reductions, weights from the 766-entry table), ragged frame,
-    rule (S) on -- the oracle's bits"""
+    """pm::group_kernel<15, 4> + the sweep kernel: the plane-keyed propagation for -color_processing (three window loads
+    and tap sets per sample, l1_norm(float4) reductions, weights from the 766-entry table), ragged frame, rule (S) on --
+    the oracle's bits"""
     gs, _ = synth.build_problem(synth.tiny_config(cols=150, rows=100, n_src=4, blocksize=15, iterations=4, n_best=3),
                                 colour=True)
     o = OracleState(gs).run()
