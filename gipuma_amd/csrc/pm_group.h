@@ -105,7 +105,7 @@ struct GroupLayout {  // offsets in 32-bit words into the dynamic LDS array
     static constexpr int R = (BOX - 1) / 2, N = R + 1;
     static constexpr int task_lanes = group_task_lanes<BOX>();
     static_assert(task_lanes == 1 || task_lanes == 2, "one lane per task, or two that split its window columns");
-    static constexpr int batch_tasks = 64 / task_lanes;   // tasks whose chains run together
+    static constexpr int batch_tasks = 64;                 // tasks of a batch (two lanes per task: chains of 32 at a time, or one lane each)
     static constexpr int NH = (N + task_lanes - 1) / task_lanes;  // window columns of a chain lane (the second of two: N - NH)
     // the support weights of a chain lane's window columns stay in registers: as floats while they are at most 64,
     // else (box 25: 169) as their table indices |dI|, four per register -- a chain term then costs a table read more
@@ -681,9 +681,14 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
     float *dbuf = wbase + LY::w_dis;
     typename std::conditional<CH == 4, GroupWalkC4<BOX>, GroupWalk<BOX> >::type W;
     W.init(P);
-    // chains: one lane per task, or (two lanes per task) lane tl sums the left window columns of task tl and lane
-    // 32 + tl the right ones
-    const int half = TL == 2 ? lane >> 5 : 0, tl = TL == 2 ? lane & 31 : lane;
+    // Chains.  One lane per task with its N x N support weights in registers (boxes 11, 15, colour).  Box 25 (169 weights):
+    // a batch of at most 32 tasks runs two lanes per task -- lane tl sums window columns 0..NH-1 of task tl from float
+    // weights, lane 32 + tl continues with the rest --; a batch with more tasks runs one lane per task with the weights as
+    // byte indices into the table, four per register (a table read, a bit-field extract and an address more per term).
+    constexpr bool kDual = TL == 2;
+    constexpr bool kHasFloat = kDual || !LY::byte_weights, kHasByte = kDual || LY::byte_weights;
+    constexpr int kFloatW = kHasFloat ? NH * N : 0, kByteWords = kHasByte ? (N * N + 3) / 4 : 0;
+    constexpr int kStore = kFloatW > kByteWords ? kFloatW : kByteWords;
 
     for (;;) {
         // -- take the next run of groups from the cursor --
@@ -778,10 +783,14 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
             return CH == 4 ? (gptr_bytes)P->view[v].packed.raw : (gptr_bytes)((uintptr_t)P->view[v].packed.raw - (uintptr_t)kMagicBits);
         };
 
-        // -- rounds of at most kBatchTasks tasks (more than one only for a single group offered to more pixels) --
-        for (int t_lo = 0; t_lo < n_alltasks; t_lo += kBatchTasks) {
-            const int n_bt = min(kBatchTasks, n_alltasks - t_lo);
-            // this lane's task: sample-buffer offset of its half window, slot, pixel, support weights of its columns
+        // -- rounds of tasks (more than one only for a single group offered to more than 64 pixels) --
+        const bool two = kDual && n_alltasks <= 32;          // (wave-uniform) two lanes per task, float weights
+        const bool bytes = kHasByte && (!kHasFloat || !two);  // one lane per task, byte-indexed weights
+        const int half = two ? lane >> 5 : 0, tl = two ? lane & 31 : lane;
+        const int round_tasks = two ? 32 : 64;
+        for (int t_lo = 0; t_lo < n_alltasks; t_lo += round_tasks) {
+            const int n_bt = min(round_tasks, n_alltasks - t_lo);
+            // this lane's task: sample-buffer offset of its (half) window, slot, pixel, support weights of its columns
             int t_off = 0, t_slot = 0, t_center = 0;
             const float *t_tp = plane + CH * (L.hh * tw + L.hw);
             const bool has = tl < n_bt;
@@ -799,53 +808,60 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
                 t_tp = plane + CH * ((oly + L.hh) * tw + (olx + L.hw));
             }
             // support weights (weight_cu, gipuma.cu:186-193: 256 possible weights) of this lane's window columns,
-            // column outer, row inner -- the order of the chain
-            constexpr bool kByteW = LY::byte_weights;
-            float wgt[kByteW ? 1 : NH * N];
-            uint32_t widx[kByteW ? (NH * N + 3) / 4 : 1];
+            // column outer, row inner -- the order of the chain; as floats, or as their table indices |dI| packed
+            // four to a register (the registers are the same ones: a batch uses one form)
+            float wst[kStore];
             if constexpr (CH == 4) {
                 // colour: the table is indexed by the integer |dB| + |dG| + |dR| (0..765), view_cost_c4_loop
                 const float4 centre = *reinterpret_cast<const float4 *>(t_tp);
-                const float *tc = t_tp + 4 * (-R * tw - R + 2 * half * NH);
+                const float *tc = t_tp + 4 * (-R * tw - R);
 #pragma unroll
-                for (int i = 0; i < NH; i++)
+                for (int i = 0; i < N; i++)
 #pragma unroll
                     for (int jj = 0; jj < N; jj++) {
                         const float4 lv = *reinterpret_cast<const float4 *>(tc + 4 * (2 * jj * tw + 2 * i));
                         const float S = __builtin_fabsf(lv.x - centre.x) + __builtin_fabsf(lv.y - centre.y) +
                                         __builtin_fabsf(lv.z - centre.z);
-                        wgt[i * N + jj] = lds[(int)S];
+                        wst[i * N + jj] = lds[(int)S];
                     }
             } else {
                 const float centre = t_tp[0];
-                const float *tc = t_tp + (-R * tw - R + 2 * half * NH);
-                if constexpr (kByteW) {
+                if (!bytes) {
+                    if constexpr (kHasFloat) {
+                        const float *tc = t_tp + (-R * tw - R + 2 * half * NH);
 #pragma unroll
-                    for (int q = 0; q < (NH * N + 3) / 4; q++) widx[q] = 0u;
-                }
+                        for (int i = 0; i < NH; i++) {
+                            // (two lanes, odd N: the second lane has one column less; its spare slot re-reads its first column)
+                            const int ci = (kDual && N % 2 != 0 && i == NH - 1 && half != 0) ? 0 : i;
 #pragma unroll
-                for (int i = 0; i < NH; i++) {
-                    // (two lanes, odd N: the second lane has one column less; its spare slot re-reads its first column)
-                    const int ci = (TL == 2 && N % 2 != 0 && i == NH - 1 && half != 0) ? 0 : i;
+                            for (int jj = 0; jj < N; jj++) {
+                                const float colorDis = __builtin_fabsf(tc[2 * jj * tw + 2 * ci] - centre);  // an integer 0..255
+                                wst[i * N + jj] = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
+                            }
+                        }
+                    }
+                } else {
+                    if constexpr (kHasByte) {
+                        const float *tc = t_tp + (-R * tw - R);
+                        uint32_t word = 0u;
 #pragma unroll
-                    for (int jj = 0; jj < N; jj++) {
-                        const float colorDis = __builtin_fabsf(tc[2 * jj * tw + 2 * ci] - centre);  // an integer 0..255
-                        if constexpr (kByteW)
-                            widx[(i * N + jj) >> 2] |= ((__float_as_uint(colorDis + kMagicF) >> 2) & 0xffu) << (8 * ((i * N + jj) & 3));
-                        else
-                            wgt[i * N + jj] = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
+                        for (int e = 0; e < N * N; e++) {
+                            const int i = e / N, jj = e - i * N;
+                            const float colorDis = __builtin_fabsf(tc[2 * jj * tw + 2 * i] - centre);
+                            word |= ((__float_as_uint(colorDis + kMagicF) >> 2) & 0xffu) << (8 * (e & 3));
+                            if ((e & 3) == 3 || e == N * N - 1) {
+                                wst[e >> 2] = __uint_as_float(word);
+                                word = 0u;
+                            }
+                        }
                     }
                 }
             }
-            // the weight of window sample e of this lane's columns
-            auto weight = [&](int e) -> float {
-                if constexpr (kByteW) {
-                    // (byte e & 3 of its word, times four: the byte offset of the table entry)
-                    const uint32_t off = (e & 3) == 0 ? (widx[e >> 2] << 2) & 0x3fcu : (widx[e >> 2] >> (8 * (e & 3) - 2)) & 0x3fcu;
-                    return *(const float *)((const char *)lds + off);
-                } else {
-                    return wgt[e];
-                }
+            // the table entry of window sample e (byte form): byte e & 3 of its word, times four = its byte offset
+            auto byte_weight = [&](int e) -> float {
+                const uint32_t w = __float_as_uint(wst[e >> 2]);
+                const uint32_t off = (e & 3) == 0 ? (w << 2) & 0x3fcu : (w >> (8 * (e & 3) - 2)) & 0x3fcu;
+                return *(const float *)((const char *)lds + off);
             };
             ViewCombiner<true> comb;
 
@@ -878,18 +894,11 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
                     else
                         W.template first<false>(view_base(v + 1), hn, sv, SA, SB);
                 }
-                // chains: the reference's summation order over each task's own window -- the left columns by lane
-                // tl, then, continuing from its sum, the right columns by lane 32 + tl.  A window column's samples
-                // are read while the column before is summed.
+                // chains: the reference's summation order over each task's own window.  A window column's samples
+                // (and, byte form, its weights) are read while the column before is summed.
                 const float *dcol = dbuf + t_off;
                 float cst = 0.0f;
-                if constexpr (kByteW) {
-                    // (the table reads depend on the pixel alone: left to itself the compiler hoists all 169 of them
-                    //  out of the view loop and spills; the empty asm makes the indices opaque per view)
-#pragma unroll
-                    for (int q = 0; q < (NH * N + 3) / 4; q++) asm volatile("" : "+v"(widx[q]));
-                }
-                auto half_chain = [&](auto ncols) {  // this lane's first ncols window columns
+                auto float_chain = [&](auto ncols) {  // this lane's first ncols window columns
                     constexpr int NC = decltype(ncols)::value;
                     float dv[2][N];
 #pragma unroll
@@ -902,25 +911,60 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int jj = 0; jj < N; jj++) cst = __builtin_fmaf(weight(i * N + jj), dv[i & 1][jj], cst);
+                        for (int jj = 0; jj < N; jj++) cst = __builtin_fmaf(wst[i * N + jj], dv[i & 1][jj], cst);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 };
-                if constexpr (TL == 2) {
-                    if (half == 0 && has) half_chain(std::integral_constant<int, NH>());
+                auto byte_chain = [&]() {
+                    // (the table reads depend on the pixel alone: left to itself the compiler hoists all of them out of
+                    //  the view loop and spills; the empty asm makes the indices opaque per view)
+#pragma unroll
+                    for (int q = 0; q < kByteWords; q++) asm volatile("" : "+v"(wst[q]));
+                    float dv[2][N], wv[2][N];
+#pragma unroll
+                    for (int jj = 0; jj < N; jj++) {
+                        dv[0][jj] = dcol[jj];
+                        wv[0][jj] = byte_weight(jj);
+                    }
+#pragma unroll
+                    for (int i = 0; i < N; i++) {
+                        if (i + 1 < N) {
+#pragma unroll
+                            for (int jj = 0; jj < N; jj++) {
+                                dv[(i + 1) & 1][jj] = dcol[(i + 1) * nr_b + jj];
+                                wv[(i + 1) & 1][jj] = byte_weight((i + 1) * N + jj);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int jj = 0; jj < N; jj++) cst = __builtin_fmaf(wv[i & 1][jj], dv[i & 1][jj], cst);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                if (bytes) {
+                    if constexpr (kHasByte) {
+                        if (has) {
+                            byte_chain();
+                            comb.add(cst, v, nullptr);
+                        }
+                    }
+                } else if constexpr (kDual) {
+                    if (half == 0 && has) float_chain(std::integral_constant<int, NH>());
                     const float left = __shfl(cst, tl);
                     if (half == 1 && has) {
                         cst = left;
-                        half_chain(std::integral_constant<int, N - NH>());
+                        float_chain(std::integral_constant<int, N - NH>());
                         comb.add(cst, v, nullptr);
                     }
-                } else if (has) {
-                    half_chain(std::integral_constant<int, NH>());
-                    comb.add(cst, v, nullptr);
+                } else if constexpr (kHasFloat) {
+                    if (has) {
+                        float_chain(std::integral_constant<int, N>());
+                        comb.add(cst, v, nullptr);
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();  // the next view's strips overwrite the samples
             }
-            if (half == TL - 1 && has) P->push_cost[(size_t)t_slot * np + (size_t)t_center] = comb.finish(P, n, nullptr);
+            if ((two ? half == 1 : true) && has) P->push_cost[(size_t)t_slot * np + (size_t)t_center] = comb.finish(P, n, nullptr);
         }
     }
     lap(3);  // batches (this workgroup's first wavefront)
