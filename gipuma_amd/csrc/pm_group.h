@@ -135,7 +135,7 @@ struct GroupLayout {  // offsets in 32-bit words into the dynamic LDS array
     static constexpr int g_hash = waves, g_gid = g_hash + kGrpHashSize, g_btask = g_gid + kGrpMaxTasks / 2,
                          g_cnt = g_btask + kGrpMaxTasks / 2;
     static constexpr int total = waves + (4 * w_stride > g_cnt + kGrpMaxTasks - waves ? 4 * w_stride : g_cnt + kGrpMaxTasks - waves);
-    static_assert(batch_samples >= max_cols * max_rows, "the largest possible group fits a wavefront's sample buffer");
+    static_assert(batch_samples >= max_cols * (max_rows | 1), "the largest possible group fits a wavefront's sample buffer");
     static_assert(kGrpBatchStrips >= max_cols, "the strips of the largest possible group fit the lanes");
     static_assert(total * 4 * group_wg<BOX, CH>() <= 160 * 1024, "workgroups per CU");
     static_assert((w_gplane % 4) == 0 && (w_hbuf % 4) == 0 && (waves % 4) == 0 && (w_stride % 4) == 0, "16-byte aligned float4 tables");
@@ -716,7 +716,9 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
             }
         }
         // (strip lengths do not decrease along gorder: a group's own nr is the largest of the run up to it)
-        const bool fits = g >= 0 && ic <= kGrpBatchStrips && it <= kBatchTasks && ic * nr <= LY::batch_samples;
+        // (a strip's samples lie `nr | 1` words apart: an odd stride keeps the 64 lanes' writes of a row -- and the
+        //  chains' reads -- off each other's LDS banks; an even one, 8 or 16 above all, serialises them)
+        const bool fits = g >= 0 && ic <= kGrpBatchStrips && it <= kBatchTasks && ic * (nr | 1) <= LY::batch_samples;
         const unsigned long long fb = __ballot(fits);
         int cnt = fb == ~0ull ? 64 : (int)__builtin_ctzll(~fb);
         if (cnt == 0) cnt = 1;  // a single group always fits the strips and the buffer; more than 32 tasks: several rounds
@@ -727,6 +729,7 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
         const int n_strips = __builtin_amdgcn_readfirstlane(__shfl(ic, cnt - 1));
         const int n_alltasks = __builtin_amdgcn_readfirstlane(__shfl(it, cnt - 1));
         const int nr_b = __builtin_amdgcn_readfirstlane(__shfl(nr, cnt - 1));
+        const int nrs = nr_b | 1;  // stride of a strip in the sample buffer
         if (lane < cnt) {
             const int sp = ic - nc, tp = it - nt;
             wtab[4 * lane + 0] = (unsigned short)g;
@@ -758,7 +761,7 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
             W.qx = (float)(L.x0 + s_lx);
             W.qy0 = (float)(L.y0 + s_ly);
             W.tcol = plane + CH * ((s_ly + L.hh) * tw + (s_lx + L.hw));
-            W.out = dbuf + s * nr_b;
+            W.out = dbuf + s * nrs;
             W.grp = j;
         }
         // homographies of (group, view) for views vb .. vb + kGrpViewsPerH - 1, one pair per lane; [9] = the fast
@@ -801,7 +804,7 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
                 const unsigned bt = sbt[(int)(gm & 2047u) + (t_lo + tl - (int)wtab[4 * j + 2])];
                 int olx, oly;
                 owner_pixel(L, (int)(bt & 255u), colour, olx, oly);
-                t_off = ((int)wtab[4 * j + 1] + ((olx - (int)((gm >> 11) & 31u)) >> 1) + half * NH) * nr_b +
+                t_off = ((int)wtab[4 * j + 1] + ((olx - (int)((gm >> 11) & 31u)) >> 1) + half * NH) * nrs +
                         ((oly - (int)((gm >> 16) & 15u)) >> 1);
                 t_slot = (int)(bt >> 8);
                 t_center = (L.y0 + oly) * cols + (L.x0 + olx);
@@ -907,7 +910,7 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
                     for (int i = 0; i < NC; i++) {
                         if (i + 1 < NC) {
 #pragma unroll
-                            for (int jj = 0; jj < N; jj++) dv[(i + 1) & 1][jj] = dcol[(i + 1) * nr_b + jj];
+                            for (int jj = 0; jj < N; jj++) dv[(i + 1) & 1][jj] = dcol[(i + 1) * nrs + jj];
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -931,7 +934,7 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
                         if (i + 1 < N) {
 #pragma unroll
                             for (int jj = 0; jj < N; jj++) {
-                                dv[(i + 1) & 1][jj] = dcol[(i + 1) * nr_b + jj];
+                                dv[(i + 1) & 1][jj] = dcol[(i + 1) * nrs + jj];
                                 wv[(i + 1) & 1][jj] = byte_weight((i + 1) * N + jj);
                             }
                         }
