@@ -35,18 +35,22 @@
 //   * per view a lane walks its strips in one continuous software pipeline (the windows of sample s+2 requested
 //     before sample s is reduced, across strip boundaries), and the first two windows of the NEXT view are requested
 //     before the chain phase of this one, so their latency hides behind it;
-//   * the 64 support weights of a task depend on its pixel alone: they are computed once per batch and stay in
-//     registers, half a window per lane (two lanes per task: the first sums the left window columns and hands its
-//     partial sum to the second); a chain term is one LDS read and one fmaf;
+//   * the support weights of a task depend on its pixel alone: they are computed once per batch and stay in
+//     registers, one lane per task (boxes 11, 15, colour: at most 64 floats); a chain term is one LDS read and one
+//     fmaf.  Box 25 has 169: batches of up to 32 tasks run two lanes per task (the first sums window columns 0..6 and
+//     hands its partial sum to the second), larger ones one lane per task with the weights as byte indices into the
+//     weight table, four to a register, read a window column ahead;
+//   * a strip's samples lie an odd number of words apart in the wavefront's buffer (LDS banks);
 //   * the homographies of a batch's (group, view) pairs are computed four views at a time, one pair per lane;
-//   * 50 KB of LDS and at most 168 registers: three workgroups per CU.
+//   * 50 KB of LDS and at most 168 registers: three workgroups per CU (box 25 and colour: 256 registers, two).
 // The aggregate goes to Problem::push_cost[slot][pixel], where the half-sweep finds it (Tune::kPushConsume);
 // candidates the skip rules removed get MAXCOST there, which the strict < of the accept test (gipuma.cu:868)
 // rejects like their true cost would be.
 // Same terms, same order, same roundings as view_cost_pipe + multiview_cost: bit-identical.
 //
-// Supported: gray window-packed planes with float-encoded offsets, box 11 / 15, best-N with n_best <= 4.
-// GIPUMA_HIP_COUNTS=1 reports its phase clocks.
+// Supported: window-packed planes (gray: float-encoded offsets), best-N with n_best <= 4; gray boxes 11 / 15 / 25 alone
+// (group_kernel) or fused with the half-sweep (sweep_group_kernel), colour box 15 alone.
+// GIPUMA_HIP_COUNTS=1 reports batch statistics and phase clocks.
 #pragma once
 #include <type_traits>
 #include "pm_device.h"
@@ -694,7 +698,7 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
         // -- take the next run of groups from the cursor --
         __builtin_amdgcn_wave_barrier();
         int start = 0;
-        if (lane == 0) start = *(volatile int *)&misc[9];
+        if (lane == 0) start = __hip_atomic_load(&misc[9], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         start = __builtin_amdgcn_readfirstlane(start);
         if (start >= n_groups) break;
         int g = -1, nc = 0, nt = 0, nr = 0, tfirst = 0;

@@ -1,5 +1,5 @@
 #!/bin/sh
-# round 4: odd strip stride in the plane-keyed sample buffers (LDS bank conflicts)
+# round 4: LDS bank conflicts of the plane-keyed kernels: odd strip stride, parity-split reference plane
 export GIPUMA_HIP_EXPERIMENTS=1
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r04l; mkdir -p $O
