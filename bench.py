@@ -26,6 +26,7 @@ import os
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -119,9 +120,10 @@ def _ref_baseline(problem_file, rows, cols, iterations, n_proc, blocks_each=4):
         cpu = cpus[(i * max(1, len(cpus) // max(n_proc, 1))) % len(cpus)] if cpus else -1
         code = ("import sys; sys.path.insert(0, %r); import bench; bench._ref_worker(%r, %d, %d, %d, %d, %d)"
                 % (ROOT, problem_file, bx0, min(bx0 + blocks_each, gx - 1), by0, by0 + 1, cpu))
+        errf = tempfile.TemporaryFile(mode="w+")  # (kept: a worker that dies says why)
         procs.append(subprocess.Popen([sys.executable, "-c", code], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
-                                      stderr=subprocess.DEVNULL, text=True,
-                                      env=dict(os.environ, OMP_NUM_THREADS="1")))
+                                      stderr=errf, text=True, env=dict(os.environ, OMP_NUM_THREADS="1")))
+        procs[-1].errf = errf
     for p in procs:  # every worker has mapped the frames and touched its pages
         while True:
             line = p.stdout.readline()
@@ -138,6 +140,11 @@ def _ref_baseline(problem_file, rows, cols, iterations, n_proc, blocks_each=4):
         lines = [l for l in out.splitlines() if l.startswith("{")]
         if lines:
             res.append(json.loads(lines[-1]))
+        else:
+            p.errf.seek(0)
+            print("bench: a reference-baseline worker produced no result (rc %s): %s"
+                  % (p.returncode, p.errf.read()[-400:].strip()), file=sys.stderr)
+        p.errf.close()
     wall = time.perf_counter() - t0
     if not res or any(r["rc"] for r in res):
         return None
