@@ -29,9 +29,11 @@
 // issue rate; its chain phase was bound by three dependent LDS reads per term).  This version has NO workgroup
 // barrier after the set-up:
 //   * the groups are sorted by strip length, so the strips a wavefront walks together are equally long;
-//   * a BATCH -- a run of consecutive groups: at most kGrpBatchGroups groups, 64 strips, 64 tasks and as many
-//     samples per view as a wavefront's slice of LDS holds -- belongs to ONE wavefront, which takes it from a shared cursor; strips
-//     and chains of a batch only meet inside that wavefront (LDS operations of a wavefront complete in order);
+//   * a BATCH -- at most kGrpBatchGroups groups, 64 strips, 64 tasks and as many samples per view as a wavefront's
+//     slice of LDS holds: groups from the long-strip end of the order until one of these is full, then groups from
+//     the short-strip end into the lanes still free -- belongs to ONE wavefront, which takes it from a shared
+//     two-ended cursor; strips and chains of a batch only meet inside that wavefront (LDS operations of a wavefront
+//     complete in order);
 //   * per view a lane walks its strips in one continuous software pipeline (the windows of sample s+2 requested
 //     before sample s is reduced, across strip boundaries), and the first two windows of the NEXT view are requested
 //     before the chain phase of this one, so their latency hides behind it;
@@ -530,7 +532,7 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
         for (int k = tid; k < kGrpHashSize; k += kThreads) hash[k] = 0u;
         if (tid == 0) {
             misc[8] = 0;   // number of groups
-            misc[9] = 0;   // batch cursor: next position in gorder
+            misc[9] = 0;   // batch cursor: groups taken from the short-strip end | from the long-strip end << 16
         }
         if (tid < 16) misc[32 + tid] = 0;  // histogram of the groups' strip lengths
         __syncthreads();
@@ -695,55 +697,71 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
     constexpr int kStore = kFloatW > kByteWords ? kFloatW : kByteWords;
 
     for (;;) {
-        // -- take the next run of groups from the cursor --
-        __builtin_amdgcn_wave_barrier();
-        int start = 0;
-        if (lane == 0) start = __hip_atomic_load(&misc[9], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        start = __builtin_amdgcn_readfirstlane(start);
-        if (start >= n_groups) break;
+        // -- take the next batch from the two-ended cursor: groups from the long-strip end of gorder until the lanes, the
+        //    tasks or the sample buffer are full, then groups from the short-strip end into the lanes still free (they
+        //    walk the batch's row count, a few rows more than their own: lanes that would otherwise idle) --
+        int cur = 0;
+        if (lane == 0) cur = __hip_atomic_load(&misc[9], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        cur = __builtin_amdgcn_readfirstlane(cur);
+        const int took_lo = cur & 0xffff, took_hi = cur >> 16;  // groups already taken from either end
+        const int remaining = n_groups - took_lo - took_hi;
+        if (remaining <= 0) break;
+        // lanes 0..7: candidates from the top (longest strips first); lanes 8..15: from the bottom
+        const bool top = lane < kGrpBatchGroups, bot = !top && lane < 2 * kGrpBatchGroups;
+        const int rank = lane & (kGrpBatchGroups - 1);
         int g = -1, nc = 0, nt = 0, nr = 0, tfirst = 0;
-        uint32_t m = 0u;
-        if (lane < kGrpBatchGroups && start + lane < n_groups) {
-            g = (int)gorder[start + lane];
-            m = meta[g];
+        if ((top || bot) && rank < remaining) {
+            g = (int)gorder[top ? n_groups - 1 - took_hi - rank : took_lo + rank];
+            const uint32_t m = meta[g];
             nc = N + (int)((m >> 20) & 15u);
             nr = N + (int)((m >> 24) & 7u);
             nt = group_tasks(g, tfirst);
         }
+        // inclusive prefix sums of strips and tasks inside each run of 8 lanes
         int ic = nc, it = nt;
 #pragma unroll
         for (int d = 1; d < kGrpBatchGroups; d <<= 1) {
             const int uc = __shfl_up(ic, d), ut = __shfl_up(it, d);
-            if (lane >= d) {
+            if (rank >= d) {
                 ic += uc;
                 it += ut;
             }
         }
-        // (strip lengths do not decrease along gorder: a group's own nr is the largest of the run up to it)
-        // (a strip's samples lie `nr | 1` words apart: an odd stride keeps the 64 lanes' writes of a row -- and the
-        //  chains' reads -- off each other's LDS banks; an even one, 8 or 16 above all, serialises them)
-        const bool fits = g >= 0 && ic <= kGrpBatchStrips && it <= kBatchTasks && ic * (nr | 1) <= LY::batch_samples;
-        const unsigned long long fb = __ballot(fits);
-        int cnt = fb == ~0ull ? 64 : (int)__builtin_ctzll(~fb);
-        if (cnt == 0) cnt = 1;  // a single group always fits the strips and the buffer; more than 32 tasks: several rounds
+        // (strip lengths do not increase from the top down: the first group's row count is the batch's; a strip's samples
+        //  lie `nr | 1` words apart: an odd stride keeps the 64 lanes' writes of a row -- and the chains' reads -- off
+        //  each other's LDS banks; an even one, 8 or 16 above all, serialises them)
+        const int nr_b = __builtin_amdgcn_readfirstlane(nr);
+        const int nrs = nr_b | 1;
+        const bool fits_top = top && g >= 0 && ic <= kGrpBatchStrips && it <= kBatchTasks && ic * nrs <= LY::batch_samples;
+        const unsigned ft = (unsigned)__ballot(fits_top) & 0xffu;
+        int k1 = (int)__builtin_ctz(~ft);  // leading lanes that fit (<= 8)
+        if (k1 == 0) k1 = 1;  // a single group always fits the strips and the buffer; more than 64 tasks: several rounds
+        const int s1 = __builtin_amdgcn_readfirstlane(__shfl(ic, k1 - 1)), t1 = __builtin_amdgcn_readfirstlane(__shfl(it, k1 - 1));
+        const bool fits_bot = bot && g >= 0 && rank < remaining - k1 && rank < kGrpBatchGroups - k1 && s1 + ic <= kGrpBatchStrips &&
+                              t1 + it <= kBatchTasks && (s1 + ic) * nrs <= LY::batch_samples;
+        const unsigned fbm = ((unsigned)(__ballot(fits_bot) >> kGrpBatchGroups)) & 0xffu;
+        const int k2 = (int)__builtin_ctz(~fbm);
+        const int cnt = k1 + k2;
         int won = 0;
-        if (lane == 0) won = atomicCAS(&misc[9], start, start + cnt) == start ? 1 : 0;
-        if (!__builtin_amdgcn_readfirstlane(won)) continue;  // another wavefront took (part of) this run
+        if (lane == 0) won = atomicCAS(&misc[9], cur, cur + k2 + (k1 << 16)) == cur ? 1 : 0;
+        if (!__builtin_amdgcn_readfirstlane(won)) continue;  // another wavefront took from an end meanwhile
         // (wave-uniform, in scalar registers: they steer the loops below)
-        const int n_strips = __builtin_amdgcn_readfirstlane(__shfl(ic, cnt - 1));
-        const int n_alltasks = __builtin_amdgcn_readfirstlane(__shfl(it, cnt - 1));
-        const int nr_b = __builtin_amdgcn_readfirstlane(__shfl(nr, cnt - 1));
-        const int nrs = nr_b | 1;  // stride of a strip in the sample buffer
-        if (lane < cnt) {
-            const int sp = ic - nc, tp = it - nt;
-            wtab[4 * lane + 0] = (unsigned short)g;
-            wtab[4 * lane + 1] = (unsigned short)sp;
-            wtab[4 * lane + 2] = (unsigned short)tp;
-            for (int k = 0; k < nc; k++) sgroup[sp + k] = (unsigned char)lane;
-            if (n_alltasks <= kBatchTasks)
-                for (int k = 0; k < nt; k++) tgroup[tp + k] = (unsigned char)lane;
-            int rlx, rly, rnb;
-            gplane[lane] = desc_plane(sbt[tfirst], rlx, rly, rnb);
+        const int n_strips = s1 + (k2 > 0 ? __builtin_amdgcn_readfirstlane(__shfl(ic, kGrpBatchGroups + k2 - 1)) : 0);
+        const int n_alltasks = t1 + (k2 > 0 ? __builtin_amdgcn_readfirstlane(__shfl(it, kGrpBatchGroups + k2 - 1)) : 0);
+        {
+            // this lane's group becomes group j of the batch
+            const int j = top ? (rank < k1 ? rank : -1) : bot ? (rank < k2 ? k1 + rank : -1) : -1;
+            if (j >= 0) {
+                const int sp = (top ? 0 : s1) + ic - nc, tp = (top ? 0 : t1) + it - nt;
+                wtab[4 * j + 0] = (unsigned short)g;
+                wtab[4 * j + 1] = (unsigned short)sp;
+                wtab[4 * j + 2] = (unsigned short)tp;
+                for (int k = 0; k < nc; k++) sgroup[sp + k] = (unsigned char)j;
+                if (n_alltasks <= kBatchTasks)
+                    for (int k = 0; k < nt; k++) tgroup[tp + k] = (unsigned char)j;
+                int rlx, rly, rnb;
+                gplane[j] = desc_plane(sbt[tfirst], rlx, rly, rnb);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         if (P->dbg != nullptr && lane == 0) {  // (GIPUMA_HIP_COUNTS: batch statistics in row 61 of Problem::dbg)

@@ -1,5 +1,5 @@
 #!/bin/sh
-# round 4: LDS bank conflicts of the plane-keyed kernels: odd strip stride, parity-split reference plane
+# round 4: plane-keyed batches taken from both ends of the strip-length order (lane fill)
 export GIPUMA_HIP_EXPERIMENTS=1
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r04l; mkdir -p $O
@@ -10,12 +10,15 @@ C_base GIPUMA_HIP_LIB=$V/libgipuma_hip_base.so
 C_new
 C_base2 GIPUMA_HIP_LIB=$V/libgipuma_hip_base.so
 C_new2
+C_counts GIPUMA_HIP_COUNTS=1
 LIST
 sh scripts/gpu_ab.sh --config D <<LIST
 D_base GIPUMA_HIP_LIB=$V/libgipuma_hip_base.so
 D_new
+D_counts GIPUMA_HIP_COUNTS=1
 LIST
 sh scripts/gpu_ab.sh --colour <<LIST
 col_base GIPUMA_HIP_LIB=$V/libgipuma_hip_base.so
 col_new
 LIST
+grep "batches" gpurun_out/ab/C_counts.err gpurun_out/ab/D_counts.err | tail -2
