@@ -234,13 +234,20 @@ struct GroupWalk {
         s.H7 = b.w;
         return s;
     }
-    template <bool FAST>
-    __device__ __forceinline__ WinReq request(gptr_bytes magic_base, const StripView &s, float qy) const
+    // (`fast`, wave-uniform: the fast reciprocal is exact on the batch's boxes for this view.  ONE loop with a scalar branch
+    //  per sample instead of two specialised loops: with two, the waits the compiler placed in the second one drained
+    //  both window loads at the top of every iteration -- vmcnt(0) where the first has vmcnt(1) twice --, which left a
+    //  load only the other set's reduce to arrive in.)
+    __device__ __forceinline__ WinReq request(gptr_bytes magic_base, const StripView &s, float qy, bool fast) const
     {
         const float X = __builtin_fmaf(s.H1, qy, s.X0);
         const float Y = __builtin_fmaf(s.H4, qy, s.Y0);
         const float Z = __builtin_fmaf(s.H7, qy, s.Z0);
-        const float rz = recip<FAST>(Z);
+        float rz;
+        if (fast)
+            rz = rcp_newton(Z);
+        else
+            rz = 1.0f / Z;
         const float sx = X * rz, sy = Y * rz;
         const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
         WinReq r;
@@ -277,13 +284,12 @@ struct GroupWalk {
         *o = __builtin_fmaf(alpha, gradDis, oma * colDis);
     }
     // the first two window requests of a view (rows 0 and 1)
-    template <bool FAST>
     __device__ __forceinline__ void first(gptr_bytes magic_base, const float *__restrict__ hb, StripView &sv, Set &A,
-                                          Set &B) const
+                                          Set &B, bool fast) const
     {
         sv = view_of(hb);
-        A.req = request<FAST>(magic_base, sv, qy0);
-        B.req = request<FAST>(magic_base, sv, qy0 + 2.0f);
+        A.req = request(magic_base, sv, qy0, fast);
+        B.req = request(magic_base, sv, qy0 + 2.0f, fast);
         A.qy = qy0 + 4.0f;
         B.qy = qy0 + 6.0f;
         A.tq = tcol;
@@ -292,8 +298,8 @@ struct GroupWalk {
         B.o = out + 1;
     }
     // A step of a set: convert the window it holds, request its next one (two rows further) unless LAST, reduce.
-    template <bool FAST, bool LAST>
-    __device__ __forceinline__ void step(gptr_bytes magic_base, const StripView &sv, Set &S) const
+    template <bool LAST>
+    __device__ __forceinline__ void step(gptr_bytes magic_base, const StripView &sv, Set &S, bool fast) const
     {
         const float *tq = S.tq;
         float *o = S.o;
@@ -303,7 +309,7 @@ struct GroupWalk {
         const float a = S.req.a, b = S.req.b;
         __builtin_amdgcn_sched_barrier(0);
         if (!LAST) {
-            S.req = request<FAST>(magic_base, sv, S.qy);
+            S.req = request(magic_base, sv, S.qy, fast);
             S.qy += 4.0f;
             S.tq = tq + 4 * tw;
             S.o = o + 2;
@@ -314,21 +320,22 @@ struct GroupWalk {
     }
     // the nr rows (wave-uniform, >= 3) of this lane's strip for the view whose first two requests are in (A, B):
     // A walks the even rows, B the odd ones; nothing is in flight at the end
-    template <bool FAST>
-    __device__ __forceinline__ void body(gptr_bytes magic_base, int nr, const StripView &sv, Set &A, Set &B) const
+    __device__ __forceinline__ void body(gptr_bytes magic_base, int nr, const StripView &sv, Set &A, Set &B, bool fast) const
     {
+        int fi = __builtin_amdgcn_readfirstlane(fast ? 1 : 0);
         const int n_pairs = (nr - 2) >> 1;  // pairs of rows both of which request (rows r, r + 1 with r + 3 < nr)
         for (int r = 0; r < n_pairs; r++) {
-            step<FAST, false>(magic_base, sv, A);
-            step<FAST, false>(magic_base, sv, B);
+            asm volatile("" : "+s"(fi));  // (opaque per iteration: the loop is not to be unswitched into two)
+            step<false>(magic_base, sv, A, fi != 0);
+            step<false>(magic_base, sv, B, fi != 0);
         }
         if (nr & 1) {  // (wave-uniform) rows nr - 3 (requests the last one), nr - 2, nr - 1
-            step<FAST, false>(magic_base, sv, A);
-            step<FAST, true>(magic_base, sv, B);
-            step<FAST, true>(magic_base, sv, A);
+            step<false>(magic_base, sv, A, fi != 0);
+            step<true>(magic_base, sv, B, false);
+            step<true>(magic_base, sv, A, false);
         } else {
-            step<FAST, true>(magic_base, sv, A);
-            step<FAST, true>(magic_base, sv, B);
+            step<true>(magic_base, sv, A, false);
+            step<true>(magic_base, sv, B, false);
         }
     }
 };
@@ -383,13 +390,16 @@ struct GroupWalkC4 {
         s.H7 = b.w;
         return s;
     }
-    template <bool FAST>
-    __device__ __forceinline__ Req request(gptr_bytes packed, const StripView &s, float qy) const
+    __device__ __forceinline__ Req request(gptr_bytes packed, const StripView &s, float qy, bool fast) const
     {
         const float X = __builtin_fmaf(s.H1, qy, s.X0);
         const float Y = __builtin_fmaf(s.H4, qy, s.Y0);
         const float Z = __builtin_fmaf(s.H7, qy, s.Z0);
-        const float rz = recip<FAST>(Z);
+        float rz;
+        if (fast)
+            rz = rcp_newton(Z);
+        else
+            rz = 1.0f / Z;
         const float sx = X * rz, sy = Y * rz;
         const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
         Req r;
@@ -403,12 +413,12 @@ struct GroupWalkC4 {
         r.q2 = *(gptr_u32x4)(base + 32);
         return r;
     }
-    template <bool FAST>
-    __device__ __forceinline__ void first(gptr_bytes packed, const float *__restrict__ hb, StripView &sv, Set &A, Set &B) const
+    __device__ __forceinline__ void first(gptr_bytes packed, const float *__restrict__ hb, StripView &sv, Set &A, Set &B,
+                                          bool fast) const
     {
         sv = view_of(hb);
-        A.req = request<FAST>(packed, sv, qy0);
-        B.req = request<FAST>(packed, sv, qy0 + 2.0f);
+        A.req = request(packed, sv, qy0, fast);
+        B.req = request(packed, sv, qy0 + 2.0f, fast);
         A.qy = qy0 + 4.0f;
         B.qy = qy0 + 6.0f;
         A.tq = tcol;
@@ -416,8 +426,8 @@ struct GroupWalkC4 {
         A.o = out;
         B.o = out + 1;
     }
-    template <bool FAST, bool LAST>
-    __device__ __forceinline__ void step(gptr_bytes packed, const StripView &sv, Set &S) const
+    template <bool LAST>
+    __device__ __forceinline__ void step(gptr_bytes packed, const StripView &sv, Set &S, bool fast) const
     {
         const float *tq = S.tq;
         float *o = S.o;
@@ -432,7 +442,7 @@ struct GroupWalkC4 {
         const float a = q.a, b = q.b;
         __builtin_amdgcn_sched_barrier(0);
         if (!LAST) {
-            S.req = request<FAST>(packed, sv, S.qy);
+            S.req = request(packed, sv, S.qy, fast);
             S.qy += 4.0f;
             S.tq = tq + 4 * 4 * tw;
             S.o = o + 2;
@@ -451,21 +461,22 @@ struct GroupWalkC4 {
         *o = __builtin_fmaf(alpha, gradDis, oma * colDis);
         __builtin_amdgcn_sched_barrier(0);
     }
-    template <bool FAST>
-    __device__ __forceinline__ void body(gptr_bytes packed, int nr, const StripView &sv, Set &A, Set &B) const
+    __device__ __forceinline__ void body(gptr_bytes packed, int nr, const StripView &sv, Set &A, Set &B, bool fast) const
     {
+        int fi = __builtin_amdgcn_readfirstlane(fast ? 1 : 0);
         const int n_pairs = (nr - 2) >> 1;
         for (int r = 0; r < n_pairs; r++) {
-            step<FAST, false>(packed, sv, A);
-            step<FAST, false>(packed, sv, B);
+            asm volatile("" : "+s"(fi));
+            step<false>(packed, sv, A, fi != 0);
+            step<false>(packed, sv, B, fi != 0);
         }
         if (nr & 1) {
-            step<FAST, false>(packed, sv, A);
-            step<FAST, true>(packed, sv, B);
-            step<FAST, true>(packed, sv, A);
+            step<false>(packed, sv, A, fi != 0);
+            step<true>(packed, sv, B, false);
+            step<true>(packed, sv, A, false);
         } else {
-            step<FAST, true>(packed, sv, A);
-            step<FAST, true>(packed, sv, B);
+            step<true>(packed, sv, A, false);
+            step<true>(packed, sv, B, false);
         }
     }
 };
@@ -895,16 +906,10 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
             StripView sv;
             typename decltype(W)::Set SA, SB;
             bool fast = view_fast(hbuf);
-            if (fast)
-                W.template first<true>(view_base(0), hbuf, sv, SA, SB);
-            else
-                W.template first<false>(view_base(0), hbuf, sv, SA, SB);
+            W.first(view_base(0), hbuf, sv, SA, SB, fast);
             for (int v = 0; v < n; v++) {
                 // strips: dis of every sample column of the batch
-                if (fast)
-                    W.template body<true>(view_base(v), nr_b, sv, SA, SB);
-                else
-                    W.template body<false>(view_base(v), nr_b, sv, SA, SB);
+                W.body(view_base(v), nr_b, sv, SA, SB, fast);
                 __builtin_amdgcn_wave_barrier();
                 // the next view's first windows travel during the chains
                 if (v + 1 < n) {
@@ -914,10 +919,7 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
                     }
                     const float *hn = hbuf + ((v + 1) % kGrpViewsPerH) * (kGrpBatchGroups * 12);
                     fast = view_fast(hn);
-                    if (fast)
-                        W.template first<true>(view_base(v + 1), hn, sv, SA, SB);
-                    else
-                        W.template first<false>(view_base(v + 1), hn, sv, SA, SB);
+                    W.first(view_base(v + 1), hn, sv, SA, SB, fast);
                 }
                 // chains: the reference's summation order over each task's own window.  A window column's samples
                 // (and, byte form, its weights) are read while the column before is summed.

@@ -1,5 +1,5 @@
 #!/bin/sh
-# round 4: plane-keyed batches taken from both ends of the strip-length order (lane fill)
+# round 4: plane-keyed strips: one loop with a scalar branch on the reciprocal instead of two specialised loops (vmcnt waits)
 export GIPUMA_HIP_EXPERIMENTS=1
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r04l; mkdir -p $O
