@@ -67,7 +67,8 @@ constexpr int kGrpBatchStrips = 64;    // one strip per lane
 // box 15, 36 for box 11.  Box 25 has 169: two lanes per task, the first sums window columns 0..6 (91 weights) and hands
 // its partial sum to the second, which continues with columns 7..12 -- the reference's order.  (One lane with the weights
 // as byte indices into the table, four per register, costs a table read, a bit-field extract and an address per term:
-// 3 VALU + 1.5 LDS instructions instead of 1 + 0.5, on 31 % of the lanes.  -DPM_GROUP_TASK_LANES25=1 builds that.)
+// 3 VALU + 1.5 LDS instructions instead of 1 + 0.5, on 31 % of the lanes: the form batches of more than 32 tasks still
+// use, see group_costs.  -DPM_GROUP_TASK_LANES25=1 builds it for every batch.)
 #ifndef PM_GROUP_TASK_LANES
 #define PM_GROUP_TASK_LANES 1
 #endif
@@ -79,7 +80,7 @@ __host__ __device__ constexpr int group_task_lanes()
 {
     return BOX == 25 ? PM_GROUP_TASK_LANES25 : PM_GROUP_TASK_LANES;
 }
-constexpr int kGrpBatchGroups = 8;     // (a group has at least 6 strips)
+constexpr int kGrpBatchGroups = 8;     // (a group has at least N strips: 6 / 8 / 13 for boxes 11 / 15 / 25)
 // dis values of one view a wavefront's LDS slice holds: 64 strips of 16 (boxes 11, 15: three workgroups per CU) or of
 // 20 (box 25: two workgroups per CU) rows
 template <int BOX>
@@ -96,7 +97,7 @@ constexpr int kGrpViewsPerH = 4;       // homographies are prepared this many vi
 #define PM_GROUP_WG 3  // workgroups per CU the kernels are compiled for (3: 168 VGPRs)
 #endif
 #ifndef PM_GROUP_WG25
-#define PM_GROUP_WG25 2  // ... box 25 (43 registers of weight indices, 13 samples per chain column; 3: spills)
+#define PM_GROUP_WG25 2  // ... box 25 (91 chain weights per lane, 13 samples per chain column) and colour: 256 registers
 #endif
 template <int BOX, int CH = 1>
 __host__ __device__ constexpr int group_wg()
@@ -121,7 +122,7 @@ struct GroupLayout {  // offsets in 32-bit words into the dynamic LDS array
     static constexpr int max_cols = N + (kTileW - 1) / 2;       // strips per group: 8 + 15 = 23
     // sweep_read_state<.., PLANE_ONLY> stages the scalar plane of reference texels -- clamp-to-edge point samples --
     // right behind the weight table; the gradients are two subtractions per sample, the ones stage_tile does.
-    // Colour: the float4 {B, G, R, 0} tile of the sweep kernels, which the refinement stage of the fused kernel reads too.
+    // Colour: the float4 {B, G, R, 0} tile of the sweep kernels.
     static constexpr int plane = lut_size<CH>();            // [th][tw] (x CH)
     static constexpr int misc = plane + CH * tw * th;       // counters
     static constexpr int meta = misc + 128;                 // [2048] per group: first task | min lx << 11 | min ly << 16 | (ncols - N) << 20 | (nrows - N) << 24
