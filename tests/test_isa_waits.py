@@ -1,0 +1,79 @@
+"""Compile-time properties of the gfx950 code object that cost measurable time when they were violated (DESIGN.md 5,
+round 4) -- checked on the assembly hipcc emits, so no GPU is needed:
+
+  * the strip loop of the plane-keyed kernels keeps the other register set's window load in flight: the `vmcnt`
+    operands of its waits are 1 (gray: two loads per iteration) / 3 (colour: six), never 0.  With two specialised
+    copies of the loop the compiler drained both loads at the top of every iteration of one of them (config C +3.5 %);
+  * no `flat_*` memory instruction: the pointers held in the Problem block are global-address-space pointers
+    (DevPtr, pm_core.h), and a flat access counts on lgkmcnt as well as vmcnt.
+"""
+import hashlib
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "gipuma_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC"]
+
+
+@pytest.fixture(scope="module")
+def asm():
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".hip")))
+    key = hashlib.sha256(b"".join(open(os.path.join(CSRC, f), "rb").read() for f in srcs)).hexdigest()[:16]
+    out = os.path.join("/tmp", "gipuma_hip_%s.s" % key)  # (one compile per source state)
+    if not os.path.exists(out):
+        subprocess.run([HIPCC] + FLAGS + ["-S", "--offload-device-only", "-o", out, "gipuma_hip.hip"], cwd=CSRC,
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return open(out).read().split("\n")
+
+
+def kernel(asm, prefix):
+    start = next(i for i, l in enumerate(asm) if l.startswith(prefix) and ":" in l)
+    end = next(i for i in range(start, len(asm)) if "s_endpgm" in asm[i])
+    return asm[start:end]
+
+
+def loops(body):
+    label = {}
+    for i, l in enumerate(body):
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:
+            label[m.group(1)] = i
+    out = []
+    for i, l in enumerate(body):
+        m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(1) in label and label[m.group(1)] < i:
+            out.append((label[m.group(1)], i))
+    return out
+
+
+@pytest.mark.parametrize("prefix,loads,depth", [
+    ("_ZN2pm18sweep_group_kernelILi11ELi1E", 2, 1), ("_ZN2pm18sweep_group_kernelILi15ELi1E", 2, 1),
+    ("_ZN2pm18sweep_group_kernelILi25ELi1E", 2, 1), ("_ZN2pm12group_kernelILi15ELi1E", 2, 1),
+    ("_ZN2pm12group_kernelILi15ELi4E", 6, 3)])
+def test_strip_loop_keeps_a_window_load_in_flight(asm, prefix, loads, depth):
+    k = kernel(asm, prefix)
+    found = []
+    for a, b in loops(k):
+        body = k[a:b + 1]
+        n_loads = sum("global_load_dwordx4" in l for l in body)
+        # the strip loop: both reciprocals (one loop serves them), the window loads of its two register sets, and the
+        # dis values written to the wavefront's LDS buffer (which tells it from the refinement stage's loops)
+        if (n_loads == loads and any("v_div_scale" in l for l in body) and any("v_rcp_f32" in l for l in body) and
+                any("ds_write_b32" in l for l in body)):
+            waits = [int(re.search(r"vmcnt\((\d+)\)", l).group(1)) for l in body if "s_waitcnt" in l and "vmcnt" in l]
+            found.append((b - a, waits))
+    assert found, "strip loop not recognised in %s: update this test to the loop's new shape" % prefix
+    length, waits = max(found)  # (the whole iteration, not a sub-cycle of its branches)
+    assert len(waits) >= 2 and min(waits) >= depth, "strip loop of %s waits vmcnt%s" % (prefix, waits)
+
+
+def test_no_flat_memory_instruction(asm):
+    bad = [l.strip() for l in asm if re.match(r"\s+flat_(load|store|atomic)", l)]
+    assert not bad, "%d flat accesses, e.g. %s" % (len(bad), bad[:3])
