@@ -607,6 +607,31 @@ def main():
                     del os.environ["GIPUMA_HIP_EXPERIMENTS"]
                 else:
                     os.environ["GIPUMA_HIP_EXPERIMENTS"] = exp_before
+            # (a') GIPUMA_HIP_FLAG_FAST: the tolerance-judged flavour of the same kernels (include/gipuma_hip.h) on the same
+            #      frames, with its agreement with the exact mode's final maps of the timed solve -- the fraction of pixels
+            #      inside the north_star tolerance (depth 1e-4 relative, unit normal 1e-3), the way the reference's own
+            #      code is judged against the exact mode.  `value` stays the exact mode.
+            with Session(gs, fast=True) as sf:
+                sf.solve(timing=True)
+                tf = sf.solve(timing=True)
+                hs_fast, _ = sf.launch_times()
+                qf = quality_of(sf, info)
+                n4f, cf = sf.get_state()
+            n4e, ce = final_default
+            d_rel = np.abs(n4f[..., 3] - n4e[..., 3]) / np.maximum(np.abs(n4e[..., 3]), 1e-30)
+            n_err = np.abs(n4f[..., :3] - n4e[..., :3]).max(-1)
+            out["value_fast"] = {
+                "value": n_pix / (tf.ms_total * 1e-3) / 1e6, "unit": "Mpix/s", "ms_per_step": float(tf.ms_total),
+                "device_ms_init": float(tf.ms_init), "half_sweep_ms": [float(x) for x in hs_fast],
+                "parity_vs_exact_mode": {
+                    "frac_within_tolerance": float(((d_rel < 1e-4) & (n_err < 1e-3)).mean()),
+                    "frac_bit_identical_planes": float((n4f.view(np.uint32) == n4e.view(np.uint32)).all(-1).mean()),
+                    "tolerance": "depth 1e-4 relative, unit normal 1e-3 (BASELINE.json north_star)"},
+                "quality": qf,
+                "what": "same frames and schedule, session created with GIPUMA_HIP_FLAG_FAST: v_rcp_f32 without the Newton "
+                        "step, homography from host-folded per-view products, reassociated bilinear taps, tree sums "
+                        "(pm_core.h PM_APPROX); judged by tolerance, not bit-exact"}
+            del n4f, cf, n4e, ce, d_rel, n_err
             # (b) a scene with depth discontinuities, an occluder and sensor noise
             if args.scene == "smooth":
                 gs3, info3 = synth.build_problem(args.config, ref_view=ref_view, device=dev, keep_on_device=True,

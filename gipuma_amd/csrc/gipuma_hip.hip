@@ -11,10 +11,13 @@
 //   * no per-pixel RNG state array (48 B/pixel, gipuma.cu:1840): the RNG is counter based.  Per-pixel state of a
 //     session: 20 B planes + costs, 1 B history flag, and -- performance only, optional (the solve runs without
 //     them when the allocation fails) -- 32 B pushed propagation costs and 16-64 B prefilter sample lists.
-#include "../../include/gipuma_hip.h"
-#include "pm_device.h"
-#include "pm_push.h"
-#include "pm_group.h"
+//
+// This file is compiled TWICE into libgipuma_hip.so.  As itself it is the exact flavour (bit-identical to the CPU restatement of the numerical model) and
+// owns the exported C-ABI.  Included by gipuma_hip_fast.hip (GIPUMA_HIP_FAST_TU, PM_APPROX = 1, namespace pm -> pm_fast,
+// entry points renamed gipuma_hipf_*, hidden visibility) it is the tolerance-judged flavour behind
+// GIPUMA_HIP_FLAG_FAST: same host logic, same schedule, kernels with the approx arithmetic of pm_core.h.  A session
+// created with the flag is a thin wrapper whose calls this flavour forwards to the other one.
+#include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cmath>
@@ -26,7 +29,43 @@
 #include <new>
 #include <tuple>
 #include <string>
+#include <type_traits>
 #include <vector>
+
+#ifdef GIPUMA_HIP_FAST_TU
+#pragma GCC visibility push(hidden)
+#endif
+#include "../../include/gipuma_hip.h"
+#include "pm_device.h"
+#include "pm_push.h"
+#include "pm_group.h"
+
+#ifndef GIPUMA_HIP_FAST_TU
+// the tolerance-judged flavour of every session entry point (gipuma_hip_fast.hip)
+struct gipuma_hipf_session;
+typedef gipuma_hipf_session fast_session_t;
+extern "C" {
+#pragma GCC visibility push(hidden)
+const char *gipuma_hipf_last_error(void);
+int gipuma_hipf_cache_clear(void);
+int gipuma_hipf_create(const gipuma_hip_desc *desc, gipuma_hipf_session **out);
+int gipuma_hipf_destroy(gipuma_hipf_session *s);
+int gipuma_hipf_init_planes(gipuma_hipf_session *s);
+int gipuma_hipf_sweep(gipuma_hipf_session *s, int iteration, int colour, unsigned stages);
+int gipuma_hipf_finalize(gipuma_hipf_session *s);
+int gipuma_hipf_eval_cost(gipuma_hipf_session *s, const float *planes_host, float *cost_out_host);
+int gipuma_hipf_get_state(gipuma_hipf_session *s, float *norm4_host, float *cost_host);
+int gipuma_hipf_set_state(gipuma_hipf_session *s, const float *norm4_host, const float *cost_host);
+int gipuma_hipf_state_device_ptrs(gipuma_hipf_session *s, float **norm4_dev, float **cost_dev);
+int gipuma_hipf_solve(gipuma_hipf_session *s, gipuma_hip_timing *timing);
+int gipuma_hipf_launch_times(gipuma_hipf_session *s, float *ms_half_sweep, int capacity, int *n_half_sweeps, int *n_pushed);
+int gipuma_hipf_group_times(gipuma_hipf_session *s, float *ms_group, int capacity, int *n_half_sweeps);
+int gipuma_hipf_schedule(gipuma_hipf_session *s, int info[4]);
+#pragma GCC visibility pop
+}
+#else
+typedef void fast_session_t;
+#endif
 
 namespace {
 
@@ -69,9 +108,26 @@ const char *exp_env(const char *name)
         if (e_ != hipSuccess) return fail(GIPUMA_HIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+#ifndef GIPUMA_HIP_FAST_TU
+// forward a call on a GIPUMA_HIP_FLAG_FAST session to its flavour; a failure's text becomes this thread's last error
+#define FORWARD_FAST(s, call)                                   \
+    do {                                                        \
+        if ((s) && (s)->fast) {                                 \
+            const int rc_ = (call);                             \
+            if (rc_) g_err = gipuma_hipf_last_error();          \
+            return rc_;                                         \
+        }                                                       \
+    } while (0)
+#else
+#define FORWARD_FAST(s, call) do { } while (0)
+#endif
+
 }  // namespace
 
 struct gipuma_hip_session {
+    // non-null: this object is only the handle of a GIPUMA_HIP_FLAG_FAST session that lives in the other flavour of this
+    // file; every entry point forwards to it and nothing below is used
+    fast_session_t *fast = nullptr;
     int device = 0;
     int rows = 0, cols = 0, n_sel = 0, iterations = 0;
     pm::Problem hp{};
@@ -436,6 +492,12 @@ int gipuma_hip_device_count(void)
 
 int gipuma_hip_cache_clear(void)
 {
+#ifndef GIPUMA_HIP_FAST_TU
+    if (const int rc = gipuma_hipf_cache_clear()) {  // (the other flavour keeps its own packed planes)
+        g_err = gipuma_hipf_last_error();
+        return rc;
+    }
+#endif
     std::lock_guard<std::mutex> lock(g_cache_mutex);
     for (auto &kv : g_cache)
         if (kv.second.users > 0)
@@ -482,6 +544,18 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         return fail(GIPUMA_HIP_ERR_ARG, "device_id out of range");
     gipuma_hip_session *s = new (std::nothrow) gipuma_hip_session;
     if (!s) return fail(GIPUMA_HIP_ERR_DEVICE, "out of host memory");
+#ifndef GIPUMA_HIP_FAST_TU
+    if (d->flags & GIPUMA_HIP_FLAG_FAST) {  // the tolerance-judged flavour: this object is only its handle
+        rc = gipuma_hipf_create(d, &s->fast);
+        if (rc) {
+            g_err = gipuma_hipf_last_error();
+            delete s;
+            return rc;
+        }
+        *out = s;
+        return 0;
+    }
+#endif
     // from here on, destroy() cleans up whatever was built.  The image cache is locked while this call looks at /
     // adds entries; a failure inside that region first takes back the packed planes this call put into the cache
     // (never verified), then UNLOCKS -- destroy() takes the same non-recursive mutex to give the use counts back.
@@ -662,6 +736,18 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         copy9(hp.view[i].K, c.K);
         copy9(hp.view[i].R, c.R);
         copy3(hp.view[i].t, c.t);
+#if PM_APPROX && defined(PM_APPROX_HFOLD)
+        // A = K R K_ref^-1, u = K t (homography(), approx flavour), formed in double
+        double KR[9];
+        for (int r = 0; r < 3; r++)
+            for (int q = 0; q < 3; q++)
+                KR[3 * r + q] = (double)c.K[3 * r] * c.R[q] + (double)c.K[3 * r + 1] * c.R[3 + q] + (double)c.K[3 * r + 2] * c.R[6 + q];
+        for (int r = 0; r < 3; r++) {
+            for (int q = 0; q < 3; q++)
+                hp.view[i].A[3 * r + q] = (float)(KR[3 * r] * c0.K_inv[q] + KR[3 * r + 1] * c0.K_inv[3 + q] + KR[3 * r + 2] * c0.K_inv[6 + q]);
+            hp.view[i].u[r] = (float)((double)c.K[3 * r] * c.t[0] + (double)c.K[3 * r + 1] * c.t[1] + (double)c.K[3 * r + 2] * c.t[2]);
+        }
+#endif
     }
     {
         const size_t tiles = (size_t)((d->cols + pm::kTileW - 1) / pm::kTileW) *
@@ -834,6 +920,13 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
 int gipuma_hip_destroy(gipuma_hip_session *s)
 {
     if (!s) return 0;
+#ifndef GIPUMA_HIP_FAST_TU
+    if (s->fast) {
+        const int rc = gipuma_hipf_destroy(s->fast);
+        delete s;
+        return rc;
+    }
+#endif
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (!s->cache_refs.empty()) {
@@ -869,6 +962,7 @@ int gipuma_hip_destroy(gipuma_hip_session *s)
 
 int gipuma_hip_init_planes(gipuma_hip_session *s)
 {
+    FORWARD_FAST(s, gipuma_hipf_init_planes(s->fast));
     if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
     HIP_OK(hipSetDevice(s->device));
     // (a fresh solve starts with fresh hints, so that repeated solves of a session do the same work)
@@ -886,6 +980,7 @@ int gipuma_hip_init_planes(gipuma_hip_session *s)
 
 int gipuma_hip_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stages)
 {
+    FORWARD_FAST(s, gipuma_hipf_sweep(s->fast, iteration, colour, stages));
     if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
     if (iteration < 0 || (colour != GIPUMA_BLACK && colour != GIPUMA_RED) || (stages & ~7u))
         return fail(GIPUMA_HIP_ERR_ARG, "bad iteration/colour/stages");
@@ -906,6 +1001,7 @@ int gipuma_hip_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned 
 
 int gipuma_hip_finalize(gipuma_hip_session *s)
 {
+    FORWARD_FAST(s, gipuma_hipf_finalize(s->fast));
     if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
     HIP_OK(hipSetDevice(s->device));
     const int n = s->rows * s->cols;
@@ -922,6 +1018,7 @@ int gipuma_hip_finalize(gipuma_hip_session *s)
 
 int gipuma_hip_eval_cost(gipuma_hip_session *s, const float *planes_host, float *cost_out_host)
 {
+    FORWARD_FAST(s, gipuma_hipf_eval_cost(s->fast, planes_host, cost_out_host));
     if (!s || !planes_host || !cost_out_host) return fail(GIPUMA_HIP_ERR_ARG, "null argument");
     HIP_OK(hipSetDevice(s->device));
     const size_t np = (size_t)s->rows * (size_t)s->cols;
@@ -947,6 +1044,7 @@ int gipuma_hip_eval_cost(gipuma_hip_session *s, const float *planes_host, float 
 
 int gipuma_hip_get_state(gipuma_hip_session *s, float *norm4_host, float *cost_host)
 {
+    FORWARD_FAST(s, gipuma_hipf_get_state(s->fast, norm4_host, cost_host));
     if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
     HIP_OK(hipSetDevice(s->device));
     const size_t np = (size_t)s->rows * (size_t)s->cols;
@@ -960,6 +1058,7 @@ int gipuma_hip_get_state(gipuma_hip_session *s, float *norm4_host, float *cost_h
 
 int gipuma_hip_set_state(gipuma_hip_session *s, const float *norm4_host, const float *cost_host)
 {
+    FORWARD_FAST(s, gipuma_hipf_set_state(s->fast, norm4_host, cost_host));
     if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
     HIP_OK(hipSetDevice(s->device));
     const size_t np = (size_t)s->rows * (size_t)s->cols;
@@ -978,6 +1077,7 @@ int gipuma_hip_set_state(gipuma_hip_session *s, const float *norm4_host, const f
 
 int gipuma_hip_state_device_ptrs(gipuma_hip_session *s, float **norm4_dev, float **cost_dev)
 {
+    FORWARD_FAST(s, gipuma_hipf_state_device_ptrs(s->fast, norm4_dev, cost_dev));
     if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
     if (norm4_dev) *norm4_dev = (float *)s->norm4;
     if (cost_dev) *cost_dev = s->cost;
@@ -986,6 +1086,7 @@ int gipuma_hip_state_device_ptrs(gipuma_hip_session *s, float **norm4_dev, float
 
 int gipuma_hip_solve(gipuma_hip_session *s, gipuma_hip_timing *timing)
 {
+    FORWARD_FAST(s, gipuma_hipf_solve(s->fast, timing));
     if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
     HIP_OK(hipSetDevice(s->device));
     int rc;
@@ -1077,6 +1178,7 @@ int gipuma_hip_solve(gipuma_hip_session *s, gipuma_hip_timing *timing)
 
 int gipuma_hip_launch_times(gipuma_hip_session *s, float *ms_half_sweep, int capacity, int *n_half_sweeps, int *n_pushed)
 {
+    FORWARD_FAST(s, gipuma_hipf_launch_times(s->fast, ms_half_sweep, capacity, n_half_sweeps, n_pushed));
     if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
     const int n = (int)s->half_sweep_ms.size();
     if (ms_half_sweep)
@@ -1088,6 +1190,7 @@ int gipuma_hip_launch_times(gipuma_hip_session *s, float *ms_half_sweep, int cap
 
 int gipuma_hip_schedule(gipuma_hip_session *s, int info[4])
 {
+    FORWARD_FAST(s, gipuma_hipf_schedule(s->fast, info));
     if (!s || !info) return fail(GIPUMA_HIP_ERR_ARG, "null argument");
     info[0] = s->push_ok ? s->push_launches : 0;
     info[1] = s->group_ok ? s->group_from : -1;
@@ -1100,6 +1203,7 @@ int gipuma_hip_schedule(gipuma_hip_session *s, int info[4])
 
 int gipuma_hip_group_times(gipuma_hip_session *s, float *ms_group, int capacity, int *n_half_sweeps)
 {
+    FORWARD_FAST(s, gipuma_hipf_group_times(s->fast, ms_group, capacity, n_half_sweeps));
     if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
     const int n = (int)s->group_ms.size();
     if (ms_group)
@@ -1124,3 +1228,7 @@ int gipuma_hip_run(const gipuma_hip_desc *desc, float *norm4_out, float *cost_ou
 }
 
 }  // extern "C"
+
+#ifdef GIPUMA_HIP_FAST_TU
+#pragma GCC visibility pop
+#endif

@@ -5,6 +5,26 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// PM_APPROX = 1 builds the TOLERANCE-JUDGED flavour of every kernel (GIPUMA_HIP_FLAG_FAST, gipuma_hip_fast.hip): the
+// same algorithm, schedule, memory layout and random numbers, with arithmetic shortcuts of the kind the reference takes by
+// being built with --use_fast_math (CMakeLists.txt:23).  What it may contain is bounded by its parity floor -- at least
+// the agreement the reference's own code has with the exact flavour (measured per ingredient on an MI355X:
+// profiles/r05_fast_mode_ingredients.txt):
+//   * v_rcp_f32 without the correcting Newton step for 1/z of the warped point (1 ulp instead of correctly rounded);
+//   * no proof that the window's denominators are in the range where that reciprocal is exact -- one instantiation of
+//     every sample loop instead of two;
+//   * the nine divisions by the plane offset in getHomography_cu as one reciprocal + a Markstein correction each (the
+//     bits of the IEEE quotient on every operand pair tried; unproven, hence not in the exact flavour).
+// Measured and rejected (compile options for A/B builds only): -DPM_APPROX_HFOLD, the homography from host-folded per-view
+// products (22 instead of ~200 instructions, but its rounding moves a whole window coherently by ~1e-4 px: 0.5 % of
+// config C's and 7.6 % of config B's pixels leave the tolerance); -DPM_APPROX_TREE_SUM, butterfly sums instead of the
+// column-per-lane kernels' relay (no time gained, 4 % of a 320x256 frame lost: the early half-sweeps decide trajectories).
+// Its results are NOT bit-identical to the exact flavour's; they are judged like the reference's own code is (fraction of
+// pixels inside 1e-4 / 1e-3, tests/test_fast_mode.py).  PM_APPROX = 0 (default) is the exact flavour.
+#ifndef PM_APPROX
+#define PM_APPROX 0
+#endif
+
 namespace pm {
 
 
@@ -45,6 +65,9 @@ struct RefCam {  // Camera_cu of view 0, camera.h:7-62
 struct ViewCam {  // Camera_cu of a selected source view + its image plane
     float K[9], R[9], t[3];
     int pad;
+#if PM_APPROX && defined(PM_APPROX_HFOLD)
+    float A[9], u[3];  // K R K_ref^-1 and K t, formed once per view on the host in double (homography(), approx flavour)
+#endif
     DevPtr<const float> img;        // float plane (row-major, Problem::pitch)
     DevPtr<const uint32_t> packed;  // window-packed u8 copy (see pack_kernel), or nullptr
 };
@@ -214,16 +237,57 @@ __device__ __forceinline__ float depth_from_plane(const RefCam &rc, float4 pl, i
 // disparityDepthConversion_cu, gipuma.cu:66-68
 __device__ __forceinline__ float disp_depth(float f, float baseline, float d) { return f * baseline / d; }
 
+// v_rcp_f32 + one Newton step: the correctly rounded 1 / z for every z with biased exponent 1..252 (see rcp_newton below,
+// which is this function in the exact flavour)
+__device__ __forceinline__ float rcp_correct(float z)
+{
+    const float r = __builtin_amdgcn_rcpf(z);
+    const float e = __builtin_fmaf(-z, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
 // getHomography_cu, gipuma.cu:339-356:  H = K_to * ((R_to - t_to n^T / d) * K_ref^-1).
 // K, R, t, K_inv are wave-uniform (SGPR operands); n, d are per lane.
 __device__ __forceinline__ void homography(const float *Kinv_ref, const ViewCam &to, float4 pl, float *H)
 {
+#if PM_APPROX && defined(PM_APPROX_HFOLD)
+    // (measured and NOT the default, DESIGN.md 3a: the same matrix with the per-view factors folded on the host,
+    //  H = A - u m^T, A = K R K_ref^-1, u = K t, m = K_ref^-T n / d -- 22 instead of 270 instructions, and no less accurate
+    //  than the literal order against the true matrix, but its rounding differs from the literal order's by ~1e-4 px
+    //  COHERENTLY over a whole window, which flips 10-100x more near-ties than per-sample rounding noise does)
+    const float rd = __builtin_amdgcn_rcpf(pl.w);
+    float m[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+        m[c] = __builtin_fmaf(pl.z, Kinv_ref[c + 6], __builtin_fmaf(pl.y, Kinv_ref[c + 3], pl.x * Kinv_ref[c])) * rd;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) H[3 * r + c] = __builtin_fmaf(-to.u[r], m[c], to.A[3 * r + c]);
+    return;
+#endif
     float a[9], b[9];
     const float n[3] = {pl.x, pl.y, pl.z};
+#if PM_APPROX
+    // the literal order with the nine IEEE divisions by the plane offset replaced by ONE correctly rounded reciprocal and
+    // a Markstein correction per quotient (q0 = x r, q = q0 + (x - d q0) r): 4 instead of ~10 instructions each, and the
+    // bits of x / d wherever nothing under- or overflows (scripts/exp/div_shared_denominator.c: 4.3e9 operand pairs
+    // without a difference; the exact flavour does not use it because the proof for every operand pair is owed).  The
+    // matrix, and with it the position of every window, then equals the exact flavour's.
+    const float rdw = rcp_correct(pl.w);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float x = to.t[r] * n[c];
+            const float q0 = x * rdw;
+            a[3 * r + c] = to.R[3 * r + c] - __builtin_fmaf(__builtin_fmaf(-pl.w, q0, x), rdw, q0);
+        }
+#else
 #pragma unroll
     for (int r = 0; r < 3; r++)
 #pragma unroll
         for (int c = 0; c < 3; c++) a[3 * r + c] = to.R[3 * r + c] - (to.t[r] * n[c]) / pl.w;
+#endif
 #pragma unroll
     for (int r = 0; r < 3; r++)
 #pragma unroll
@@ -437,6 +501,9 @@ __global__ __launch_bounds__(kThreads) void check_u8_kernel(const float *__restr
 // only after proving the whole window stays inside a (much narrower) safe range.
 __device__ __forceinline__ float rcp_newton(float z)
 {
+#if PM_APPROX && !defined(PM_APPROX_KEEP_NEWTON)  // (-DPM_APPROX_KEEP_NEWTON: A/B builds, +0.5 % time)
+    return __builtin_amdgcn_rcpf(z);  // 1 ulp; no correction step
+#endif
     const float r = __builtin_amdgcn_rcpf(z);
     const float e = __builtin_fmaf(-z, r, 1.0f);
     return __builtin_fmaf(e, r, r);
@@ -444,6 +511,9 @@ __device__ __forceinline__ float rcp_newton(float z)
 template <bool FAST>
 __device__ __forceinline__ float recip(float z)
 {
+#if PM_APPROX
+    return rcp_newton(z);
+#endif
     return FAST ? rcp_newton(z) : 1.0f / z;
 }
 // counts inputs in [lo_exp, hi_exp] (biased exponents) where rcp_newton != 1.0f/z
@@ -487,14 +557,15 @@ __device__ __forceinline__ Taps taps12(float a, float b, float t01, float t02, f
                                        float t13, float t20, float t21, float t22, float t23, float t31,
                                        float t32)
 {
-    const float C0 = lerp(a, t01, t02);
-    const float L1 = lerp(a, t10, t11), C1 = lerp(a, t11, t12), R1 = lerp(a, t12, t13);
-    const float L2 = lerp(a, t20, t21), C2 = lerp(a, t21, t22), R2 = lerp(a, t22, t23);
-    const float C3 = lerp(a, t31, t32);
+    // Columns interpolated along y first, the +-1 differences taken on the texels BEFORE the interpolation (bilinear
+    // interpolation is linear in the texels): 24 operations where five separate taps take 28.  This order IS the
+    // numerical model's (M1; the CPU restatement computes the same expressions).
+    const float V0 = lerp(b, t10, t20), V1 = lerp(b, t11, t21), V2 = lerp(b, t12, t22), V3 = lerp(b, t13, t23);
+    const float W1 = lerp(b, t21 - t01, t31 - t11), W2 = lerp(b, t22 - t02, t32 - t12);
     Taps o;
-    o.sc = lerp(b, C1, C2);
-    o.gx2 = lerp(b, R1, R2) - lerp(b, L1, L2);
-    o.gy2 = lerp(b, C2, C3) - lerp(b, C0, C1);
+    o.sc = lerp(a, V1, V2);
+    o.gx2 = lerp(a, V2 - V0, V3 - V1);
+    o.gy2 = lerp(a, W1, W2);
     return o;
 }
 // window words w0..w3 = columns X..X+3, byte r = row Y+r

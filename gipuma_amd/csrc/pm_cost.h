@@ -14,6 +14,9 @@ namespace pm {
 // so all window values lie between the four corner values.
 __device__ __forceinline__ bool window_z_safe(const float *H, float qx0, float qx1, float qy0, float qy1)
 {
+#if PM_APPROX
+    return true;  // (the approx flavour's reciprocal is v_rcp_f32 everywhere: nothing to prove)
+#endif
     const float z00 = __builtin_fmaf(H[7], qy0, __builtin_fmaf(H[6], qx0, H[8]));
     const float z01 = __builtin_fmaf(H[7], qy1, __builtin_fmaf(H[6], qx0, H[8]));
     const float z10 = __builtin_fmaf(H[7], qy0, __builtin_fmaf(H[6], qx1, H[8]));
@@ -621,6 +624,26 @@ __host__ __device__ constexpr int col_tasks()  // pairs evaluated concurrently b
     return kThreads / col_group<BOX>();
 }
 
+#if PM_APPROX && defined(PM_APPROX_TREE_SUM)
+// (A/B builds) instead of the relay below: every lane sums its own window column, the columns of a group are added by a
+// butterfly over the group's lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror): log2(G) DPP adds instead of
+// N relay steps of N fmaf each; every lane of the group ends with the total
+template <int BOX>
+__device__ __forceinline__ float cols_tree_sum(const float *wgt, const float *dis, int col)
+{
+    constexpr int N = (BOX + 1) / 2, G = col_group<BOX>();
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < N; k++) acc = __builtin_fmaf(wgt[k], dis[k], acc);
+    if (col >= N) acc = 0.0f;  // spare lanes shadow the last column
+    acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x141, 0xf, 0xf, false));  // row_half_mirror
+    if (G == 16) acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x140, 0xf, 0xf, false));  // row_mirror
+    return acc;
+}
+#endif
+
 template <int BOX, bool FAST>
 __device__ __forceinline__ float view_cost_cols(const Problem *__restrict__ P, const ViewCam &vc,
                                                 const float *__restrict__ H, const float *__restrict__ tp0,
@@ -685,6 +708,9 @@ __device__ __forceinline__ float view_cost_cols(const Problem *__restrict__ P, c
         const float colDis = min_abs_nc(colDiff, tau_color);
         dis[k] = __builtin_fmaf(alpha16, gradDis, oma * colDis);
     }
+#if PM_APPROX && defined(PM_APPROX_TREE_SUM)  // (A/B builds only: measured, no gain, costs agreement)
+    return cols_tree_sum<BOX>(wgt, dis, col);
+#endif
     // relay: after step c, lane c of the group holds the sum over columns 0..c in reference order
     float out = 0.0f;
 #pragma unroll
@@ -782,6 +808,9 @@ __device__ __forceinline__ float view_cost_cols_c4(const Problem *__restrict__ P
         const float colDis = min_nc(colDiff, tau_color);
         dis[k] = __builtin_fmaf(alpha16, gradDis, oma * colDis);
     }
+#if PM_APPROX && defined(PM_APPROX_TREE_SUM)  // (A/B builds only: measured, no gain, costs agreement)
+    return cols_tree_sum<BOX>(wgt, dis, col);
+#endif
     // relay: after step c, lane c of the group holds the sum over columns 0..c in reference order
     float out = 0.0f;
 #pragma unroll

@@ -245,10 +245,15 @@ struct GroupWalk {
         const float Y = __builtin_fmaf(s.H4, qy, s.Y0);
         const float Z = __builtin_fmaf(s.H7, qy, s.Z0);
         float rz;
+#if PM_APPROX
+        rz = rcp_newton(Z);
+        (void)fast;
+#else
         if (fast)
             rz = rcp_newton(Z);
         else
             rz = 1.0f / Z;
+#endif
         const float sx = X * rz, sy = Y * rz;
         const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
         WinReq r;
@@ -326,7 +331,9 @@ struct GroupWalk {
         int fi = __builtin_amdgcn_readfirstlane(fast ? 1 : 0);
         const int n_pairs = (nr - 2) >> 1;  // pairs of rows both of which request (rows r, r + 1 with r + 3 < nr)
         for (int r = 0; r < n_pairs; r++) {
+#if !PM_APPROX  // (the approx flavour has one reciprocal: nothing to unswitch)
             asm volatile("" : "+s"(fi));  // (opaque per iteration: the loop is not to be unswitched into two)
+#endif
             step<false>(magic_base, sv, A, fi != 0);
             step<false>(magic_base, sv, B, fi != 0);
         }
@@ -397,10 +404,15 @@ struct GroupWalkC4 {
         const float Y = __builtin_fmaf(s.H4, qy, s.Y0);
         const float Z = __builtin_fmaf(s.H7, qy, s.Z0);
         float rz;
+#if PM_APPROX
+        rz = rcp_newton(Z);
+        (void)fast;
+#else
         if (fast)
             rz = rcp_newton(Z);
         else
             rz = 1.0f / Z;
+#endif
         const float sx = X * rz, sy = Y * rz;
         const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
         Req r;
@@ -467,7 +479,9 @@ struct GroupWalkC4 {
         int fi = __builtin_amdgcn_readfirstlane(fast ? 1 : 0);
         const int n_pairs = (nr - 2) >> 1;
         for (int r = 0; r < n_pairs; r++) {
+#if !PM_APPROX
             asm volatile("" : "+s"(fi));
+#endif
             step<false>(packed, sv, A, fi != 0);
             step<false>(packed, sv, B, fi != 0);
         }

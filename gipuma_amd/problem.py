@@ -188,16 +188,34 @@ def _fptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
-def runcuda(gs, timing=False):
+class _mode:
+    """`with _mode(gs, fast)`: the descriptor carries GIPUMA_HIP_FLAG_FAST for the calls inside (the library reads the
+    flags when it creates the session)"""
+
+    def __init__(self, gs, fast):
+        self.gs, self.fast = gs, fast
+
+    def __enter__(self):
+        self.keep = self.gs.desc.flags
+        if self.fast:
+            self.gs.desc.flags = self.keep | abi.FLAG_FAST
+
+    def __exit__(self, *a):
+        self.gs.desc.flags = self.keep
+
+
+def runcuda(gs, timing=False, fast=False):
     """The reference's ``int runcuda(GlobalState&)`` (gipuma.h:2) on the HIP path.
 
     Returns (norm4, cost[, Timing]): norm4[y, x] = (n_world.xyz, depth), cost[y, x], as the
-    reference leaves them in gs.lines (gipuma.cu:1080-1103, main.cpp:976-985)."""
+    reference leaves them in gs.lines (gipuma.cu:1080-1103, main.cpp:976-985).  `fast`: the tolerance-judged
+    flavour of the kernels (GIPUMA_HIP_FLAG_FAST) instead of the bit-exact one."""
     lib = abi.load_library()
     norm4 = np.empty((gs.rows, gs.cols, 4), dtype=np.float32)
     cost = np.empty((gs.rows, gs.cols), dtype=np.float32)
     t = abi.Timing()
-    rc = lib.gipuma_hip_run(C.byref(gs.desc), _fptr(norm4), _fptr(cost), C.byref(t))
+    with _mode(gs, fast):
+        rc = lib.gipuma_hip_run(C.byref(gs.desc), _fptr(norm4), _fptr(cost), C.byref(t))
     abi.check(lib, rc, "gipuma_hip_run")
     return (norm4, cost, t) if timing else (norm4, cost)
 
@@ -206,12 +224,14 @@ class Session:
     """One reference view resident on the GPU: the launches of gipuma<T>() (gipuma.cu:1825-1960)
     one call at a time."""
 
-    def __init__(self, gs):
+    def __init__(self, gs, fast=False):
         self.lib = abi.load_library()
         self.gs = gs
+        self.fast = fast
         self.h = C.c_void_p()
-        abi.check(self.lib, self.lib.gipuma_hip_create(C.byref(gs.desc), C.byref(self.h)),
-                  "gipuma_hip_create")
+        with _mode(gs, fast):
+            rc = self.lib.gipuma_hip_create(C.byref(gs.desc), C.byref(self.h))
+        abi.check(self.lib, rc, "gipuma_hip_create")
 
     def close(self):
         if self.h:

@@ -99,6 +99,14 @@ typedef struct gipuma_hip_params {
  * views (the reference re-uploads every image for every view, main.cpp:960-968).  The caller promises not
  * to change or free those planes before gipuma_hip_cache_clear(). */
 #define GIPUMA_HIP_FLAG_CACHE_IMAGES 4u
+/* Mode flag (SURVEY.md 8b "mode flags (bit-exact/fast)"): without it every result is bit-identical to the CPU oracle of
+ * the stated numerical model.  With it the session runs the TOLERANCE-JUDGED flavour of the same kernels --
+ * the operation-order freedoms the reference takes by being built with --use_fast_math (CMakeLists.txt:23): hardware
+ * reciprocal without the correcting step, the homography of getHomography_cu (gipuma.cu:339-356) from per-view products
+ * folded on the host, reassociated bilinear taps, tree sums.  Same algorithm, schedule and random numbers; results agree
+ * with the exact mode's like the reference's own code does (fraction of pixels inside 1e-4 relative depth / 1e-3 normal:
+ * tests/test_fast_mode.py), not bit for bit. */
+#define GIPUMA_HIP_FLAG_FAST 8u
 
 /* Everything runcuda() reads out of GlobalState (globalstate.h:24-45). */
 typedef struct gipuma_hip_desc {

@@ -13,7 +13,11 @@
  *       weights.  gfx950 has no texture unit; the model is an exact fp32 lerp
  *       t0 + a*(t1-t0) (one fmaf) of the texels floor(x), floor(x)+1 with clamp-to-edge
  *       texel addressing, a = x - floor(x).  The +-1 gradient taps (gipuma.cu:251-252) reuse
- *       the centre tap's a/b and move the texel window by whole texels.
+ *       the centre tap's a/b and move the texel window by whole texels; since round 5 the two
+ *       gradient differences are taken on the texels BEFORE the interpolation (bilinear
+ *       interpolation is linear in the texels) and columns are interpolated along y first:
+ *       go_taps3_s() below -- 24 instead of 28 operations per sample on the GPU.  Measured against
+ *       the reference's own code, which of these orders is used does not matter (flavours below).
  *   M2  expf / rsqrtf / division are approximate in the reference build (--use_fast_math,
  *       CMakeLists.txt:23).  Model: exp is go_exp() below (Cephes-style, ~1 ulp), rsqrtf(x) is
  *       1/sqrtf(x), x/z and y/z of the warped point are x*(1/z), y*(1/z) with an IEEE 1/z.
@@ -291,6 +295,37 @@ void gipuma_oracle_sample5(const float *img, int rows, int cols, int pitch, floa
     go_sample5(img, rows, cols, pitch, x, y, out);
 }
 
+/* The taps as the cost functions use them (model M1, the kernels' taps12 in pm_core.h): out = { centre value,
+ * I(x+1, y) - I(x-1, y), I(x, y+1) - I(x, y-1) } of the bilinear image at (x, y), from the same 4x4 texel window as
+ * go_sample5_s (t[r][c]: row iy-1+r, column ix-1+c; the corners are not read), columns interpolated along y first and the
+ * two differences taken on the texels:
+ *     V_c = lerp(b, t[1][c], t[2][c])  c = 0..3        W_c = lerp(b, t[2][c] - t[0][c], t[3][c] - t[1][c])  c = 1, 2
+ *     centre = lerp(a, V_1, V_2)     d/dx = lerp(a, V_2 - V_0, V_3 - V_1)     d/dy = lerp(a, W_1, W_2)
+ * In exact arithmetic these are out[0], out[1] - out[2] and out[3] - out[4] of go_sample5_s. */
+static inline void go_taps3_s(const float *img, int rows, int cols, int pitch, int stride, float x, float y,
+                              float out[3])
+{
+    const float fx0 = floorf(x), fy0 = floorf(y);
+    const float a = x - fx0, b = y - fy0;
+    const int ix = (int)fminf(fmaxf(fx0, -2.0f), (float)cols);
+    const int iy = (int)fminf(fmaxf(fy0, -2.0f), (float)rows);
+    float t[4][4];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) t[r][c] = go_texel_s(img, rows, cols, pitch, stride, ix - 1 + c, iy - 1 + r);
+    const float V0 = go_lerp(b, t[1][0], t[2][0]), V1 = go_lerp(b, t[1][1], t[2][1]);
+    const float V2 = go_lerp(b, t[1][2], t[2][2]), V3 = go_lerp(b, t[1][3], t[2][3]);
+    const float W1 = go_lerp(b, t[2][1] - t[0][1], t[3][1] - t[1][1]);
+    const float W2 = go_lerp(b, t[2][2] - t[0][2], t[3][2] - t[1][2]);
+    out[0] = go_lerp(a, V1, V2);
+    out[1] = go_lerp(a, V2 - V0, V3 - V1);
+    out[2] = go_lerp(a, W1, W2);
+}
+
+void gipuma_oracle_taps3(const float *img, int rows, int cols, int pitch, float x, float y, float out[3])
+{
+    go_taps3_s(img, rows, cols, pitch, 1, x, y, out);
+}
+
 /* ------------------------------------------------------------------------------------------
  * patch cost of one view: pmCost_shared + pmCostComputation_shared, gipuma.cu:585-680, 223-277
  * (pmCost/pmCostComputation, :455-518/:278-320, used by the init kernel, are the same function
@@ -321,10 +356,10 @@ static inline float go_dis_at(const gipuma_hip_desc *d, int view, const float *H
     const float rz = 1.0f / Z;
     const float sx = X * rz, sy = Y * rz;
     /* pmCostComputation_shared, gipuma.cu:251-274 */
-    float s[5];
-    go_sample5(src, rows, cols, pitch, sx, sy, s);
-    const float gx2 = s[1] - s[2];
-    const float gy2 = s[3] - s[4];
+    float s[3];
+    go_taps3_s(src, rows, cols, pitch, 1, sx, sy, s);
+    const float gx2 = s[1];
+    const float gy2 = s[2];
     const float colDiff = fabsf(leftValue - s[0]);
     const float up = go_texel(ref, rows, cols, pitch, ix, iy - 1);
     const float down = go_texel(ref, rows, cols, pitch, ix, iy + 1);
@@ -362,6 +397,121 @@ static float go_view_cost(const gipuma_hip_desc *d, int view, int px, int py, co
             const float w = go_exp(-colorDis / gamma);
             const float dis = go_dis_at(d, view, H, ix, iy, leftValue);
             cost = fmaf(w, dis, cost);
+        }
+    }
+    return cost;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * LITERAL flavours of the gray patch cost.
+ * The numerical model M1-M3 above is ONE choice among the orderings the reference's source leaves to
+ * nvcc and the texture unit.  These switches replace one model choice at a time by the literal
+ * operation order of the reference's source as g++ compiles it in oracle/_ref (no contraction,
+ * IEEE division, one tex2D call per tap), so that the cause of every oracle <-> _ref difference can
+ * be named (scripts/ref_vs_oracle_fraction.py --flavour, tests/test_oracle_vs_ref.py):
+ *   GO_LIT_TAPS (1)  M1 -> every one of the five taps of gipuma.cu:251-253 is its own bilinear
+ *                    fetch at the coordinates the source writes, (pt.x +- 1 + 0.5f, pt.y + 0.5f),
+ *                    with xB = x - 0.5f, i = floor(xB), a = xB - i recomputed per tap: the +-1 taps'
+ *                    fractions differ from the centre's in the last bits (two roundings each);
+ *   GO_LIT_DIV  (2)  M2 -> x / z and y / z as IEEE divisions (vecdiv4, config.h:44-47);
+ *   GO_LIT_FMA  (4)  M3 -> H*(x,y,1) as m0*x + m1*y + m2 (matvecmul4noz, config.h:150-162),
+ *                    dis = (1-alpha)*colDis + alpha*gradDis (gipuma.cu:272), cost = cost + w*dis
+ *                    (:274, :672), all unfused.
+ * Flavour 7 is the reference's own source order; 0 is the model the kernels implement.  The
+ * bilinear lerp itself (fmaf(a, t1 - t0, t0), exact fp32 weights) is the shim's stand-in for the
+ * texture unit in both and is not part of the switch.  Gray only.
+ * ---------------------------------------------------------------------------------------- */
+#define GO_LIT_TAPS 1
+#define GO_LIT_DIV 2
+#define GO_LIT_FMA 4
+static int go_flavour = 0;
+void gipuma_oracle_set_flavour(int mask) { go_flavour = mask & 7; }
+int gipuma_oracle_get_flavour(void) { return go_flavour; }
+
+/* one bilinear fetch tex2D(r, x, y) of the shim's texture model (ref_harness.cpp: ref_tex_channel) */
+static inline float go_tex2d(const float *img, int rows, int cols, int pitch, float x, float y)
+{
+    const float xb = x - 0.5f, yb = y - 0.5f;
+    const float fx = floorf(xb), fy = floorf(yb);
+    const float a = xb - fx, b = yb - fy;
+    const int ix = (int)fminf(fmaxf(fx, -2.0f), (float)cols);
+    const int iy = (int)fminf(fmaxf(fy, -2.0f), (float)rows);
+    const float t00 = go_texel(img, rows, cols, pitch, ix, iy), t10 = go_texel(img, rows, cols, pitch, ix + 1, iy);
+    const float t01 = go_texel(img, rows, cols, pitch, ix, iy + 1), t11 = go_texel(img, rows, cols, pitch, ix + 1, iy + 1);
+    const float r0 = fmaf(a, t10 - t00, t00), r1 = fmaf(a, t11 - t01, t01);
+    return fmaf(b, r1 - r0, r0);
+}
+
+static float go_view_cost_flavoured(const gipuma_hip_desc *d, int view, int px, int py, const float pl[4], int fl)
+{
+    const gipuma_hip_params *ap = &d->params;
+    const int rows = d->rows, cols = d->cols, pitch = d->pitch;
+    const float *ref = d->images[0];
+    const float *src = d->images[view];
+    const int hRad = (ap->box_hsize - 1) / 2;
+    const int vRad = (ap->box_vsize - 1) / 2;
+    const float alpha = ap->alpha, tau_color = ap->tau_color, tau_gradient = ap->tau_gradient;
+    const float gamma = ap->gamma;
+    float H[9];
+    go_homography(&d->cameras[0], &d->cameras[view], pl, pl[3], H);
+    const float centre = go_texel(ref, rows, cols, pitch, px, py);
+    float cost = 0.0f;
+    for (int i = -hRad; i < hRad + 1; i += GO_WIN_INCREMENT) {
+        for (int j = -vRad; j < vRad + 1; j += GO_WIN_INCREMENT) {
+            const int ix = px + i, iy = py + j;
+            const float leftValue = go_texel(ref, rows, cols, pitch, ix, iy);
+            const float colorDis = fabsf(leftValue - centre);
+            const float w = go_exp(-colorDis / gamma);
+            const float qx = (float)ix, qy = (float)iy;
+            float X, Y, Z;
+            if (fl & GO_LIT_FMA) { /* matvecmul4noz, config.h:150-162 */
+                X = H[0] * qx + H[1] * qy + H[2];
+                Y = H[3] * qx + H[4] * qy + H[5];
+                Z = H[6] * qx + H[7] * qy + H[8];
+            } else {
+                X = fmaf(H[1], qy, fmaf(H[0], qx, H[2]));
+                Y = fmaf(H[4], qy, fmaf(H[3], qx, H[5]));
+                Z = fmaf(H[7], qy, fmaf(H[6], qx, H[8]));
+            }
+            float sx, sy;
+            if (fl & GO_LIT_DIV) { /* vecdiv4, config.h:44-47 */
+                sx = X / Z;
+                sy = Y / Z;
+            } else {
+                const float rz = 1.0f / Z;
+                sx = X * rz;
+                sy = Y * rz;
+            }
+            float sc, gx2, gy2;
+            if (fl & GO_LIT_TAPS) { /* gipuma.cu:251-253, argument expressions as written */
+                gx2 = go_tex2d(src, rows, cols, pitch, sx + 1 + 0.5f, sy + 0.5f) -
+                      go_tex2d(src, rows, cols, pitch, sx - 1 + 0.5f, sy + 0.5f);
+                gy2 = go_tex2d(src, rows, cols, pitch, sx + 0.5f, sy + 1 + 0.5f) -
+                      go_tex2d(src, rows, cols, pitch, sx + 0.5f, sy - 1 + 0.5f);
+                sc = go_tex2d(src, rows, cols, pitch, sx + 0.5f, sy + 0.5f);
+            } else { /* the model's taps */
+                float m[3];
+                go_taps3_s(src, rows, cols, pitch, 1, sx, sy, m);
+                sc = m[0];
+                gx2 = m[1];
+                gy2 = m[2];
+            }
+            const float colDiff = fabsf(leftValue - sc);
+            const float up = go_texel(ref, rows, cols, pitch, ix, iy - 1);
+            const float down = go_texel(ref, rows, cols, pitch, ix, iy + 1);
+            const float left = go_texel(ref, rows, cols, pitch, ix - 1, iy);
+            const float right = go_texel(ref, rows, cols, pitch, ix + 1, iy);
+            const float gradX = (right - left) - gx2;
+            const float gradY = (down - up) - gy2;
+            const float gradDis = fminf((fabsf(gradX) + fabsf(gradY)) * 0.0625f, tau_gradient);
+            const float colDis = fminf(colDiff, tau_color);
+            if (fl & GO_LIT_FMA) {
+                const float dis = (1.f - alpha) * colDis + alpha * gradDis; /* gipuma.cu:272 */
+                cost = cost + w * dis;                                      /* :274, :672 */
+            } else {
+                const float dis = fmaf(alpha, gradDis, (1.f - alpha) * colDis);
+                cost = fmaf(w, dis, cost);
+            }
         }
     }
     return cost;
@@ -417,10 +567,10 @@ static float go_view_cost_c4(const gipuma_hip_desc *d, int view, int px, int py,
             const float sx = X * rz, sy = Y * rz;
             float cd[3], gradX[3], gradY[3];
             for (int c = 0; c < 3; c++) {
-                float s[5];
-                go_sample5_s(src + c, rows, cols, pitch, 4, sx, sy, s);
-                const float gx2 = s[1] - s[2];
-                const float gy2 = s[3] - s[4];
+                float s[3];
+                go_taps3_s(src + c, rows, cols, pitch, 4, sx, sy, s);
+                const float gx2 = s[1];
+                const float gy2 = s[2];
                 cd[c] = leftValue[c] - s[0];
                 const float up = go_texel_s(ref + c, rows, cols, pitch, 4, ix, iy - 1);
                 const float down = go_texel_s(ref + c, rows, cols, pitch, 4, ix, iy + 1);
@@ -441,7 +591,9 @@ static float go_view_cost_c4(const gipuma_hip_desc *d, int view, int px, int py,
 
 static float go_view_cost_any(const gipuma_hip_desc *d, int view, int px, int py, const float pl[4])
 {
-    return d->channels == 4 ? go_view_cost_c4(d, view, px, py, pl) : go_view_cost(d, view, px, py, pl);
+    if (d->channels == 4) return go_view_cost_c4(d, view, px, py, pl);
+    if (go_flavour) return go_view_cost_flavoured(d, view, px, py, pl, go_flavour);
+    return go_view_cost(d, view, px, py, pl);
 }
 
 float gipuma_oracle_view_cost(const gipuma_hip_desc *d, int view, int x, int y,

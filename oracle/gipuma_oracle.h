@@ -44,6 +44,11 @@ int gipuma_oracle_time(const gipuma_hip_desc *d, int n_iter_timed, double *sec_i
 int gipuma_oracle_time_band(const gipuma_hip_desc *d, int y0, int y1, double *sec_init_band,
                             double *sec_iter_band);
 int gipuma_oracle_num_threads(void);
+/* Literal flavours of the gray patch cost (see gipuma_oracle.c): bit 0 = one bilinear fetch per tap at the coordinates
+ * the source writes (M1), bit 1 = IEEE x/z, y/z (M2), bit 2 = unfused multiply-adds (M3).  0 (default) = the model the
+ * kernels implement; 7 = the operation order of the reference's source.  Process-wide; tests restore 0. */
+void gipuma_oracle_set_flavour(int mask);
+int gipuma_oracle_get_flavour(void);
 void gipuma_oracle_set_threads(int n);
 
 /* ---- unit pieces, exported for the known-answer tests ---- */
@@ -53,6 +58,9 @@ void gipuma_oracle_homography(const gipuma_hip_camera *ref, const gipuma_hip_cam
                               const float n[3], float dpl, float H[9]);
 void gipuma_oracle_sample5(const float *img, int rows, int cols, int pitch, float x, float y,
                            float out[5]);
+/* the three quantities the cost reads from the five bilinear taps, in the model's operation order (M1): centre value,
+ * I(x+1,y) - I(x-1,y), I(x,y+1) - I(x,y-1) */
+void gipuma_oracle_taps3(const float *img, int rows, int cols, int pitch, float x, float y, float out[3]);
 float gipuma_oracle_aggregate(const float *view_costs, int n, int cost_comb, int n_best,
                               float good_factor);
 float gipuma_oracle_view_cost(const gipuma_hip_desc *d, int view, int x, int y,

@@ -1,9 +1,14 @@
 #!/bin/sh
-export GIPUMA_HIP_EXPERIMENTS=1  # the library reads its A/B switches only under this one
-# build a differently configured library for A/B runs (loaded through GIPUMA_HIP_LIB):
+# build a differently configured library for A/B runs (loaded through GIPUMA_HIP_LIB under GIPUMA_HIP_EXPERIMENTS=1):
 #   sh scripts/build_variant.sh <name> [-DFLAG ...]   ->  gipuma_amd/csrc/variants/libgipuma_hip_<name>.so
+# Both translation units (exact flavour + the GIPUMA_HIP_FLAG_FAST flavour) get the extra flags.
 R=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; shift
 mkdir -p $R/gipuma_amd/csrc/variants
-cd $R/gipuma_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize \
-    -fPIC -shared -Wall "$@" -o variants/libgipuma_hip_$NAME.so gipuma_hip.hip
+cd $R/gipuma_amd/csrc || exit 1
+F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fPIC -Wall"
+/opt/rocm/bin/hipcc $F "$@" -c -o variants/$NAME.exact.o gipuma_hip.hip &
+/opt/rocm/bin/hipcc $F "$@" -c -o variants/$NAME.fast.o gipuma_hip_fast.hip &
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libgipuma_hip_$NAME.so variants/$NAME.exact.o variants/$NAME.fast.o \
+  && rm -f variants/$NAME.exact.o variants/$NAME.fast.o

@@ -64,6 +64,7 @@ def lib():
         L.gipuma_oracle_homography.argtypes = [C.POINTER(abi.Camera), C.POINTER(abi.Camera), _FP,
                                                C.c_float, _FP]
         L.gipuma_oracle_sample5.argtypes = [_FP, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _FP]
+        L.gipuma_oracle_taps3.argtypes = [_FP, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _FP]
         L.gipuma_oracle_aggregate.argtypes = [_FP, C.c_int, C.c_int, C.c_int, C.c_float]
         L.gipuma_oracle_aggregate.restype = C.c_float
         L.gipuma_oracle_view_cost.argtypes = [D, C.c_int, C.c_int, C.c_int, _FP]
@@ -77,6 +78,7 @@ def lib():
         L.gipuma_oracle_plane_d.restype = C.c_float
         L.gipuma_oracle_view_vector.argtypes = [C.POINTER(abi.Camera), C.c_int, C.c_int, _FP]
         L.gipuma_oracle_refine_schedule.argtypes = [C.c_float, _FP, _FP, C.c_int]
+        L.gipuma_oracle_set_flavour.argtypes = [C.c_int]
         _lib = L
     return _lib
 

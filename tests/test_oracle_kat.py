@@ -237,6 +237,35 @@ def test_k9_bilinear_and_clamp_addressing():
     assert math.isnan(s5(float("nan"), 1)[0])
 
 
+def test_k9b_model_taps_equal_the_five_taps():
+    """The cost functions read the taps through gipuma_oracle_taps3 (model M1: columns interpolated along y first, the
+    +-1 differences taken on the texels before the interpolation).  Same quantities as the five separate fetches of
+    gipuma.cu:251-253: identical on integer positions and on an image that is affine in (x, y); within rounding
+    (a few ulp of 255) anywhere; clamp addressing and NaN behaviour unchanged."""
+    rows, cols = 9, 11
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, size=(rows, cols)).astype(np.float32)
+    o5, o3 = np.zeros(5, dtype=np.float32), np.zeros(3, dtype=np.float32)
+
+    def both(im, x, y):
+        lib().gipuma_oracle_sample5(fptr(im), rows, cols, cols, f32(x), f32(y), fptr(o5))
+        lib().gipuma_oracle_taps3(fptr(im), rows, cols, cols, f32(x), f32(y), fptr(o3))
+        return o5.copy(), o3.copy()
+
+    for x, y in [(3, 2), (0, 0), (10, 8), (-5, 3), (4, 40)]:   # integer positions incl. clamped ones: exact texels
+        a, b = both(img, x, y)
+        assert list(b) == [a[0], a[1] - a[2], a[3] - a[4]]
+    aff = (np.arange(rows * cols, dtype=np.float32).reshape(rows, cols) * 3 + 1)
+    a, b = both(aff, 3.25, 2.5)
+    assert b[0] == pytest.approx(1 + 3 * (2.5 * cols + 3.25), rel=1e-6)
+    assert b[1] == pytest.approx(6.0, rel=1e-6) and b[2] == pytest.approx(6.0 * cols, rel=1e-6)
+    for _ in range(500):
+        x, y = rng.uniform(-3, cols + 2), rng.uniform(-3, rows + 2)
+        a, b = both(img, x, y)
+        assert abs(b[0] - a[0]) <= 1e-4 and abs(b[1] - (a[1] - a[2])) <= 2e-4 and abs(b[2] - (a[3] - a[4])) <= 2e-4
+    assert math.isnan(both(img, float("nan"), 1)[1][0])
+
+
 # ------------------------------------------------------------------------------------------ K10
 def test_k10_initial_normals_face_the_camera(tiny_problem):
     gs, _ = tiny_problem
