@@ -23,7 +23,7 @@ def in_tolerance(a, b):
 
 # (configuration, frame, floor of fast vs exact, the reference's own agreement with the exact mode at that size)
 CASES = [
-    ("A", dict(cols=320, rows=256), 0.994, 0.9942),   # measured 0.9981
+    ("A", dict(cols=320, rows=256), 0.995, 0.9942),   # measured 0.9981
     ("B", dict(cols=320, rows=256), 0.985, 0.9845),   # measured 0.9946
     ("B", {}, 0.95, 0.9462),                          # 640x480 in full; measured 0.9828
     ("C", dict(cols=320, rows=256), 0.9996, 0.9996),  # measured 0.9999
