@@ -14,12 +14,13 @@ MI355X-first differences from the shell loop:
     inter-GPU communication;
   * several reference views are kept in flight per GPU (--in_flight, default 2): one session and HIP
     stream each, the solves enqueued asynchronously -- launch tails of one view fill with workgroups of
-    another and kernels bound by different units overlap (bench.py `value_views_in_flight`: +5 % / +6 %
-    throughput with 2 / 3 views on config C);
+    another (bench.py `value_views_in_flight`: +2 % with 2 / 3 views on config C since the fused launches of
+    round 4 -- they leave little to overlap --, far more on frames whose tiles do not fill the GPU, e.g. config B);
   * results land in <output>/<refname>/{disp.dmb, normals.dmb, cost.dmb} -- the dumps the
     reference writes (main.cpp:1001-1015) and fusibile reads.
 
-Images: binary PGM (P5, 8 bit).  Calibration: <p-folder>/<image name>.P (fileIoUtils.h:83-110).
+Images: what the reference's scripts hand to imread (main.cpp:739-751) -- PNG, JPG (through PIL), binary PGM / PPM.
+Calibration: <p-folder>/<image name>.P (fileIoUtils.h:83-110).
 """
 import argparse
 import collections
@@ -59,6 +60,37 @@ def read_pgm(path):
         raise ValueError("%s: 8-bit images only" % path)
     img = np.frombuffer(data, dtype=np.uint8, count=rows * cols, offset=pos + 1).reshape(rows, cols)
     return img.astype(np.float32)
+
+
+IMAGE_EXTENSIONS = (".png", ".jpg", ".jpeg", ".pgm", ".ppm", ".pnm")
+
+
+def read_image(path):
+    """imread(path, IMREAD_GRAYSCALE) as float32 (main.cpp:741, :941).  PGM: the bytes.  Everything else through PIL:
+    single-channel files as they are (16-bit: the high byte); colour PNG / PPM by the rule of the C++ front-end
+    (gipuma_host.cpp read_image_gray: libpng's 15-bit 9797 / 19234 / 3737 for PNG, OpenCV's 14-bit BGR2GRAY for PPM);
+    JPEG decoded to luma by libjpeg itself (PIL draft mode 'L'), which is what OpenCV's JPEG reader does for
+    IMREAD_GRAYSCALE."""
+    with open(path, "rb") as f:
+        head = f.read(4)
+    if head[:2] == b"P5":
+        return read_pgm(path)
+    from PIL import Image
+    im = Image.open(path)
+    if im.format == "JPEG":
+        im.draft("L", im.size)
+        return np.asarray(im.convert("L"), dtype=np.uint8).astype(np.float32)
+    if im.mode in ("I;16", "I;16B", "I;16L", "I"):
+        return (np.asarray(im, dtype=np.uint32) >> 8).astype(np.uint8).astype(np.float32)
+    if im.mode in ("L", "1", "LA"):
+        return np.asarray(im.convert("L"), dtype=np.uint8).astype(np.float32)
+    if im.mode == "P" and im.palette is not None and im.palette.mode == "L":
+        return np.asarray(im.convert("L"), dtype=np.uint8).astype(np.float32)
+    rgb = np.asarray(im.convert("RGB"), dtype=np.int64)
+    r, g, b = rgb[..., 0], rgb[..., 1], rgb[..., 2]
+    if im.format == "PPM":
+        return ((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).astype(np.float32)
+    return ((9797 * r + 19234 * g + 3737 * b) >> 15).astype(np.float32)
 
 
 def plan_views(P_all, names, ref_idx, cols, rows, ap, cam_scale=1.0):
@@ -109,13 +141,13 @@ def main(argv=None):
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
 
-    names = sorted(n for n in os.listdir(args.images_folder) if n.lower().endswith(".pgm"))
+    names = sorted(n for n in os.listdir(args.images_folder) if n.lower().endswith(IMAGE_EXTENSIONS))
     if len(names) < 2:
-        raise SystemExit("need at least 2 PGM images in %s" % args.images_folder)
+        raise SystemExit("need at least 2 images (png / jpg / pgm / ppm) in %s" % args.images_folder)
     P_all = [read_p_file(os.path.join(args.p_folder, n + ".P")) for n in names]
     # the whole scan resident in HBM, once
     t0 = time.perf_counter()
-    host = [read_pgm(os.path.join(args.images_folder, n)) for n in names]
+    host = [read_image(os.path.join(args.images_folder, n)) for n in names]
     rows, cols = host[0].shape
     dev = [torch.from_numpy(im).to("cuda:%d" % dev_index) for im in host]
     torch.cuda.synchronize()

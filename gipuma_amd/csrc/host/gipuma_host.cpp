@@ -3,6 +3,7 @@
 
 #include <dirent.h>
 #include <sys/stat.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <cmath>
@@ -131,7 +132,7 @@ int parse_command_line(int argc, char **argv, InputFiles &in, OutputFiles &out, 
                 const size_t dot = nm.find_last_of('.');
                 std::string ext = dot == std::string::npos ? "" : nm.substr(dot + 1);
                 for (char &ch : ext) ch = (char)tolower((unsigned char)ch);
-                if (ext == "pgm" || ext == "ppm" || ext == "pnm" || ext == "pfm")
+                if (ext == "pgm" || ext == "ppm" || ext == "pnm" || ext == "pfm" || ext == "png")
                     in.img_filenames.push_back(nm);
                 else
                     n_skipped++;
@@ -141,8 +142,9 @@ int parse_command_line(int argc, char **argv, InputFiles &in, OutputFiles &out, 
             printf("Cannot open the image folder %s\n", in.images_folder.c_str());
         }
         if (n_skipped > 0)
-            printf("%d file(s) in %s are in formats this front-end does not read (it reads pgm/ppm/pnm/pfm; a PMVS "
-                   "visualize/ folder holds jpg): convert them to PNM\n", n_skipped, in.images_folder.c_str());
+            printf("%d file(s) in %s are in formats this front-end does not read (it reads png/pgm/ppm/pnm/pfm; a PMVS "
+                   "visualize/ folder holds jpg): convert them, or use python -m gipuma_amd.batch, which reads jpg\n",
+                   n_skipped, in.images_folder.c_str());
         if (in.img_filenames.empty()) {
             printf("No readable images in %s\n", in.images_folder.c_str());
             return -1;
@@ -495,6 +497,156 @@ bool read_pnm_colour(const std::string &path, std::vector<float> &img, int &rows
     return true;
 }
 
+// ---- PNG (what the reference's scripts pass: scripts/dtu_fast.sh, templeRing.sh hand rect_*.png / *.png to imread,
+// main.cpp:739-751).  The image has no libpng headers; the container format is simple enough to read with zlib alone:
+// signature, IHDR / PLTE / IDAT / IEND chunks, one zlib stream, five scanline filters (PNG specification 1.2, section 6 and
+// 9).  Bit depths 1-16, colour types gray / RGB / palette / gray+alpha / RGBA, non-interlaced.  16-bit samples keep their
+// high byte and alpha is dropped, as imread without IMREAD_ANYDEPTH / IMREAD_UNCHANGED does.  out: rows*cols*3 bytes
+// R, G, B (gray images replicated), `was_gray` = the file had no colour channels.
+static bool read_png_rgb8(const std::string &path, std::vector<unsigned char> &rgb, int &rows, int &cols, bool &was_gray)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::vector<unsigned char> file;
+    unsigned char buf[65536];
+    size_t got;
+    while ((got = fread(buf, 1, sizeof buf, f)) > 0) file.insert(file.end(), buf, buf + got);
+    fclose(f);
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (file.size() < 8 + 25 || memcmp(file.data(), sig, 8)) return false;
+    auto be32 = [&](size_t o) -> uint32_t {
+        return ((uint32_t)file[o] << 24) | ((uint32_t)file[o + 1] << 16) | ((uint32_t)file[o + 2] << 8) | file[o + 3];
+    };
+    uint32_t w = 0, h = 0;
+    int depth = 0, ctype = -1, interlace = 0;
+    std::vector<unsigned char> idat, plte;
+    for (size_t o = 8; o + 12 <= file.size();) {
+        const uint32_t len = be32(o);
+        if (o + 12 + (size_t)len > file.size()) return false;
+        const char *type = (const char *)&file[o + 4];
+        const unsigned char *d = &file[o + 8];
+        if (!memcmp(type, "IHDR", 4) && len >= 13) {
+            w = be32(o + 8);
+            h = be32(o + 12);
+            depth = d[8];
+            ctype = d[9];
+            interlace = d[12];
+        } else if (!memcmp(type, "PLTE", 4)) {
+            plte.assign(d, d + len);
+        } else if (!memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), d, d + len);
+        } else if (!memcmp(type, "IEND", 4)) {
+            break;
+        }
+        o += 12 + (size_t)len;
+    }
+    const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!ch || w < 1 || h < 1 || w > 65535 || h > 65535 || idat.empty()) return false;
+    if (!(depth == 8 || depth == 16 || (depth < 8 && (ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4))))
+        return false;
+    if (ctype == 3 && (depth > 8 || plte.size() < 3)) return false;
+    if (interlace) {
+        printf("%s: interlaced (Adam7) PNG is not read here; re-save it non-interlaced\n", path.c_str());
+        return false;
+    }
+    const size_t bpp_bits = (size_t)ch * depth, stride = (w * bpp_bits + 7) / 8, bpp = bpp_bits >= 8 ? bpp_bits / 8 : 1;
+    std::vector<unsigned char> raw((stride + 1) * (size_t)h);
+    uLongf raw_len = (uLongf)raw.size();
+    if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) return false;
+    // scanline filters: 0 none, 1 sub, 2 up, 3 average, 4 Paeth (PNG 1.2, 6.2 - 6.6)
+    std::vector<unsigned char> zero(stride, 0);
+    for (size_t y = 0; y < h; y++) {
+        unsigned char *cur = &raw[y * (stride + 1) + 1];
+        const unsigned char *up = y ? &raw[(y - 1) * (stride + 1) + 1] : zero.data();
+        const int ft = raw[y * (stride + 1)];
+        for (size_t x = 0; x < stride; x++) {
+            const int a = x >= bpp ? cur[x - bpp] : 0, b = up[x], c = x >= bpp ? up[x - bpp] : 0;
+            int pred = 0;
+            if (ft == 1) pred = a;
+            else if (ft == 2) pred = b;
+            else if (ft == 3) pred = (a + b) >> 1;
+            else if (ft == 4) {
+                const int pp = a + b - c, pa = abs(pp - a), pb = abs(pp - b), pc = abs(pp - c);
+                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+            } else if (ft != 0) return false;
+            cur[x] = (unsigned char)(cur[x] + pred);
+        }
+    }
+    rows = (int)h;
+    cols = (int)w;
+    was_gray = ctype == 0 || ctype == 4;
+    rgb.resize((size_t)h * w * 3);
+    const int maxv = (1 << (depth < 8 ? depth : 8)) - 1;
+    for (size_t y = 0; y < h; y++) {
+        const unsigned char *row = &raw[y * (stride + 1) + 1];
+        for (size_t x = 0; x < w; x++) {
+            auto sample = [&](int k) -> int {  // k-th sample of pixel x, reduced to 8 bits
+                if (depth == 8) return row[x * ch + k];
+                if (depth == 16) return row[(x * ch + k) * 2];  // high byte
+                const size_t bit = x * depth;                    // sub-byte: one sample per pixel
+                return (row[bit >> 3] >> (8 - depth - (bit & 7))) & maxv;
+            };
+            unsigned char *o = &rgb[(y * w + x) * 3];
+            if (ctype == 3) {
+                const size_t idx = (size_t)sample(0) * 3;
+                if (idx + 3 > plte.size()) return false;
+                o[0] = plte[idx]; o[1] = plte[idx + 1]; o[2] = plte[idx + 2];
+            } else if (ch <= 2) {
+                int v = sample(0);
+                if (depth < 8) v = v * 255 / maxv;  // (libpng's expansion of 1/2/4-bit gray)
+                o[0] = o[1] = o[2] = (unsigned char)v;
+            } else {
+                o[0] = (unsigned char)sample(0); o[1] = (unsigned char)sample(1); o[2] = (unsigned char)sample(2);
+            }
+        }
+    }
+    return true;
+}
+
+static bool is_png(const std::string &path)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    unsigned char m[4] = {0, 0, 0, 0};
+    const bool ok = fread(m, 1, 4, f) == 4 && m[0] == 0x89 && m[1] == 'P' && m[2] == 'N' && m[3] == 'G';
+    fclose(f);
+    return ok;
+}
+
+// imread(path, IMREAD_GRAYSCALE) / imread(path, IMREAD_COLOR) of main.cpp:741-744 for the containers this front-end reads:
+// binary PNM and PNG, by content.  Gray from colour: PNM through OpenCV's own 8-bit BGR2GRAY (read_pnm_gray); PNG the way
+// OpenCV's PNG decoder does it -- inside libpng, png_set_rgb_to_gray(1, 0.299, 0.587): 15-bit coefficients 9797 / 19234 /
+// 3737, truncated (libpng 1.6 without gamma tables; OpenCV and libpng are dependencies the reference does not pin,
+// CMakeLists.txt:13, so the last bit of a gray value converted from a colour file is theirs to choose).
+bool read_image_gray(const std::string &path, std::vector<float> &img, int &rows, int &cols)
+{
+    if (!is_png(path)) return read_pnm_gray(path, img, rows, cols);
+    std::vector<unsigned char> rgb;
+    bool was_gray = false;
+    if (!read_png_rgb8(path, rgb, rows, cols, was_gray)) return false;
+    img.resize((size_t)rows * cols);
+    for (size_t k = 0; k < img.size(); k++) {
+        const int r = rgb[3 * k], g = rgb[3 * k + 1], b = rgb[3 * k + 2];
+        img[k] = was_gray ? (float)r : (float)((9797 * r + 19234 * g + 3737 * b) >> 15);
+    }
+    return true;
+}
+
+bool read_image_colour(const std::string &path, std::vector<float> &img, int &rows, int &cols)
+{
+    if (!is_png(path)) return read_pnm_colour(path, img, rows, cols);
+    std::vector<unsigned char> rgb;
+    bool was_gray = false;
+    if (!read_png_rgb8(path, rgb, rows, cols, was_gray)) return false;
+    img.assign((size_t)rows * cols * 4, 0.0f);
+    for (size_t k = 0; k < (size_t)rows * cols; k++) {
+        img[4 * k + 0] = (float)rgb[3 * k + 2];  // B
+        img[4 * k + 1] = (float)rgb[3 * k + 1];  // G
+        img[4 * k + 2] = (float)rgb[3 * k + 0];  // R
+    }
+    return true;
+}
+
 int write_dmb(const std::string &path, const float *data, int rows, int cols, int nb)
 {  // writeDmb / writeDmbNormal, fileIoUtils.h:320-368: int32 {type=1, h, w, nb} + h*w*nb float32
     FILE *f = fopen(path.c_str(), "wb");
@@ -716,7 +868,7 @@ int run_gipuma(const InputFiles &in, const OutputFiles &out, AlgorithmParameters
     for (int i = 0; i < n; i++) {
         int r, c;
         const std::string path = in.images_folder + in.img_filenames[i];
-        const bool ok = ap.color_processing ? read_pnm_colour(path, imgs[i], r, c) : read_pnm_gray(path, imgs[i], r, c);
+        const bool ok = ap.color_processing ? read_image_colour(path, imgs[i], r, c) : read_image_gray(path, imgs[i], r, c);
         if (!ok || (i && (r != rows || c != cols))) {
             printf("Image seems to be invalid\n");
             return -1;
@@ -973,6 +1125,19 @@ int gipuma_host_camera_parameters_world(const double *P_list, int n, float cam_s
 int gipuma_host_write_dmb(const char *path, const float *data, int rows, int cols, int nb)
 {
     return gipuma_host::write_dmb(path, data, rows, cols, nb);
+}
+
+int gipuma_host_read_image(const char *path, int colour, float *out, int *rows, int *cols)
+{
+    if (!path || !rows || !cols) return -1;
+    std::vector<float> img;
+    int r = 0, c = 0;
+    const bool ok = colour ? gipuma_host::read_image_colour(path, img, r, c) : gipuma_host::read_image_gray(path, img, r, c);
+    if (!ok) return -1;
+    *rows = r;
+    *cols = c;
+    if (out) memcpy(out, img.data(), img.size() * sizeof(float));
+    return 0;
 }
 
 int gipuma_host_main(int argc, char **argv)

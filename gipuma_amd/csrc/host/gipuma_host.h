@@ -100,6 +100,9 @@ std::vector<int> select_views(const CameraSet &cs, int cols, int rows, Algorithm
 bool read_pnm_gray(const std::string &path, std::vector<float> &img, int &rows, int &cols);
 // -color_processing: P6 only, float4 texels B, G, R, 0 (imread(IMREAD_COLOR) order, main.cpp:943-956)
 bool read_pnm_colour(const std::string &path, std::vector<float> &img, int &rows, int &cols);
+// imread(IMREAD_GRAYSCALE) / imread(IMREAD_COLOR) of main.cpp:741-744 for binary PNM and PNG files (by content)
+bool read_image_gray(const std::string &path, std::vector<float> &img, int &rows, int &cols);
+bool read_image_colour(const std::string &path, std::vector<float> &img, int &rows, int &cols);
 int write_dmb(const std::string &path, const float *data, int rows, int cols, int nb);
 bool read_dmb(const std::string &path, std::vector<float> &data, int &rows, int &cols, int &nb);
 // 3d_model<i>.ply of storePlyFileBinary (displayUtils.h:78-159): per pixel the world point of its depth,
@@ -123,6 +126,9 @@ int gipuma_host_write_ply(const char *path, const float *depth, const float *nor
                           int cols, const gipuma_hip_camera *cam);
 int gipuma_host_camera_parameters_world(const double *P_list, int n, float cam_scale, gipuma_hip_camera *out);
 int gipuma_host_main(int argc, char **argv);
+/* image files as the CLI reads them (PNG or binary PNM): colour == 0: rows*cols floats; else rows*cols*4 floats B, G, R, 0.
+ * Call with out == NULL to get the size. Returns 0, or -1 if the file cannot be read. */
+int gipuma_host_read_image(const char *path, int colour, float *out, int *rows, int *cols);
 // computeError / computeNormalError on caller data (tests): out = error, error2, error_nocc, error_valid,
 // error_valid_all, valid_ratio, num_gt;  out2 = normal error, normal error2
 // from_bundler_get_range on caller data (tests): *depth_min / *depth_max in = current values (-1 = unset)

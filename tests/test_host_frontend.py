@@ -134,18 +134,23 @@ def test_ply_layout_and_points(tmp_path):
     assert abs(q[0] / q[2] - 5.0) < 0.05 and abs(q[1] / q[2] - 1.0) < 0.05
 
 
-def write_scene(tmp, gs, view_ids):
-    """PGM (gray) or PPM (colour: the float4 planes are B, G, R, alpha -> file order R, G, B)"""
+def write_scene(tmp, gs, view_ids, png=False):
+    """PGM (gray) or PPM (colour: the float4 planes are B, G, R, alpha -> file order R, G, B); png: the same planes as
+    rect_XXX.png, the names the reference's scripts pass (scripts/dtu_fast.sh:30-55)"""
     img_dir, p_dir = tmp / "img", tmp / "calib"
     img_dir.mkdir()
     p_dir.mkdir()
     P = synth.dtu_projection_matrices()
     names = []
     for im, vid in zip(gs.images, view_ids):
-        name = "rect_%03d.%s" % (vid, "ppm" if im.ndim == 3 else "pgm")
-        with open(img_dir / name, "wb") as f:
-            f.write(b"%s\n# synthetic\n%d %d\n255\n" % (b"P6" if im.ndim == 3 else b"P5", gs.cols, gs.rows))
-            f.write((im[..., 2::-1] if im.ndim == 3 else im).astype(np.uint8).tobytes())
+        name = "rect_%03d.%s" % (vid, "png" if png else "ppm" if im.ndim == 3 else "pgm")
+        if png:
+            from PIL import Image
+            Image.fromarray(np.ascontiguousarray((im[..., 2::-1] if im.ndim == 3 else im).astype(np.uint8))).save(img_dir / name)
+        else:
+            with open(img_dir / name, "wb") as f:
+                f.write(b"%s\n# synthetic\n%d %d\n255\n" % (b"P6" if im.ndim == 3 else b"P5", gs.cols, gs.rows))
+                f.write((im[..., 2::-1] if im.ndim == 3 else im).astype(np.uint8).tobytes())
         with open(p_dir / (name + ".P"), "w") as f:
             for r in P[vid]:
                 f.write(" ".join("%.6f" % v for v in r) + "\n")
@@ -178,15 +183,15 @@ def test_cli_without_gpu_fails_loudly(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("colour", [False, True])
-def test_cli_end_to_end_dmb_matches_oracle(hip, tmp_path, colour):
-    """PGM + .P files in, disp.dmb / normals.dmb out, through the reference's flags; the oracle is
+@pytest.mark.parametrize("colour,png", [(False, False), (True, False), (False, True), (True, True)])
+def test_cli_end_to_end_dmb_matches_oracle(hip, tmp_path, colour, png):
+    """PGM / PPM / PNG + .P files in, disp.dmb / normals.dmb out, through the reference's flags; the oracle is
     fed the cameras the C++ front-end produced, so the dumps must match it bit for bit"""
     from tests.oracle_lib import OracleState
     cfg = synth.tiny_config(cols=96, rows=64, n_src=3, blocksize=11, iterations=2, n_best=2)
     gs, info = synth.build_problem(cfg, colour=colour)
     ids = info["view_ids"]
-    img_dir, p_dir, names = write_scene(tmp_path, gs, ids)
+    img_dir, p_dir, names = write_scene(tmp_path, gs, ids, png=png)
     out_dir = tmp_path / "out"
     args = cli_args(cfg, img_dir, p_dir, names, out_dir) + (["-color_processing"] if colour else [])
     r = subprocess.run(args, capture_output=True, text=True)
@@ -583,3 +588,76 @@ def test_front_ends_match_the_references_own_code_live(tmp_path):
     for what, cs in (("cameras.py", get_camera_parameters([allP[k] if k != ids[0] else -allP[k] for k in ids])),
                      ("gipuma_host.cpp", cpp_cameras([allP[k] if k != ids[0] else -allP[k] for k in ids]))):
         _assert_cameras_agree(pos, cs, what + ", -P")
+
+
+# ------------------------------------------------------------------ image containers the reference's scripts pass (round 5)
+def _host_read_image(path, colour=False):
+    L = C.CDLL(os.path.join(HOST, "libgipuma_host.so"))
+    L.gipuma_host_read_image.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    r, c = C.c_int(0), C.c_int(0)
+    if L.gipuma_host_read_image(str(path).encode(), int(colour), None, C.byref(r), C.byref(c)) != 0:
+        return None
+    out = np.zeros((r.value, c.value, 4) if colour else (r.value, c.value), dtype=np.float32)
+    assert L.gipuma_host_read_image(str(path).encode(), int(colour), out.ctypes.data_as(C.POINTER(C.c_float)),
+                                    C.byref(r), C.byref(c)) == 0
+    return out
+
+
+def test_png_reader_matches_pil_for_every_colour_type(tmp_path):
+    """scripts/dtu_fast.sh and templeRing.sh hand PNG files to imread (main.cpp:739-751): the C++ front-end decodes them
+    with zlib alone (signature, chunks, five scanline filters, bit depths 1-16, gray / RGB / palette / alpha), the Python
+    runner through PIL; both give the same planes"""
+    from PIL import Image
+    from gipuma_amd import batch
+    rng = np.random.default_rng(11)
+    h, w = 37, 53  # odd sizes: ragged sub-byte rows
+    base = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    base[5:20, 7:30] = np.linspace(0, 255, 23, dtype=np.uint8)[None, :, None]  # smooth part: exercises sub/up/Paeth filters
+    cases = {
+        "gray8": Image.fromarray(base[..., 0], "L"),
+        "rgb8": Image.fromarray(base, "RGB"),
+        "rgba8": Image.fromarray(np.dstack([base, rng.integers(0, 256, size=(h, w), dtype=np.uint8)]), "RGBA"),
+        "la8": Image.fromarray(np.dstack([base[..., 1], base[..., 2]]), "LA"),
+        "pal8": Image.fromarray(base, "RGB").quantize(64),
+        "gray16": Image.fromarray((base[..., 0].astype(np.uint16) << 8) | base[..., 1]),
+        "bit1": Image.fromarray(base[..., 0] > 127).convert("1"),
+    }
+    for name, im in cases.items():
+        p = tmp_path / (name + ".png")
+        im.save(p, optimize=(name == "rgb8"))
+        got = _host_read_image(p)
+        assert got is not None, name
+        want = batch.read_image(str(p))
+        assert got.shape == (h, w) and np.array_equal(got, want), name
+        assert np.array_equal(got, np.floor(got)) and got.min() >= 0 and got.max() <= 255
+    # what the values ARE: gray files keep their bytes, colour files go through libpng's rgb_to_gray coefficients
+    assert np.array_equal(_host_read_image(tmp_path / "gray8.png"), base[..., 0].astype(np.float32))
+    assert np.array_equal(_host_read_image(tmp_path / "gray16.png"), base[..., 0].astype(np.float32))  # the high byte
+    r, g, b = (base[..., k].astype(np.int64) for k in range(3))
+    assert np.array_equal(_host_read_image(tmp_path / "rgb8.png"), ((9797 * r + 19234 * g + 3737 * b) >> 15).astype(np.float32))
+    # -color_processing: float4 texels B, G, R, 0 (main.cpp:943-956)
+    col = _host_read_image(tmp_path / "rgba8.png", colour=True)
+    assert np.array_equal(col[..., 0], base[..., 2]) and np.array_equal(col[..., 2], base[..., 0]) and not col[..., 3].any()
+    # PNM still goes the PNM way, garbage is refused
+    (tmp_path / "x.pgm").write_bytes(b"P5\n%d %d\n255\n" % (w, h) + base[..., 0].tobytes())
+    assert np.array_equal(_host_read_image(tmp_path / "x.pgm"), base[..., 0].astype(np.float32))
+    (tmp_path / "bad.png").write_bytes(b"\x89PNG\r\n\x1a\n" + b"\0" * 40)
+    assert _host_read_image(tmp_path / "bad.png") is None
+    # an interlaced file is refused, not misread (PIL cannot write Adam7: flip the IHDR flag of a good file and fix its CRC)
+    import struct
+    import zlib
+    good = bytearray((tmp_path / "gray8.png").read_bytes())
+    good[8 + 8 + 12] = 1
+    good[8 + 8 + 13:8 + 8 + 17] = struct.pack(">I", zlib.crc32(bytes(good[12:8 + 8 + 13])))
+    (tmp_path / "adam7.png").write_bytes(bytes(good))
+    assert _host_read_image(tmp_path / "adam7.png") is None
+
+
+def test_python_runner_reads_jpeg_as_luma(tmp_path):
+    from PIL import Image
+    from gipuma_amd import batch
+    g = (np.add.outer(np.arange(40), np.arange(56)) * 2 % 256).astype(np.uint8)
+    Image.fromarray(np.dstack([g, g, g]), "RGB").save(tmp_path / "a.jpg", quality=95)
+    got = batch.read_image(str(tmp_path / "a.jpg"))
+    assert got.shape == g.shape and got.dtype == np.float32
+    assert np.abs(got - g).mean() < 3.0 and np.array_equal(got, np.floor(got))
