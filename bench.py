@@ -461,15 +461,24 @@ def main():
 
         def stale(j):
             return None if not j else (j.get("_src_sha16") != src_now)
-        traffic = None
+        # the imported traffic figure is only printed when it belongs to this build and this kernel time: counters
+        # collected from other kernel sources, or at a launch duration more than 5 % away from the one measured in this
+        # run, are refused (traffic = null, the reason in traffic_source.refused)
+        traffic, traffic_refused = None, None
         if pd and "hbm_read_bytes_per_launch_x2corr" in pd:
-            traffic = (pd["hbm_read_bytes_per_launch_x2corr"] + pd["hbm_write_bytes_per_launch"]) / 1e9
+            ms_pmc = pd.get("_kernel_ms_profiled_mean")
+            if stale(pd):
+                traffic_refused = "collected with other kernel sources (src sha16 %s, this run %s)" % (pd.get("_src_sha16"), src_now)
+            elif ms_pmc and abs(ms_pmc - ms_launch) > 0.05 * ms_launch:
+                traffic_refused = "collected at %.3f ms per launch, this run measures %.3f ms (> 5 %% apart)" % (ms_pmc, ms_launch)
+            else:
+                traffic = (pd["hbm_read_bytes_per_launch_x2corr"] + pd["hbm_write_bytes_per_launch"]) / 1e9
         imported_dom = {"measured_in_this_run": False, "file": "profiles/" + dom_pmc_file,
                         "collected_at_kernel_ms": pd.get("_kernel_ms_profiled_mean") if pd else None,
                         "collected_with_lib_sha16": pd.get("_lib_sha16") if pd else None, "commit": pd.get("_commit") if pd else None,
                         "collected_with_src_sha16": pd.get("_src_sha16") if pd else None,
                         "lib_sha16_of_this_run": lib_now, "src_sha16_of_this_run": src_now, "stale": stale(pd),
-                        "note": pd.get("_note") if pd else None}
+                        "refused": traffic_refused, "note": pd.get("_note") if pd else None}
         imported = {"measured_in_this_run": False, "file": "profiles/pmc_latest.json",
                     "collected_at_kernel_ms": pj.get("_kernel_ms_profiled_mean") if pj else None,
                     "collected_with_lib_sha16": pj.get("_lib_sha16") if pj else None, "commit": pj.get("_commit") if pj else None,
@@ -667,7 +676,7 @@ def main():
             #     at the end.  Launch tails of one view fill with workgroups of another, and kernels bound
             #     by different units (the push kernels by the vector L1, the sweep kernels by VALU issue)
             #     overlap.  Reported beside `value`, which stays one view at a time.
-            if args.config in ("C", "D") and args.scene == "smooth":
+            if args.scene == "smooth":
                 inflight = {}
                 others = [v for v in synth.DTU_REF_VIEWS if v != ref_view]
                 extra = []

@@ -873,23 +873,25 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
                                (size_t)((d->rows + pm::kSweepTileH - 1) / pm::kSweepTileH);
     s->push_launches = s->ch == 4 ? (sweep_tiles >= 1024 ? 3 : 6) : s->box == 15 ? 4 : s->box == 25 ? 3 : 2;
     if (const char *t = exp_env("PUSH_LAUNCHES")) s->push_launches = atoi(t);  // A/B runs: 0 = never
-    // plane-keyed propagation (pm_group.h) after the pushed half-sweeps: box 11 / 15, gray
+    // plane-keyed propagation (pm_group.h) after the pushed half-sweeps.  The kernels exist for boxes 11 / 15 / 25 in gray and
+    // box 15 in colour; the DEFAULT schedule uses them for boxes 15 and 25 (gray) and box 15 (colour) on frames of >= 1024
+    // tiles.  Box 11 and every frame under 1024 tiles (configs A and B) keep group_from = -1: their instantiation is
+    // reached only through GIPUMA_HIP_GROUP_FROM under GIPUMA_HIP_EXPERIMENTS (and is parity-tested there).
     s->group_ok = s->push_ok && ((s->ch == 1 && (s->box == 11 || s->box == 15 || s->box == 25)) || (s->ch == 4 && s->box == 15));
     if (s->push_launches <= 0) s->push_ok = false;
-    // Default: from the fifth half-sweep on (the first four read pm::push_kernel's costs) for box 15 on frames of
-    // >= 1024 tiles: config C 90.6 -> 80.8 ms per view, any start between the third and the fifth half-sweep within
-    // 0.5 %; on config B's 300 tiles (one wave of workgroups) it loses 1.5 % (scripts/gpu_r04_sched.sh).
+    // Default: right after the pushed half-sweeps -- from the fifth half-sweep on for box 15 (config C 90.6 -> 80.8 ms per
+    // view in round 4; any start between the third and the fifth within 0.5 %), from the fourth for box 25 and colour; on
+    // config B's 300 tiles (one wave of workgroups) it loses 1.5 % (scripts/gpu_r04_sched.sh).
     // GIPUMA_HIP_GROUP_FROM=<first half-sweep> (experiments): < 0 = never.
     {
         const size_t tiles = (size_t)((d->cols + pm::kTileW - 1) / pm::kTileW) *
                              (size_t)((d->rows + pm::kSweepTileH - 1) / pm::kSweepTileH);
-        s->group_from = tiles < 1024 ? -1 : s->ch == 4 ? 3 : s->box == 15 ? 4 : s->box == 25 ? 3 : -1;  // (right after the pushed half-sweeps)
+        s->group_from = tiles < 1024 ? -1 : s->ch == 4 ? 3 : s->box == 15 ? 4 : s->box == 25 ? 3 : -1;
     }
     if (const char *t = exp_env("GROUP_FROM")) s->group_from = atoi(t);
-    // one launch per half-sweep (pm::sweep_group_kernel) for gray; colour: two (its sweep kernel is compiled for four
-    // workgroups per CU, the fused one holds two: 219 ms fused against 205 ms per view, config C's geometry in colour)
-    // gray: one launch per half-sweep; colour: pm::group_kernel<15, 4> + the sweep kernel (the fused colour kernel was
-    // slower -- 256 registers, 121 of them spilled -- and is not built: DESIGN.md 5, round 4)
+    // gray: ONE launch per half-sweep (pm::sweep_group_kernel).  Colour: pm::group_kernel<15, 4> in front of the sweep
+    // kernel, two launches -- a fused colour instantiation is not built (it held two workgroups per CU at
+    // 256 registers with 121 spilled, was slower, and could not be trusted).
     s->group_fused = s->ch == 1;
     if (const char *t = exp_env("GROUP_FUSED")) s->group_fused = s->ch == 1 && atoi(t) != 0;  // 0: group_kernel + sweep_kernel, two launches
     if (s->group_from < 0) s->group_ok = false;

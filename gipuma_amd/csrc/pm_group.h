@@ -145,6 +145,12 @@ struct GroupLayout {  // offsets in 32-bit words into the dynamic LDS array
     static_assert(batch_samples >= max_cols * (max_rows | 1), "the largest possible group fits a wavefront's sample buffer");
     static_assert(kGrpBatchStrips >= max_cols, "the strips of the largest possible group fit the lanes");
     static_assert(total * 4 * group_wg<BOX, CH>() <= 160 * 1024, "workgroups per CU");
+    // Every strip of a batch walks the BATCH's row count (GroupWalk::body, nr_b = the longest group's), so a strip of a
+    // shorter group near the bottom of the tile reads reference texels of up to 2 (max_rows - N) rows (+ 1 for the lower
+    // neighbour of the central difference) below the staged plane.  Those words are the misc / meta / sbt tables that
+    // follow `plane`: the reads stay inside this workgroup's allocation, the dis values computed from them are never read
+    // by a chain (no task of that group has those rows).  A layout change must keep the over-read inside the allocation:
+    static_assert(plane + CH * tw * (th + 2 * (max_rows - N) + 1) <= total, "the strips' over-read below the plane stays inside the allocation");
     static_assert((w_gplane % 4) == 0 && (w_hbuf % 4) == 0 && (waves % 4) == 0 && (w_stride % 4) == 0, "16-byte aligned float4 tables");
 };
 

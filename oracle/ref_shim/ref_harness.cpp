@@ -173,6 +173,12 @@ static int ref_create_impl(const gipuma_hip_desc *d, int allow_ragged)
     /* frames that are not tile multiples hit the reference's tile under-fill quirk in their last
      * blocks; only the timing of interior blocks may use them */
     if (!d || d->n_images > MAX_IMAGES || (!allow_ragged && (d->rows % 32 || d->cols % 32))) return -1;
+    {   /* the block's shared tile (gipuma.cu:1844-1856: (32 + 2 R)^2 texels of T) must fit the buffer that stands in for
+         * dynamic shared memory: 64 KiB holds box <= 25 in colour; a larger window is refused, not overrun */
+        const size_t rw = (size_t)(d->params.box_hsize + 1) / 2, rh = (size_t)(d->params.box_vsize + 1) / 2;
+        const size_t texel = d->channels == 4 ? sizeof(float4) : sizeof(float);
+        if (d->params.box_hsize < 1 || d->params.box_vsize < 1 || (32 + 2 * rw) * (32 + 2 * rh) * texel > sizeof(my_smem)) return -1;
+    }
     g_gs = new GlobalState;
     g_params = new AlgorithmParameters;
     AlgorithmParameters &p = *g_params;

@@ -8,8 +8,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-# the library reads its A/B switches (GIPUMA_HIP_TUNE, ..._LB_K, ...: the knobs the exactness tests turn) only
-# when this one is set; a production process never sets it
+# The library reads its A/B switches (GIPUMA_HIP_TUNE, ..._LB_K, ...: the knobs the exactness tests turn) only when
+# GIPUMA_HIP_EXPERIMENTS is set; a production process never sets it.  The tests set it -- and start from a clean slate:
+# any other GIPUMA_HIP_* variable a developer's or CI's shell happens to carry would silently change what the
+# default-schedule tests exercise, so everything but the switch itself is dropped here (tests that want a knob set it
+# themselves, scoped: tests/test_parity_gpu.py::_with_env).
+for _k in [k for k in os.environ if k.startswith("GIPUMA_HIP_") and k != "GIPUMA_HIP_EXPERIMENTS"]:
+    del os.environ[_k]
 os.environ["GIPUMA_HIP_EXPERIMENTS"] = "1"
 
 

@@ -16,8 +16,14 @@ _lib = None
 
 
 def build():
-    subprocess.check_call(["make", "-C", ORACLE_DIR, "libgipuma_oracle.so"],
-                          stdout=subprocess.DEVNULL)
+    # one `make` at a time: parallel test workers (pytest-xdist) must not link the same .so concurrently
+    import fcntl
+    with open(os.path.join(ORACLE_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "libgipuma_oracle.so"], stdout=subprocess.DEVNULL)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def _granted_cores():

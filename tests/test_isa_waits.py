@@ -11,6 +11,7 @@ import hashlib
 import os
 import re
 import subprocess
+import tempfile
 
 import pytest
 
@@ -20,17 +21,34 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC"]
 
 
+def _compile_to_assembly(tu):
+    """assembly of one translation unit, cached per source state under /tmp.  The file appears under its final name only
+    when the compile has finished and the text is complete (an interrupted or concurrent run -- pytest-xdist -- must not
+    leave a truncated cache entry that later runs parse)."""
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".hip")))
+    key = hashlib.sha256(b"".join(open(os.path.join(CSRC, f), "rb").read() for f in srcs)).hexdigest()[:16]
+    out = os.path.join("/tmp", "gipuma_hip_%s_%s.s" % (key, tu.replace(".hip", "")))
+    if not os.path.exists(out):
+        fd, tmp = tempfile.mkstemp(prefix=os.path.basename(out) + ".", suffix=".part", dir="/tmp")
+        os.close(fd)
+        try:
+            subprocess.run([HIPCC] + FLAGS + ["-S", "--offload-device-only", "-o", tmp, tu], cwd=CSRC,
+                           check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            assert "s_endpgm" in open(tmp).read(), "hipcc left an incomplete assembly file"
+            os.replace(tmp, out)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+    text = open(out).read()
+    assert "s_endpgm" in text, "cached assembly %s is incomplete: delete it" % out
+    return text.split("\n")
+
+
 @pytest.fixture(scope="module")
 def asm():
     if not os.path.exists(HIPCC):
         pytest.skip("no hipcc")
-    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".hip")))
-    key = hashlib.sha256(b"".join(open(os.path.join(CSRC, f), "rb").read() for f in srcs)).hexdigest()[:16]
-    out = os.path.join("/tmp", "gipuma_hip_%s.s" % key)  # (one compile per source state)
-    if not os.path.exists(out):
-        subprocess.run([HIPCC] + FLAGS + ["-S", "--offload-device-only", "-o", out, "gipuma_hip.hip"], cwd=CSRC,
-                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    return open(out).read().split("\n")
+    return _compile_to_assembly("gipuma_hip.hip")
 
 
 def kernel(asm, prefix):

@@ -407,8 +407,13 @@ def test_early_termination_colour(hip, theta, tune):
 
 
 def _with_env(env, fn):
+    """run fn() with the variables of `env` set (a value of None: unset), then restore the environment"""
     old = {k: os.environ.get(k) for k in env}
-    os.environ.update({k: str(v) for k, v in env.items()})
+    for k, v in env.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = str(v)
     try:
         return fn()
     finally:
@@ -817,6 +822,24 @@ def test_config_d_and_colour_all_iterations_against_the_oracle(hip, cfg, colour)
     assert_same(a[1], o_c, "config %s colour=%r 832x640 cost" % (cfg, colour))
 
 
+@pytest.mark.parametrize("cfg,colour", [("D", False), ("C", True)])
+def test_config_d_and_colour_whole_frame_two_iterations_against_the_oracle(hip, cfg, colour):
+    """BASELINE config D (1600x1200, 20 source views, box 25; scripts/dtu_accurate.sh) and the colour variant of config C
+    at the FULL frame size, free-running through the first two iterations -- the push launches, the column-per-lane
+    launches and the first plane-keyed launch at 3750 tiles -- against the oracle's solve of the same frame: every pixel
+    of the final maps and costs, bit for bit.  (All eight iterations: the 832x640 test above; every launch of all eight at
+    this size on bands: test_config_d_every_launch_at_full_size, test_colour_every_launch_at_full_size.)"""
+    import time
+    gs, info = full_problem(cfg, colour=colour, iterations=2)
+    n4, c = runcuda(gs)
+    t0 = time.time()
+    o_n4, o_c = OracleState(gs).run()
+    print("config %s%s, %dx%d, 2 iterations: oracle free-running solve %.1f s"
+          % (cfg, " colour" if colour else "", gs.cols, gs.rows, time.time() - t0))
+    assert_same(n4, o_n4, "config %s colour=%r full frame norm4" % (cfg, colour))
+    assert_same(c, o_c, "config %s colour=%r full frame cost" % (cfg, colour))
+
+
 @pytest.mark.parametrize("cfg,kw,bands", [("C", {}, [(0, 6), (604, 612)]), ("D", dict(iterations=2), [(0, 3), (606, 610)]),
                                           ("C", dict(colour=True, iterations=2), [(0, 3), (606, 610)])])
 def test_exhaustive_schedule_every_launch_at_full_size(hip, cfg, kw, bands):
@@ -1211,3 +1234,28 @@ def test_hip_against_reference_golden_fixture(hip, fixture):
     ok = (d_rel < 1e-4) & (n_err < 1e-3)
     assert ok.mean() >= 0.9995  # measured: 1.0 on both fixtures (every pixel inside the tolerance)
     assert costs_close(g["final_cost"][ok], fc[ok])
+
+
+def test_production_process_ignores_the_experiment_switches(hip):
+    """Without GIPUMA_HIP_EXPERIMENTS the library reads none of its A/B variables: a session created with
+    GIPUMA_HIP_GROUP_FROM=-1, ..._PUSH_LAUNCHES=0, ..._COLS_LAUNCHES=0 and ..._TUNE=64 in the environment has the default
+    schedule (a regression of the gate -- a variable read with a bare getenv -- would change it), and its solve is the
+    oracle's.  With the switch set the same variables do change the schedule."""
+    gs, _ = synth.build_problem(synth.tiny_config(cols=1056, rows=512, n_src=2, blocksize=15, iterations=1, n_best=2))
+    knobs = {"GIPUMA_HIP_GROUP_FROM": "-1", "GIPUMA_HIP_PUSH_LAUNCHES": "0", "GIPUMA_HIP_COLS_LAUNCHES": "0",
+             "GIPUMA_HIP_TUNE": "64"}
+
+    def schedule():
+        with Session(gs) as s:
+            return s.schedule()
+
+    default = _with_env({"GIPUMA_HIP_EXPERIMENTS": None}, schedule)
+    assert default == dict(push_launches=4, group_from=4, group_fused=True, cols_launches=4)
+    production = _with_env(dict(knobs, GIPUMA_HIP_EXPERIMENTS=None), schedule)
+    assert production == default
+    experiment = _with_env(dict(knobs, GIPUMA_HIP_EXPERIMENTS="1"), schedule)
+    assert experiment != default and experiment["group_from"] == -1 and experiment["push_launches"] == 0
+    a = _with_env(dict(knobs, GIPUMA_HIP_EXPERIMENTS=None), lambda: runcuda(gs))
+    o = OracleState(gs).run()
+    assert_same(a[0], o[0], "production configuration norm4")
+    assert_same(a[1], o[1], "production configuration cost")
