@@ -261,6 +261,8 @@ def main():
     ap.add_argument("--cols", type=int, default=0, help="experiments only: override the frame width")
     ap.add_argument("--rows", type=int, default=0, help="experiments only: override the frame height")
     ap.add_argument("--views", type=int, default=0, help="experiments only: override the number of source views")
+    ap.add_argument("--blocksize", type=int, default=0, help="experiments only: override the window size (e.g. 19, the "
+                    "reference's default: algorithmparameters.h:25-26)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercise the rank plumbing only (CPU tests)")
     ap.add_argument("--oversubscribe", action="store_true", help="allow more ranks than GPUs (tests on a 1-GPU box)")
     args = ap.parse_args()
@@ -342,6 +344,8 @@ def main():
         over["rows"] = args.rows
     if args.views:
         over["n_src"] = args.views
+    if args.blocksize:
+        over["blocksize"] = args.blocksize
     gs, info = synth.build_problem(args.config, ref_view=ref_view, device=dev, keep_on_device=True,
                                    colour=args.colour, scene=args.scene, **over)
     gs.desc.device_id = dev_index

@@ -218,6 +218,11 @@ sweep_fn pick_sweep_ch(const gipuma_hip_session *s)
     switch (s->box) {
     case 11: return pick_sweep_box<11, CH>(s->u8, s->combine_reg);
     case 15: return pick_sweep_box<15, CH>(s->u8, s->combine_reg);
+    case 19:  // the reference's default window (algorithmparameters.h:25-26), gray: compile-time loops of the sweep and
+              // init kernels (pipelined sample loop, two-phase refinement, prefilter); no push / plane-keyed / column-per-lane
+              // instantiation (the reference's scripts pass 11, 15 or 25)
+        if constexpr (CH == 1) return pick_sweep_box<19, 1>(s->u8, s->combine_reg);
+        return pick_sweep_box<0, CH>(s->u8, s->combine_reg);
     case 25: return pick_sweep_box<25, CH>(s->u8, s->combine_reg);
     default: return pick_sweep_box<0, CH>(s->u8, s->combine_reg);
     }
@@ -239,6 +244,9 @@ init_fn pick_init_ch(const gipuma_hip_session *s)
     switch (s->box) {
     case 11: return s->u8 ? pm::init_kernel<11, true, false, GEN, CH> : pm::init_kernel<11, false, false, GEN, CH>;
     case 15: return s->u8 ? pm::init_kernel<15, true, false, GEN, CH> : pm::init_kernel<15, false, false, GEN, CH>;
+    case 19:
+        if constexpr (CH == 1) return s->u8 ? pm::init_kernel<19, true, false, GEN, 1> : pm::init_kernel<19, false, false, GEN, 1>;
+        return s->u8 ? pm::init_kernel<0, true, false, GEN, CH> : pm::init_kernel<0, false, false, GEN, CH>;
     case 25: return s->u8 ? pm::init_kernel<25, true, false, GEN, CH> : pm::init_kernel<25, false, false, GEN, CH>;
     default: return s->u8 ? pm::init_kernel<0, true, false, GEN, CH> : pm::init_kernel<0, false, false, GEN, CH>;
     }
@@ -423,6 +431,7 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
                                                             : pm::weight_order_kernel<11, 4>)
                             : s->box == 15 ? pm::weight_order_kernel<15>
                             : s->box == 25 ? pm::weight_order_kernel<25>
+                            : s->box == 19 ? pm::weight_order_kernel<19>
                                            : pm::weight_order_kernel<11>;
         const int n = s->rows * s->cols;
         hipLaunchKernelGGL(ok, dim3((n + pm::kThreads - 1) / pm::kThreads), dim3(pm::kThreads), 0, s->stream, s->dp,
@@ -796,7 +805,7 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     // kernel variant
     s->box = 0;
     if (hp.box_h == hp.box_v && !(s->tune & Tune::kGenericBox) &&
-        (hp.box_h == 11 || hp.box_h == 15 || hp.box_h == 25))
+        (hp.box_h == 11 || hp.box_h == 15 || hp.box_h == 25 || (hp.box_h == 19 && s->ch == 1)))
         s->box = hp.box_h;
     {
         // the specialised loops fold the gradient term's 1/16 into alpha and tau_gradient (dis_fold, pm_cost.h): exact
@@ -852,7 +861,7 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     if (const char *t = exp_env("LB_K")) hp.lb_k = atoi(t);  // experiment: fixed length, < 0 = off
     if (hp.et_enable && s->box > 0 && hp.lb_k >= 0 && !(s->tune & (Tune::kNoTwoPhase | Tune::kNoEarlyExit))) {
         // (one plane of rows*cols words per two listed samples: 8 planes for box 15, 16 for box 25, 4 for box 11)
-        const int lb_planes = (s->box == 15 ? pm::lb_max<15>() : s->box == 25 ? pm::lb_max<25>() : pm::lb_max<11>()) / 2;
+        const int lb_planes = (s->box == 15 ? pm::lb_max<15>() : s->box == 25 ? pm::lb_max<25>() : s->box == 19 ? pm::lb_max<19>() : pm::lb_max<11>()) / 2;
         // performance-only state: without the memory for it the solve runs without the prefilter, same results
         if (hipMalloc(&s->worder, (size_t)lb_planes * np * sizeof(uint32_t)) != hipSuccess) {
             (void)hipGetLastError();

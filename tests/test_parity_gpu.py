@@ -116,6 +116,7 @@ def test_fused_sweep_equals_three_launches(hip, tiny_problem):
     dict(cols=80, rows=56, blocksize=15, n_src=4, n_best=3, iterations=1),   # box 15
     dict(cols=70, rows=50, blocksize=9, n_src=2, n_best=1),  # cols/rows not multiples of the tile
     dict(cols=96, rows=40, blocksize=25, n_src=2, iterations=1),             # box 25
+    dict(cols=90, rows=50, blocksize=19, n_src=3, n_best=2, iterations=2),   # box 19, the reference's default window
 ])
 def test_full_run_bit_exact(hip, cfg):
     gs, _ = synth.build_problem(synth.tiny_config(**cfg))
@@ -368,6 +369,7 @@ def test_lower_bound_prefilter_colour(hip, lbk, theta):
 
 @pytest.mark.parametrize("cfg", [dict(cols=96, rows=80, n_src=5, blocksize=11, iterations=3, n_best=1),
                                  dict(cols=96, rows=64, n_src=3, blocksize=25, iterations=2, n_best=2),
+                                 dict(cols=96, rows=64, n_src=4, blocksize=19, iterations=3, n_best=2),
                                  dict(cols=150, rows=100, n_src=12, blocksize=15, iterations=2, n_best=2)])
 def test_lower_bound_prefilter_other_boxes(hip, cfg):
     """the prefilter with the default (probe-chosen) length on boxes 11 and 25 and on a ragged frame with
