@@ -14,7 +14,7 @@ cp $R/gpurun_out/final_pmc/pmc_summary*.json $O/ 2>/dev/null
 cp $O/pmc_summary.json $R/profiles/pmc_latest.json
 cp $O/pmc_summary_sweep_group.json $R/profiles/pmc_latest_sweep_group_kernel.json
 cd $R
-GIPUMA_HIP_LAUNCH_TIMES=1 python bench.py > $O/bench_C.json 2> $O/bench_C.err
+GIPUMA_HIP_LAUNCH_TIMES=1 python bench.py --steps 20 --warmup 2 > $O/bench_C.json 2> $O/bench_C.err
 python bench.py --config B --steps 20 --no-cpu-baseline --no-extras > $O/bench_B.json 2> $O/bench_B.err
 python bench.py --config D --steps 3 --no-cpu-baseline --no-extras > $O/bench_D.json 2> $O/bench_D.err
 python bench.py --colour --steps 3 --no-cpu-baseline --no-extras > $O/bench_colour.json 2> $O/bench_colour.err
