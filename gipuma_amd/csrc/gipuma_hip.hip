@@ -890,7 +890,7 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     if (s->push_launches <= 0) s->push_ok = false;
     // Default: right after the pushed half-sweeps -- from the fifth half-sweep on for box 15 (config C 90.6 -> 80.8 ms per
     // view in round 4; any start between the third and the fifth within 0.5 %), from the fourth for box 25 and colour; on
-    // config B's 300 tiles (one wave of workgroups) it loses 1.5 % (scripts/gpu_r04_sched.sh).
+    // config B's 300 tiles (one wave of workgroups) it loses 1.5 % (scripts/history/gpu_r04_sched.sh).
     // GIPUMA_HIP_GROUP_FROM=<first half-sweep> (experiments): < 0 = never.
     {
         const size_t tiles = (size_t)((d->cols + pm::kTileW - 1) / pm::kTileW) *
