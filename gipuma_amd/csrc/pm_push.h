@@ -81,7 +81,11 @@ struct PushLayout {  // offsets in 32-bit words into the dynamic LDS array
     static_assert(FWH * vs <= (two_pass ? dstride : hbase) && hbase + N * hs <= dstride, "families inside the buffer");
     static constexpr int tile4 = kLutSize;            // {I, gx1, gy1, I} per compressed texel
     static constexpr int iplane = tile4 + 4 * twc * th;  // I alone (4-byte reads of the chain)
+#ifdef PM_PUSH_EXP_ALIAS  // (timing experiment, WRONG results: the sample buffers on top of the tile, so that three workgroups fit a CU)
+    static constexpr int dis = tile4;
+#else
     static constexpr int dis = iplane + ips * th;     // [kPushGroups][dstride]; before that the staging plane
+#endif
     static constexpr int list = dis + kPushGroups * dstride;  // 256 u16: producers with something to offer
     static constexpr int cnt = list + kThreads / 2;
     static constexpr int total = cnt + 8;
