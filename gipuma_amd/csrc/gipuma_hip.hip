@@ -442,10 +442,18 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
     if (fused_group) {
         // propagation costs per plane + accept replay + refinement in one launch (pm_group.h)
         typedef void (*fused_fn)(const pm::Problem *, float4 *, float *, int, uint32_t, unsigned);
+#ifdef PM_FUSED_COLOUR_EXPERIMENT
+        const fused_fn fk = s->ch == 4 ? pm::sweep_group_kernel<15, 4> : s->box == 15 ? pm::sweep_group_kernel<15> : s->box == 25 ? pm::sweep_group_kernel<25> : pm::sweep_group_kernel<11>;
+        const size_t glds = sizeof(float) * (size_t)(s->ch == 4     ? pm::GroupLayout<15, 4>::total
+                                                     : s->box == 15 ? pm::GroupLayout<15>::total
+                                                     : s->box == 25 ? pm::GroupLayout<25>::total
+                                                                    : pm::GroupLayout<11>::total);
+#else
         const fused_fn fk = s->box == 15 ? pm::sweep_group_kernel<15> : s->box == 25 ? pm::sweep_group_kernel<25> : pm::sweep_group_kernel<11>;
         const size_t glds = sizeof(float) * (size_t)(s->box == 15   ? pm::GroupLayout<15>::total
                                                      : s->box == 25 ? pm::GroupLayout<25>::total
                                                                     : pm::GroupLayout<11>::total);
+#endif
         const size_t flds = std::max(glds, s->lds_sweep);
         if (!s->fused_attr_set) {
             HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
@@ -902,7 +910,11 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     // kernel, two launches -- a fused colour instantiation is not built (it held two workgroups per CU at
     // 256 registers with 121 spilled, was slower, and could not be trusted).
     s->group_fused = s->ch == 1;
+#ifdef PM_FUSED_COLOUR_EXPERIMENT
+    if (const char *t = exp_env("GROUP_FUSED")) s->group_fused = atoi(t) != 0;  // (hunt builds: colour too)
+#else
     if (const char *t = exp_env("GROUP_FUSED")) s->group_fused = s->ch == 1 && atoi(t) != 0;  // 0: group_kernel + sweep_kernel, two launches
+#endif
     if (s->group_from < 0) s->group_ok = false;
     if (s->push_ok || s->group_ok) {
         // performance-only state too: without it every half-sweep evaluates its own propagation candidates

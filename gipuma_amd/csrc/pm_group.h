@@ -1047,7 +1047,9 @@ __global__ __launch_bounds__(kThreads, (group_wg<BOX, CH>())) void sweep_group_k
                                                                                     float *__restrict__ cost, int colour,
                                                                                     uint32_t phase, unsigned tune)
 {
+#ifndef PM_FUSED_COLOUR_EXPERIMENT  // (builds of the miscompile hunt, DESIGN.md 9: scripts/gpu_r05_fusedcolour.sh)
     static_assert(CH == 1, "gray only: colour sessions run pm::group_kernel<15, 4> and the sweep kernel (gipuma_hip_create)");
+#endif
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using LY = GroupLayout<BOX, CH>;
     constexpr int tw = LY::tw, th = LY::th;
