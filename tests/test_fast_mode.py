@@ -102,3 +102,29 @@ def test_fast_flag_does_not_leak_into_exact_sessions(hip, tiny_problem):
     assert np.array_equal(n4.view(np.uint32), on.view(np.uint32))
     assert np.array_equal(c.view(np.uint32), oc.view(np.uint32))
     assert gs.desc.flags & abi.FLAG_FAST == 0
+
+
+@pytest.mark.parametrize("what", ["colour", "float_images", "runtime_window", "box25", "generic_combiner"])
+def test_fast_mode_serves_every_kernel_family(hip, what):
+    """the tolerance-judged flavour of the kernels the headline configurations do not reach -- colour (T = float4),
+    images that are not 8-bit (float planes, exp evaluated per sample), a runtime-sized window (box 9), box 25, the
+    generic view combiner -- on small frames: they run, and agree with the exact mode like the rest (most pixels bit for bit)"""
+    cfg = dict(cols=160, rows=112, n_src=4, blocksize=15, iterations=3, n_best=3)
+    kw = {}
+    if what == "colour":
+        kw["colour"] = True
+    elif what == "runtime_window":
+        cfg["blocksize"] = 9
+    elif what == "box25":
+        cfg.update(blocksize=25, n_src=3, iterations=2)
+    elif what == "generic_combiner":
+        kw["cost_comb"] = abi.COMB_GOOD
+    gs, _ = synth.build_problem(synth.tiny_config(**cfg), **kw)
+    if what == "float_images":
+        from gipuma_amd.problem import GlobalState
+        imgs = [im + np.float32(0.25) for im in gs.images]
+        gs = GlobalState(imgs, gs.cameras, gs.selected, gs.params, seed=gs.desc.seed)
+    exact, ce = runcuda(gs)
+    fast, cf = runcuda(gs, fast=True)
+    assert np.isfinite(fast).all() and np.isfinite(cf).all()
+    assert in_tolerance(fast, exact) >= 0.97, what
