@@ -19,6 +19,7 @@ FLAG_IMAGES_ON_DEVICE = 1
 FLAG_UNFUSED = 2
 FLAG_CACHE_IMAGES = 4
 FLAG_FAST = 8  # tolerance-judged flavour of the kernels (include/gipuma_hip.h); default: bit-exact
+FLAG_LITERAL = 16  # reference-order flavour: bit-identical to the reference's own code (fp32 filter model); slow
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgipuma_hip.so")

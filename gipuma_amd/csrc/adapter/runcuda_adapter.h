@@ -96,6 +96,9 @@ int runcuda_impl(GS &gs, unsigned seed = 1)
      * the counterpart of the reference's --use_fast_math build, CMakeLists.txt:23) is chosen like the seed, by the environment */
     if (const char *fm = getenv("GIPUMA_FAST"))
         if (atoi(fm) != 0) d.flags |= GIPUMA_HIP_FLAG_FAST;
+    /* ... and the reference-order validation mode (bit-identical to the reference's own arithmetic under fp32 filter weights) */
+    if (const char *lm = getenv("GIPUMA_LITERAL"))
+        if (atoi(lm) != 0) d.flags |= GIPUMA_HIP_FLAG_LITERAL;
 
     /* the lines the reference prints (gipuma.cu:1899-1912, 1952); scripts grep them */
     printf("Blocksize is %dx%d\n", ap.box_hsize, ap.box_vsize);

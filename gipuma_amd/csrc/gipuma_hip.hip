@@ -12,11 +12,13 @@
 //     session: 20 B planes + costs, 1 B history flag, and -- performance only, optional (the solve runs without
 //     them when the allocation fails) -- 32 B pushed propagation costs and 16-64 B prefilter sample lists.
 //
-// This file is compiled TWICE into libgipuma_hip.so.  As itself it is the exact flavour (bit-identical to the CPU restatement of the numerical model) and
-// owns the exported C-ABI.  Included by gipuma_hip_fast.hip (GIPUMA_HIP_FAST_TU, PM_APPROX = 1, namespace pm -> pm_fast,
-// entry points renamed gipuma_hipf_*, hidden visibility) it is the tolerance-judged flavour behind
-// GIPUMA_HIP_FLAG_FAST: same host logic, same schedule, kernels with the approx arithmetic of pm_core.h.  A session
-// created with the flag is a thin wrapper whose calls this flavour forwards to the other one.
+// This file is compiled THREE times into libgipuma_hip.so.  As itself it is the exact flavour (bit-identical to the CPU
+// restatement of the numerical model) and owns the exported C-ABI.  Included by gipuma_hip_fast.hip (PM_APPROX = 1,
+// namespace pm -> pm_fast, entry points gipuma_hipf_*) it is the tolerance-judged flavour behind GIPUMA_HIP_FLAG_FAST; included
+// by gipuma_hip_literal.hip (PM_LITERAL = 1, pm_lit, gipuma_hipl_*) the reference-order flavour behind GIPUMA_HIP_FLAG_LITERAL.
+// Same host logic in all three (GIPUMA_HIP_FLAVOUR_TU marks the two inclusions; their symbols have hidden visibility).  A
+// session created with one of the flags is a thin handle whose calls this flavour forwards through a table of the other
+// flavour's entry points.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -32,7 +34,7 @@
 #include <type_traits>
 #include <vector>
 
-#ifdef GIPUMA_HIP_FAST_TU
+#ifdef GIPUMA_HIP_FLAVOUR_TU
 #pragma GCC visibility push(hidden)
 #endif
 #include "../../include/gipuma_hip.h"
@@ -40,31 +42,55 @@
 #include "pm_push.h"
 #include "pm_group.h"
 
-#ifndef GIPUMA_HIP_FAST_TU
-// the tolerance-judged flavour of every session entry point (gipuma_hip_fast.hip)
-struct gipuma_hipf_session;
-typedef gipuma_hipf_session fast_session_t;
+#ifndef GIPUMA_HIP_FLAVOUR_TU
+// the session entry points of the other flavours (C linkage: the session pointer is opaque here)
 extern "C" {
 #pragma GCC visibility push(hidden)
-const char *gipuma_hipf_last_error(void);
-int gipuma_hipf_cache_clear(void);
-int gipuma_hipf_create(const gipuma_hip_desc *desc, gipuma_hipf_session **out);
-int gipuma_hipf_destroy(gipuma_hipf_session *s);
-int gipuma_hipf_init_planes(gipuma_hipf_session *s);
-int gipuma_hipf_sweep(gipuma_hipf_session *s, int iteration, int colour, unsigned stages);
-int gipuma_hipf_finalize(gipuma_hipf_session *s);
-int gipuma_hipf_eval_cost(gipuma_hipf_session *s, const float *planes_host, float *cost_out_host);
-int gipuma_hipf_get_state(gipuma_hipf_session *s, float *norm4_host, float *cost_host);
-int gipuma_hipf_set_state(gipuma_hipf_session *s, const float *norm4_host, const float *cost_host);
-int gipuma_hipf_state_device_ptrs(gipuma_hipf_session *s, float **norm4_dev, float **cost_dev);
-int gipuma_hipf_solve(gipuma_hipf_session *s, gipuma_hip_timing *timing);
-int gipuma_hipf_launch_times(gipuma_hipf_session *s, float *ms_half_sweep, int capacity, int *n_half_sweeps, int *n_pushed);
-int gipuma_hipf_group_times(gipuma_hipf_session *s, float *ms_group, int capacity, int *n_half_sweeps);
-int gipuma_hipf_schedule(gipuma_hipf_session *s, int info[4]);
+#define DECLARE_FLAVOUR(P)                                                                                             \
+    const char *P##last_error(void);                                                                                    \
+    int P##cache_clear(void);                                                                                           \
+    int P##create(const gipuma_hip_desc *desc, void **out);                                                             \
+    int P##destroy(void *s);                                                                                            \
+    int P##init_planes(void *s);                                                                                        \
+    int P##sweep(void *s, int iteration, int colour, unsigned stages);                                                  \
+    int P##finalize(void *s);                                                                                           \
+    int P##eval_cost(void *s, const float *planes_host, float *cost_out_host);                                          \
+    int P##get_state(void *s, float *norm4_host, float *cost_host);                                                     \
+    int P##set_state(void *s, const float *norm4_host, const float *cost_host);                                         \
+    int P##state_device_ptrs(void *s, float **norm4_dev, float **cost_dev);                                             \
+    int P##solve(void *s, gipuma_hip_timing *timing);                                                                   \
+    int P##launch_times(void *s, float *ms_half_sweep, int capacity, int *n_half_sweeps, int *n_pushed);                \
+    int P##group_times(void *s, float *ms_group, int capacity, int *n_half_sweeps);                                     \
+    int P##schedule(void *s, int info[4]);
+DECLARE_FLAVOUR(gipuma_hipf_)
+DECLARE_FLAVOUR(gipuma_hipl_)
+#undef DECLARE_FLAVOUR
 #pragma GCC visibility pop
 }
+struct FlavourApi {
+    const char *(*last_error)(void);
+    int (*cache_clear)(void);
+    int (*create)(const gipuma_hip_desc *, void **);
+    int (*destroy)(void *);
+    int (*init_planes)(void *);
+    int (*sweep)(void *, int, int, unsigned);
+    int (*finalize)(void *);
+    int (*eval_cost)(void *, const float *, float *);
+    int (*get_state)(void *, float *, float *);
+    int (*set_state)(void *, const float *, const float *);
+    int (*state_device_ptrs)(void *, float **, float **);
+    int (*solve)(void *, gipuma_hip_timing *);
+    int (*launch_times)(void *, float *, int, int *, int *);
+    int (*group_times)(void *, float *, int, int *);
+    int (*schedule)(void *, int *);
+};
+#define FLAVOUR_API(P)                                                                                                  \
+    {P##last_error, P##cache_clear, P##create, P##destroy, P##init_planes, P##sweep, P##finalize, P##eval_cost,        \
+     P##get_state, P##set_state, P##state_device_ptrs, P##solve, P##launch_times, P##group_times, P##schedule}
+static const FlavourApi kFastApi = FLAVOUR_API(gipuma_hipf_), kLiteralApi = FLAVOUR_API(gipuma_hipl_);
+#undef FLAVOUR_API
 #else
-typedef void fast_session_t;
+struct FlavourApi;
 #endif
 
 namespace {
@@ -108,26 +134,27 @@ const char *exp_env(const char *name)
         if (e_ != hipSuccess) return fail(GIPUMA_HIP_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-#ifndef GIPUMA_HIP_FAST_TU
-// forward a call on a GIPUMA_HIP_FLAG_FAST session to its flavour; a failure's text becomes this thread's last error
-#define FORWARD_FAST(s, call)                                   \
+#ifndef GIPUMA_HIP_FLAVOUR_TU
+// forward a call on a GIPUMA_HIP_FLAG_FAST / _LITERAL session to its flavour; a failure's text becomes this thread's last error
+#define FORWARD(s, fn, ...)                                     \
     do {                                                        \
-        if ((s) && (s)->fast) {                                 \
-            const int rc_ = (call);                             \
-            if (rc_) g_err = gipuma_hipf_last_error();          \
+        if ((s) && (s)->api) {                                  \
+            const int rc_ = (s)->api->fn((s)->impl, ##__VA_ARGS__); \
+            if (rc_) g_err = (s)->api->last_error();            \
             return rc_;                                         \
         }                                                       \
     } while (0)
 #else
-#define FORWARD_FAST(s, call) do { } while (0)
+#define FORWARD(s, fn, ...) do { } while (0)
 #endif
 
 }  // namespace
 
 struct gipuma_hip_session {
-    // non-null: this object is only the handle of a GIPUMA_HIP_FLAG_FAST session that lives in the other flavour of this
-    // file; every entry point forwards to it and nothing below is used
-    fast_session_t *fast = nullptr;
+    // non-null: this object is only the handle of a GIPUMA_HIP_FLAG_FAST / _LITERAL session that lives in another flavour
+    // of this file; every entry point forwards to it through `api` and nothing below is used
+    const FlavourApi *api = nullptr;
+    void *impl = nullptr;
     int device = 0;
     int rows = 0, cols = 0, n_sel = 0, iterations = 0;
     pm::Problem hp{};
@@ -509,11 +536,12 @@ int gipuma_hip_device_count(void)
 
 int gipuma_hip_cache_clear(void)
 {
-#ifndef GIPUMA_HIP_FAST_TU
-    if (const int rc = gipuma_hipf_cache_clear()) {  // (the other flavour keeps its own packed planes)
-        g_err = gipuma_hipf_last_error();
-        return rc;
-    }
+#ifndef GIPUMA_HIP_FLAVOUR_TU
+    for (const FlavourApi *api : {&kFastApi, &kLiteralApi})  // (the other flavours keep their own packed planes)
+        if (const int rc = api->cache_clear()) {
+            g_err = api->last_error();
+            return rc;
+        }
 #endif
     std::lock_guard<std::mutex> lock(g_cache_mutex);
     for (auto &kv : g_cache)
@@ -561,16 +589,27 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         return fail(GIPUMA_HIP_ERR_ARG, "device_id out of range");
     gipuma_hip_session *s = new (std::nothrow) gipuma_hip_session;
     if (!s) return fail(GIPUMA_HIP_ERR_DEVICE, "out of host memory");
-#ifndef GIPUMA_HIP_FAST_TU
-    if (d->flags & GIPUMA_HIP_FLAG_FAST) {  // the tolerance-judged flavour: this object is only its handle
-        rc = gipuma_hipf_create(d, &s->fast);
+#ifndef GIPUMA_HIP_FLAVOUR_TU
+    if (d->flags & (GIPUMA_HIP_FLAG_FAST | GIPUMA_HIP_FLAG_LITERAL)) {  // another flavour: this object is only its handle
+        if ((d->flags & GIPUMA_HIP_FLAG_FAST) && (d->flags & GIPUMA_HIP_FLAG_LITERAL)) {
+            delete s;
+            return fail(GIPUMA_HIP_ERR_ARG, "GIPUMA_HIP_FLAG_FAST and GIPUMA_HIP_FLAG_LITERAL exclude each other");
+        }
+        s->api = (d->flags & GIPUMA_HIP_FLAG_LITERAL) ? &kLiteralApi : &kFastApi;
+        rc = s->api->create(d, &s->impl);
         if (rc) {
-            g_err = gipuma_hipf_last_error();
+            g_err = s->api->last_error();
             delete s;
             return rc;
         }
         *out = s;
         return 0;
+    }
+#endif
+#if PM_LITERAL
+    if (d->channels != 1) {
+        delete s;
+        return fail(GIPUMA_HIP_ERR_UNSUPPORTED, "GIPUMA_HIP_FLAG_LITERAL: gray (T = float) only");
     }
 #endif
     // from here on, destroy() cleans up whatever was built.  The image cache is locked while this call looks at /
@@ -609,6 +648,12 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         s->tune = (unsigned)strtoul(t, nullptr, 0);
         s->tune &= ~(Tune::kHistorySkip | Tune::kUntrustedCosts | Tune::kAccumChanged | Tune::kPushConsume);  // host-internal bits
     }
+#if PM_LITERAL
+    // the reference-order arithmetic lives in the generic sample loop on float planes (view_cost_loop): no packed 8-bit
+    // planes, no compile-time window -- and with them no push / plane-keyed / column-per-lane kernels, no bounded evaluation
+    // (all of those need the packed planes); the skip rules (A) / (D) / (H) hold for any cost that is a pure function
+    s->tune |= Tune::kNoLut | Tune::kGenericBox;
+#endif
     if (const char *t = exp_env("COLS_LAUNCHES")) s->cols_launches = atoi(t);  // experiment
     if (const char *t = exp_env("LAUNCH_TIMES")) s->launch_times = atoi(t) != 0;
     if (d->stream) {
@@ -943,9 +988,9 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
 int gipuma_hip_destroy(gipuma_hip_session *s)
 {
     if (!s) return 0;
-#ifndef GIPUMA_HIP_FAST_TU
-    if (s->fast) {
-        const int rc = gipuma_hipf_destroy(s->fast);
+#ifndef GIPUMA_HIP_FLAVOUR_TU
+    if (s->api) {
+        const int rc = s->api->destroy(s->impl);
         delete s;
         return rc;
     }
@@ -985,7 +1030,7 @@ int gipuma_hip_destroy(gipuma_hip_session *s)
 
 int gipuma_hip_init_planes(gipuma_hip_session *s)
 {
-    FORWARD_FAST(s, gipuma_hipf_init_planes(s->fast));
+    FORWARD(s, init_planes);
     if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
     HIP_OK(hipSetDevice(s->device));
     // (a fresh solve starts with fresh hints, so that repeated solves of a session do the same work)
@@ -1003,7 +1048,7 @@ int gipuma_hip_init_planes(gipuma_hip_session *s)
 
 int gipuma_hip_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stages)
 {
-    FORWARD_FAST(s, gipuma_hipf_sweep(s->fast, iteration, colour, stages));
+    FORWARD(s, sweep, iteration, colour, stages);
     if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
     if (iteration < 0 || (colour != GIPUMA_BLACK && colour != GIPUMA_RED) || (stages & ~7u))
         return fail(GIPUMA_HIP_ERR_ARG, "bad iteration/colour/stages");
@@ -1024,7 +1069,7 @@ int gipuma_hip_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned 
 
 int gipuma_hip_finalize(gipuma_hip_session *s)
 {
-    FORWARD_FAST(s, gipuma_hipf_finalize(s->fast));
+    FORWARD(s, finalize);
     if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
     HIP_OK(hipSetDevice(s->device));
     const int n = s->rows * s->cols;
@@ -1041,7 +1086,7 @@ int gipuma_hip_finalize(gipuma_hip_session *s)
 
 int gipuma_hip_eval_cost(gipuma_hip_session *s, const float *planes_host, float *cost_out_host)
 {
-    FORWARD_FAST(s, gipuma_hipf_eval_cost(s->fast, planes_host, cost_out_host));
+    FORWARD(s, eval_cost, planes_host, cost_out_host);
     if (!s || !planes_host || !cost_out_host) return fail(GIPUMA_HIP_ERR_ARG, "null argument");
     HIP_OK(hipSetDevice(s->device));
     const size_t np = (size_t)s->rows * (size_t)s->cols;
@@ -1067,7 +1112,7 @@ int gipuma_hip_eval_cost(gipuma_hip_session *s, const float *planes_host, float 
 
 int gipuma_hip_get_state(gipuma_hip_session *s, float *norm4_host, float *cost_host)
 {
-    FORWARD_FAST(s, gipuma_hipf_get_state(s->fast, norm4_host, cost_host));
+    FORWARD(s, get_state, norm4_host, cost_host);
     if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
     HIP_OK(hipSetDevice(s->device));
     const size_t np = (size_t)s->rows * (size_t)s->cols;
@@ -1081,7 +1126,7 @@ int gipuma_hip_get_state(gipuma_hip_session *s, float *norm4_host, float *cost_h
 
 int gipuma_hip_set_state(gipuma_hip_session *s, const float *norm4_host, const float *cost_host)
 {
-    FORWARD_FAST(s, gipuma_hipf_set_state(s->fast, norm4_host, cost_host));
+    FORWARD(s, set_state, norm4_host, cost_host);
     if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
     HIP_OK(hipSetDevice(s->device));
     const size_t np = (size_t)s->rows * (size_t)s->cols;
@@ -1100,7 +1145,7 @@ int gipuma_hip_set_state(gipuma_hip_session *s, const float *norm4_host, const f
 
 int gipuma_hip_state_device_ptrs(gipuma_hip_session *s, float **norm4_dev, float **cost_dev)
 {
-    FORWARD_FAST(s, gipuma_hipf_state_device_ptrs(s->fast, norm4_dev, cost_dev));
+    FORWARD(s, state_device_ptrs, norm4_dev, cost_dev);
     if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
     if (norm4_dev) *norm4_dev = (float *)s->norm4;
     if (cost_dev) *cost_dev = s->cost;
@@ -1109,7 +1154,7 @@ int gipuma_hip_state_device_ptrs(gipuma_hip_session *s, float **norm4_dev, float
 
 int gipuma_hip_solve(gipuma_hip_session *s, gipuma_hip_timing *timing)
 {
-    FORWARD_FAST(s, gipuma_hipf_solve(s->fast, timing));
+    FORWARD(s, solve, timing);
     if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
     HIP_OK(hipSetDevice(s->device));
     int rc;
@@ -1201,7 +1246,7 @@ int gipuma_hip_solve(gipuma_hip_session *s, gipuma_hip_timing *timing)
 
 int gipuma_hip_launch_times(gipuma_hip_session *s, float *ms_half_sweep, int capacity, int *n_half_sweeps, int *n_pushed)
 {
-    FORWARD_FAST(s, gipuma_hipf_launch_times(s->fast, ms_half_sweep, capacity, n_half_sweeps, n_pushed));
+    FORWARD(s, launch_times, ms_half_sweep, capacity, n_half_sweeps, n_pushed);
     if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
     const int n = (int)s->half_sweep_ms.size();
     if (ms_half_sweep)
@@ -1213,7 +1258,7 @@ int gipuma_hip_launch_times(gipuma_hip_session *s, float *ms_half_sweep, int cap
 
 int gipuma_hip_schedule(gipuma_hip_session *s, int info[4])
 {
-    FORWARD_FAST(s, gipuma_hipf_schedule(s->fast, info));
+    FORWARD(s, schedule, info);
     if (!s || !info) return fail(GIPUMA_HIP_ERR_ARG, "null argument");
     info[0] = s->push_ok ? s->push_launches : 0;
     info[1] = s->group_ok ? s->group_from : -1;
@@ -1226,7 +1271,7 @@ int gipuma_hip_schedule(gipuma_hip_session *s, int info[4])
 
 int gipuma_hip_group_times(gipuma_hip_session *s, float *ms_group, int capacity, int *n_half_sweeps)
 {
-    FORWARD_FAST(s, gipuma_hipf_group_times(s->fast, ms_group, capacity, n_half_sweeps));
+    FORWARD(s, group_times, ms_group, capacity, n_half_sweeps);
     if (!s) return fail(GIPUMA_HIP_ERR_ARG, "null session");
     const int n = (int)s->group_ms.size();
     if (ms_group)
@@ -1252,6 +1297,6 @@ int gipuma_hip_run(const gipuma_hip_desc *desc, float *norm4_out, float *cost_ou
 
 }  // extern "C"
 
-#ifdef GIPUMA_HIP_FAST_TU
+#ifdef GIPUMA_HIP_FLAVOUR_TU
 #pragma GCC visibility pop
 #endif

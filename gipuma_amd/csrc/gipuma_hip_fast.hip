@@ -5,7 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #define PM_APPROX 1
-#define GIPUMA_HIP_FAST_TU 1
+#define GIPUMA_HIP_FLAVOUR_TU 1
 #define pm pm_fast
 #define gipuma_hip_session gipuma_hipf_session
 #define gipuma_hip_version gipuma_hipf_version

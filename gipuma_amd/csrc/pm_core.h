@@ -24,6 +24,17 @@
 #ifndef PM_APPROX
 #define PM_APPROX 0
 #endif
+// PM_LITERAL = 1 builds the REFERENCE-ORDER flavour (GIPUMA_HIP_FLAG_LITERAL, gipuma_hip_literal.hip): the per-sample
+// arithmetic of the patch cost in the literal operation order of the reference's source -- one bilinear fetch per tap at the
+// coordinates gipuma.cu:251-253 writes, x / z and y / z as IEEE divisions (config.h:44-47), H*(x, y, 1), dis and the cost
+// accumulation as unfused multiply-adds (config.h:150-162, gipuma.cu:272-274, 672) -- instead of the numerical model's
+// M1-M3.  Everything else already is the reference's order.  Its results equal the reference's OWN code
+// (compiled for the CPU with fp32 filter weights: the test infrastructure's _ref build) in every bit, at several times the
+// exact flavour's cost: a validation mode.  The host
+// forces the generic kernels (float planes, runtime-sized window); see view_cost_loop.
+#ifndef PM_LITERAL
+#define PM_LITERAL 0
+#endif
 
 namespace pm {
 
@@ -574,6 +585,25 @@ __device__ __forceinline__ Taps taps_u8(float a, float b, uint32_t w0, uint32_t 
     return taps12(a, b, ub0(w1), ub0(w2), ub1(w0), ub1(w1), ub1(w2), ub1(w3), ub2(w0), ub2(w1), ub2(w2),
                   ub2(w3), ub3(w1), ub3(w2));
 }
+
+#if PM_LITERAL
+// tex2D<float>(tex, x, y) with cudaFilterModeLinear on unnormalised coordinates and clamp addressing (main.cpp:641-648),
+// fp32 filter weights: xB = x - 0.5, i = floor(xB), a = xB - i, the four texels blended by fmaf lerps -- the texture model
+// of the reference-on-CPU build the tests compare with (its ref_tex_channel) and of the CPU restatement's literal flavour
+__device__ __forceinline__ float tex2d_literal(gptr_f32 img, int rows, int cols, int pitch, float x, float y)
+{
+    const float xb = x - 0.5f, yb = y - 0.5f;
+    const float fx = __builtin_floorf(xb), fy = __builtin_floorf(yb);
+    const float a = xb - fx, b = yb - fy;
+    const int ix = (int)__builtin_fminf(__builtin_fmaxf(fx, -2.0f), (float)cols);
+    const int iy = (int)__builtin_fminf(__builtin_fmaxf(fy, -2.0f), (float)rows);
+    const int c0 = clampi(ix, 0, cols - 1), c1 = clampi(ix + 1, 0, cols - 1);
+    const int r0 = clampi(iy, 0, rows - 1) * pitch, r1 = clampi(iy + 1, 0, rows - 1) * pitch;
+    const float t00 = img[r0 + c0], t10 = img[r0 + c1], t01 = img[r1 + c0], t11 = img[r1 + c1];
+    const float v0 = __builtin_fmaf(a, t10 - t00, t00), v1 = __builtin_fmaf(a, t11 - t01, t01);
+    return __builtin_fmaf(b, v1 - v0, v0);
+}
+#endif
 
 // colour (float4 texels: B, G, R, unused): V3[Y][X][c], c = 0..2 -- the window of all three
 // channels is 12 consecutive words (word 3k+c = column X+k, channel c): three dwordx4 loads

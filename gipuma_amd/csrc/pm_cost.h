@@ -58,6 +58,42 @@ __device__ __forceinline__ float view_cost_loop(const Problem *__restrict__ P, c
     const gptr_bytes magic_base = (gptr_bytes)((uintptr_t)packed - (uintptr_t)kMagicBits);
     const char *lut_magic = (const char *)lut - kMagicBits;
     float cost = 0.0f;
+#if PM_LITERAL
+    if constexpr (!U8) {
+        // The reference's own operation order (pmCost_shared, gipuma.cu:633-676; getCorrespondingPoint_cu :207-217;
+        // pmCostComputation_shared :251-274), what the CPU restatement computes in its literal flavour 7 and the
+        // reference's code compiled for the CPU computes: bit for bit the same planes and costs.  Float planes only (the host
+        // forces them: the U8 instantiations of this flavour are never launched); -ffp-contract=off keeps every multiply-add
+        // unfused.
+        for (int i = -hr; i <= hr; i += 2) {
+            for (int j = -vr; j <= vr; j += 2) {
+                const float4 t4 = *reinterpret_cast<const float4 *>(tp0 + 4 * (j * tw + i));
+                const float leftValue = t4.x;
+                const float colorDis = __builtin_fabsf(leftValue - centre);
+                const float w = exp_model(-colorDis / gamma);  // weight_cu, :186-193
+                const float qxf = (float)(px + i), qyf = (float)(py + j);
+                // matvecmul4noz, config.h:150-162, then vecdiv4, :44-47
+                const float X = H[0] * qxf + H[1] * qyf + H[2];
+                const float Y = H[3] * qxf + H[4] * qyf + H[5];
+                const float Z = H[6] * qxf + H[7] * qyf + H[8];
+                const float sx = X / Z, sy = Y / Z;
+                // gipuma.cu:251-253, the argument expressions as written
+                const float gx2 = tex2d_literal(img, rows, cols, pitch, sx + 1 + 0.5f, sy + 0.5f) -
+                                  tex2d_literal(img, rows, cols, pitch, sx - 1 + 0.5f, sy + 0.5f);
+                const float gy2 = tex2d_literal(img, rows, cols, pitch, sx + 0.5f, sy + 1 + 0.5f) -
+                                  tex2d_literal(img, rows, cols, pitch, sx + 0.5f, sy - 1 + 0.5f);
+                const float colDiff = __builtin_fabsf(leftValue - tex2d_literal(img, rows, cols, pitch, sx + 0.5f, sy + 0.5f));
+                const float gradX = t4.y - gx2;  // (right - left) - gx2: the tile holds the central differences
+                const float gradY = t4.z - gy2;
+                const float gradDis = __builtin_fminf((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
+                const float colDis = __builtin_fminf(colDiff, tau_color);
+                const float dis = (1.f - alpha) * colDis + alpha * gradDis;  // :272
+                cost = cost + w * dis;                                      // :274, :672
+            }
+        }
+        return cost;
+    }
+#endif
     // (float)(px + i) == (float)px + (float)i exactly (small integers): full-rate adds, no cvt
     float qx = (float)(px - hr);
     for (int i = -hr; i <= hr; i += 2, qx += 2.0f) {

@@ -189,32 +189,32 @@ def _fptr(a):
 
 
 class _mode:
-    """`with _mode(gs, fast)`: the descriptor carries GIPUMA_HIP_FLAG_FAST for the calls inside (the library reads the
-    flags when it creates the session)"""
+    """`with _mode(gs, fast, literal)`: the descriptor carries GIPUMA_HIP_FLAG_FAST / _LITERAL for the calls inside (the
+    library reads the flags when it creates the session)"""
 
-    def __init__(self, gs, fast):
-        self.gs, self.fast = gs, fast
+    def __init__(self, gs, fast, literal=False):
+        self.gs, self.fast, self.literal = gs, fast, literal
 
     def __enter__(self):
         self.keep = self.gs.desc.flags
-        if self.fast:
-            self.gs.desc.flags = self.keep | abi.FLAG_FAST
+        self.gs.desc.flags = self.keep | (abi.FLAG_FAST if self.fast else 0) | (abi.FLAG_LITERAL if self.literal else 0)
 
     def __exit__(self, *a):
         self.gs.desc.flags = self.keep
 
 
-def runcuda(gs, timing=False, fast=False):
+def runcuda(gs, timing=False, fast=False, literal=False):
     """The reference's ``int runcuda(GlobalState&)`` (gipuma.h:2) on the HIP path.
 
     Returns (norm4, cost[, Timing]): norm4[y, x] = (n_world.xyz, depth), cost[y, x], as the
     reference leaves them in gs.lines (gipuma.cu:1080-1103, main.cpp:976-985).  `fast`: the tolerance-judged
-    flavour of the kernels (GIPUMA_HIP_FLAG_FAST) instead of the bit-exact one."""
+    flavour of the kernels (GIPUMA_HIP_FLAG_FAST) instead of the bit-exact one; `literal`: the reference-order flavour
+    (GIPUMA_HIP_FLAG_LITERAL: bit-identical to the reference's own code, slow)."""
     lib = abi.load_library()
     norm4 = np.empty((gs.rows, gs.cols, 4), dtype=np.float32)
     cost = np.empty((gs.rows, gs.cols), dtype=np.float32)
     t = abi.Timing()
-    with _mode(gs, fast):
+    with _mode(gs, fast, literal):
         rc = lib.gipuma_hip_run(C.byref(gs.desc), _fptr(norm4), _fptr(cost), C.byref(t))
     abi.check(lib, rc, "gipuma_hip_run")
     return (norm4, cost, t) if timing else (norm4, cost)
@@ -224,12 +224,12 @@ class Session:
     """One reference view resident on the GPU: the launches of gipuma<T>() (gipuma.cu:1825-1960)
     one call at a time."""
 
-    def __init__(self, gs, fast=False):
+    def __init__(self, gs, fast=False, literal=False):
         self.lib = abi.load_library()
         self.gs = gs
-        self.fast = fast
+        self.fast, self.literal = fast, literal
         self.h = C.c_void_p()
-        with _mode(gs, fast):
+        with _mode(gs, fast, literal):
             rc = self.lib.gipuma_hip_create(C.byref(gs.desc), C.byref(self.h))
         abi.check(self.lib, rc, "gipuma_hip_create")
 

@@ -107,6 +107,14 @@ typedef struct gipuma_hip_params {
  * with the exact mode's like the reference's own code does (fraction of pixels inside 1e-4 relative depth / 1e-3 normal:
  * tests/test_fast_mode.py), not bit for bit. */
 #define GIPUMA_HIP_FLAG_FAST 8u
+/* Mode flag: the REFERENCE-ORDER flavour.  The per-sample arithmetic of the patch cost in the literal operation order of the
+ * reference's source -- one bilinear fetch per tap at the coordinates gipuma.cu:251-253 writes, IEEE x/z and y/z
+ * (config.h:44-47), unfused multiply-adds (config.h:150-162, gipuma.cu:272-274, 672) -- instead of the numerical model's
+ * cheaper forms.  Results equal the reference's OWN device code (compiled for the CPU with fp32 texture-filter
+ * weights, oracle/_ref; tests/golden/ref_*.npz) in every bit of every plane and cost; several times slower than the default
+ * mode (float planes, five gathers of four texels per sample, none of the work-sharing kernels): a validation mode.  Gray
+ * (channels == 1) only; excludes GIPUMA_HIP_FLAG_FAST. */
+#define GIPUMA_HIP_FLAG_LITERAL 16u
 
 /* Everything runcuda() reads out of GlobalState (globalstate.h:24-45). */
 typedef struct gipuma_hip_desc {

@@ -1,0 +1,101 @@
+"""GIPUMA_HIP_FLAG_LITERAL (include/gipuma_hip.h): the reference-order flavour of the kernels.  Its results must equal the
+reference's OWN device code -- /root/reference/gipuma.cu compiled for the CPU with fp32 texture-filter weights (oracle/_ref,
+which travels with the snapshot; its committed outputs tests/golden/ref_*.npz where it does not) -- in EVERY bit of every plane
+and every cost, launch by launch and free-running, and the oracle's literal flavour 7 likewise."""
+import numpy as np
+import pytest
+
+from gipuma_amd import abi, synth
+from gipuma_amd.problem import Session, runcuda
+from tests import oracle_lib, ref_lib
+from tests.oracle_lib import OracleState
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("fixture", ["ref_tiny64", "ref_box15"])
+def test_literal_mode_reproduces_the_reference_s_golden_dumps(hip, fixture):
+    """tests/golden/*.npz: what the reference's own code produced (scripts/make_ref_golden.py) -- initial planes and costs,
+    the state after the first black launches, the final maps: all bit-identical"""
+    from tests.test_oracle_vs_ref import golden_problem
+    gs, g = golden_problem(fixture)
+    with Session(gs, literal=True) as s:
+        s.init_planes()
+        n4, c = s.get_state()
+        assert np.array_equal(bits(n4), bits(g["init_norm4"]))
+        assert np.array_equal(bits(c), bits(g["init_cost"]))
+        s.sweep(0, abi.BLACK)
+        b4, bc = s.get_state()
+        assert np.array_equal(bits(b4), bits(g["black0_norm4"]))
+        assert np.array_equal(bits(bc), bits(g["black0_cost"]))
+    f4, fc = runcuda(gs, literal=True)
+    assert np.array_equal(bits(f4), bits(g["final_norm4"]))
+    assert np.array_equal(bits(fc), bits(g["final_cost"]))
+
+
+@pytest.mark.parametrize("cfg,over", [("A", dict(cols=128, rows=96)), ("B", dict(cols=160, rows=128)),
+                                      ("C", dict(cols=96, rows=64, iterations=3)),
+                                      ("C", dict(cols=320, rows=256))])
+def test_literal_mode_equals_the_reference_s_own_code_live(hip, cfg, over):
+    """free-running solves with the BASELINE configurations' parameters against oracle/_ref run on the box's CPU: every
+    plane and every cost bit for bit (config C's parameters on 320x256: 10 views, box 15, 8 iterations, 81 920 pixels)"""
+    if not ref_lib.available():
+        pytest.skip("oracle/_ref not built (needs the reference tree at build time)")
+    gs, _ = synth.build_problem(cfg, **over)
+    rn, rc = ref_lib.RefState(gs, tex_mode=0).run()
+    n4, c = runcuda(gs, literal=True)
+    assert np.array_equal(bits(n4), bits(rn))
+    assert np.array_equal(bits(c), bits(rc))
+
+
+def test_literal_mode_equals_the_oracle_s_literal_flavour(hip):
+    """... and the oracle's flavour 7 (gipuma_oracle_set_flavour), on a ragged frame the reference's 32-pixel tiles cannot
+    run, launch by launch: the two restatements of the reference's order agree where the reference itself cannot be asked"""
+    gs, _ = synth.build_problem(synth.tiny_config(cols=150, rows=100, n_src=4, blocksize=11, iterations=2, n_best=3))
+    L = oracle_lib.lib()
+    L.gipuma_oracle_set_flavour(7)
+    try:
+        o = OracleState(gs)
+        with Session(gs, literal=True) as s:
+            o.init_planes()
+            s.init_planes()
+            for it in range(2):
+                for colour in (abi.BLACK, abi.RED):
+                    o.sweep(it, colour)
+                    s.sweep(it, colour)
+                    n4, c = s.get_state()
+                    assert np.array_equal(bits(n4), bits(o.norm4)), (it, colour)
+                    assert np.array_equal(bits(c), bits(o.cost)), (it, colour)
+            o.finalize()
+            s.finalize()
+            n4, c = s.get_state()
+            assert np.array_equal(bits(n4), bits(o.norm4))
+    finally:
+        L.gipuma_oracle_set_flavour(0)
+
+
+def test_literal_mode_boundaries(hip, tiny_problem):
+    """colour and the combination with the fast flag are refused with an error, not run in another mode; an exact session
+    beside a literal one is unaffected"""
+    import ctypes as C
+    gs, _ = tiny_problem
+    lib = abi.load_library()
+    h = C.c_void_p()
+    keep = gs.desc.flags
+    try:
+        gs.desc.flags = keep | abi.FLAG_FAST | abi.FLAG_LITERAL
+        assert lib.gipuma_hip_create(C.byref(gs.desc), C.byref(h)) == abi.ERR_ARG
+    finally:
+        gs.desc.flags = keep
+    gc, _ = synth.build_problem(synth.tiny_config(), colour=True)
+    with pytest.raises(abi.GipumaHipError):
+        Session(gc, literal=True)
+    on, oc = OracleState(gs).run()
+    with Session(gs, literal=True) as s:
+        s.solve(timing=False)
+        n4, c = runcuda(gs)
+    assert np.array_equal(bits(n4), bits(on)) and np.array_equal(bits(c), bits(oc))
