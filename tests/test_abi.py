@@ -127,3 +127,18 @@ def test_product_never_touches_the_oracle():
     if os.path.exists(so):
         needed = subprocess.check_output(["readelf", "-d", so]).decode()
         assert "oracle" not in needed
+
+
+def test_flag_constants_match_the_header_and_the_other_flavours_are_not_exported():
+    """the bindings' GIPUMA_HIP_FLAG_* values are the header's; the library's dynamic symbol table holds the declared C-ABI
+    only -- the entry points of the tolerance-judged and reference-order flavours (gipuma_hipf_*, gipuma_hipl_*, reached
+    through GIPUMA_HIP_FLAG_FAST / _LITERAL) have hidden visibility"""
+    src = open(HEADER).read()
+    flags = {k: int(v) for k, v in re.findall(r"#define\s+GIPUMA_HIP_FLAG_([A-Z_]+)\s+(\d+)u", src)}
+    assert flags == {"IMAGES_ON_DEVICE": abi.FLAG_IMAGES_ON_DEVICE, "UNFUSED": abi.FLAG_UNFUSED,
+                     "CACHE_IMAGES": abi.FLAG_CACHE_IMAGES, "FAST": abi.FLAG_FAST, "LITERAL": abi.FLAG_LITERAL}
+    assert len(set(flags.values())) == len(flags) and all(v & (v - 1) == 0 for v in flags.values())
+    out = subprocess.check_output(["nm", "-D", "--defined-only", abi.LIB_PATH]).decode()
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    c_abi = {e for e in exported if e.startswith("gipuma_hip")}
+    assert c_abi == {name for name, _, _ in abi.SYMBOLS}, c_abi ^ {name for name, _, _ in abi.SYMBOLS}
