@@ -646,20 +646,22 @@ def main():
                         "(pm_core.h PM_APPROX); judged by tolerance, not bit-exact"}
             # (a'') GIPUMA_HIP_FLAG_LITERAL: the reference-order flavour -- bit-identical to the reference's own code
             #       (tests/test_literal_mode.py), a validation mode -- and how far the exact mode's maps are from it
-            with Session(gs, literal=True) as sl:
-                sl.solve(timing=True)
-                tl = sl.solve(timing=True)
-                n4l, _ = sl.get_state()
-            d_rel = np.abs(n4e[..., 3] - n4l[..., 3]) / np.maximum(np.abs(n4l[..., 3]), 1e-30)
-            n_err = np.abs(n4e[..., :3] - n4l[..., :3]).max(-1)
-            out["value_literal"] = {
-                "value": n_pix / (tl.ms_total * 1e-3) / 1e6, "unit": "Mpix/s", "ms_per_step": float(tl.ms_total),
-                "exact_mode_vs_this": {"frac_within_tolerance": float(((d_rel < 1e-4) & (n_err < 1e-3)).mean()),
-                                       "frac_bit_identical_planes": float((n4e.view(np.uint32) == n4l.view(np.uint32)).all(-1).mean())},
-                "what": "session created with GIPUMA_HIP_FLAG_LITERAL: the per-sample arithmetic in the reference's own operation "
-                        "order (one bilinear fetch per tap, IEEE divisions, unfused multiply-adds) on float planes through the "
-                        "generic kernels; equals the reference's own code bit for bit; `exact_mode_vs_this` is therefore the "
-                        "exact mode's distance from the reference on this frame"}
+            n4l = None
+            if not args.colour:  # (gray only: the flag is refused for T = float4)
+                with Session(gs, literal=True) as sl:
+                    sl.solve(timing=True)
+                    tl = sl.solve(timing=True)
+                    n4l, _ = sl.get_state()
+                d_rel = np.abs(n4e[..., 3] - n4l[..., 3]) / np.maximum(np.abs(n4l[..., 3]), 1e-30)
+                n_err = np.abs(n4e[..., :3] - n4l[..., :3]).max(-1)
+                out["value_literal"] = {
+                    "value": n_pix / (tl.ms_total * 1e-3) / 1e6, "unit": "Mpix/s", "ms_per_step": float(tl.ms_total),
+                    "exact_mode_vs_this": {"frac_within_tolerance": float(((d_rel < 1e-4) & (n_err < 1e-3)).mean()),
+                                           "frac_bit_identical_planes": float((n4e.view(np.uint32) == n4l.view(np.uint32)).all(-1).mean())},
+                    "what": "session created with GIPUMA_HIP_FLAG_LITERAL: the per-sample arithmetic in the reference's own operation "
+                            "order (one bilinear fetch per tap, IEEE divisions, unfused multiply-adds) on float planes through the "
+                            "generic kernels; equals the reference's own code bit for bit; `exact_mode_vs_this` is therefore the "
+                            "exact mode's distance from the reference on this frame"}
             del n4f, cf, n4e, ce, d_rel, n_err, n4l
             # (b) a scene with depth discontinuities, an occluder and sensor noise
             if args.scene == "smooth":

@@ -33,6 +33,12 @@ def lib():
         L.ref_plane_d.argtypes = [_FP, C.c_int, C.c_int, C.c_float]
         L.ref_plane_d.restype = C.c_float
         L.ref_view_vector.argtypes = [C.c_int, C.c_int, _FP]
+        # the blocks of a launch run under OpenMP: as many threads as the box GRANTS (its cgroup quota), not as many as it
+        # shows -- the GPU box shows 256 hardware threads and grants the time of 16
+        if "OMP_NUM_THREADS" not in os.environ and hasattr(L, "ref_set_threads"):
+            from tests.oracle_lib import _granted_cores
+            L.ref_set_threads.argtypes = [C.c_int]
+            L.ref_set_threads(_granted_cores())
         _lib = L
     return _lib
 
