@@ -647,7 +647,7 @@ def main():
             # (a'') GIPUMA_HIP_FLAG_LITERAL: the reference-order flavour -- bit-identical to the reference's own code
             #       (tests/test_literal_mode.py), a validation mode -- and how far the exact mode's maps are from it
             n4l = None
-            if not args.colour:  # (gray only: the flag is refused for T = float4)
+            if True:
                 with Session(gs, literal=True) as sl:
                     sl.solve(timing=True)
                     tl = sl.solve(timing=True)

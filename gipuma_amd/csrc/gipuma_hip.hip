@@ -606,12 +606,7 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         return 0;
     }
 #endif
-#if PM_LITERAL
-    if (d->channels != 1) {
-        delete s;
-        return fail(GIPUMA_HIP_ERR_UNSUPPORTED, "GIPUMA_HIP_FLAG_LITERAL: gray (T = float) only");
-    }
-#endif
+
     // from here on, destroy() cleans up whatever was built.  The image cache is locked while this call looks at /
     // adds entries; a failure inside that region first takes back the packed planes this call put into the cache
     // (never verified), then UNLOCKS -- destroy() takes the same non-recursive mutex to give the use counts back.

@@ -590,6 +590,8 @@ __device__ __forceinline__ Taps taps_u8(float a, float b, uint32_t w0, uint32_t 
 // tex2D<float>(tex, x, y) with cudaFilterModeLinear on unnormalised coordinates and clamp addressing (main.cpp:641-648),
 // fp32 filter weights: xB = x - 0.5, i = floor(xB), a = xB - i, the four texels blended by fmaf lerps -- the texture model
 // of the reference-on-CPU build the tests compare with (its ref_tex_channel) and of the CPU restatement's literal flavour
+// (STRIDE floats per texel: 1 for gray planes, 4 for float4 texels -- tex2D<float4> filters every component alike)
+template <int STRIDE = 1>
 __device__ __forceinline__ float tex2d_literal(gptr_f32 img, int rows, int cols, int pitch, float x, float y)
 {
     const float xb = x - 0.5f, yb = y - 0.5f;
@@ -597,7 +599,7 @@ __device__ __forceinline__ float tex2d_literal(gptr_f32 img, int rows, int cols,
     const float a = xb - fx, b = yb - fy;
     const int ix = (int)__builtin_fminf(__builtin_fmaxf(fx, -2.0f), (float)cols);
     const int iy = (int)__builtin_fminf(__builtin_fmaxf(fy, -2.0f), (float)rows);
-    const int c0 = clampi(ix, 0, cols - 1), c1 = clampi(ix + 1, 0, cols - 1);
+    const int c0 = STRIDE * clampi(ix, 0, cols - 1), c1 = STRIDE * clampi(ix + 1, 0, cols - 1);
     const int r0 = clampi(iy, 0, rows - 1) * pitch, r1 = clampi(iy + 1, 0, rows - 1) * pitch;
     const float t00 = img[r0 + c0], t10 = img[r0 + c1], t01 = img[r1 + c0], t11 = img[r1 + c1];
     const float v0 = __builtin_fmaf(a, t10 - t00, t00), v1 = __builtin_fmaf(a, t11 - t01, t01);

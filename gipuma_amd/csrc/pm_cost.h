@@ -427,6 +427,50 @@ __device__ __forceinline__ float view_cost_c4_loop(const Problem *__restrict__ P
     const float4 centre = *reinterpret_cast<const float4 *>(tp0);
     const int hr = win.hrad(), vr = win.vrad();
     float cost = cost0;
+#if PM_LITERAL
+    if constexpr (!U8) {
+        // T = float4 in the reference's own operation order (see view_cost_loop): per channel one bilinear fetch per tap,
+        // l1_norm(float4) = (|x| + |y| + |z|) * 0.3333333f (gipuma.cu:174-179), the float4 operators of vector_operations.h
+        (void)c0; (void)c1; (void)cols_run; (void)tau;
+        const float alpha = P->alpha;
+        for (int i = -hr; i <= hr; i += 2) {
+            for (int j = -vr; j <= vr; j += 2) {
+                const float *tp = tp0 + 4 * (j * tw + i);
+                const float4 lv = *reinterpret_cast<const float4 *>(tp);
+                const float w = exp_model(-l1_3(lv.x - centre.x, lv.y - centre.y, lv.z - centre.z) / gamma);
+                const float qxf = (float)(px + i), qyf = (float)(py + j);
+                const float X = H[0] * qxf + H[1] * qyf + H[2];
+                const float Y = H[3] * qxf + H[4] * qyf + H[5];
+                const float Z = H[6] * qxf + H[7] * qyf + H[8];
+                const float sx = X / Z, sy = Y / Z;
+                const float4 up = *reinterpret_cast<const float4 *>(tp - 4 * tw);
+                const float4 down = *reinterpret_cast<const float4 *>(tp + 4 * tw);
+                const float4 left = *reinterpret_cast<const float4 *>(tp - 4);
+                const float4 right = *reinterpret_cast<const float4 *>(tp + 4);
+                const float lvc[3] = {lv.x, lv.y, lv.z};
+                const float gx1[3] = {right.x - left.x, right.y - left.y, right.z - left.z};
+                const float gy1[3] = {down.x - up.x, down.y - up.y, down.z - up.z};
+                float cd[3], gX[3], gY[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float gx2 = tex2d_literal<4>(img + c, rows, cols, pitch, sx + 1 + 0.5f, sy + 0.5f) -
+                                      tex2d_literal<4>(img + c, rows, cols, pitch, sx - 1 + 0.5f, sy + 0.5f);
+                    const float gy2 = tex2d_literal<4>(img + c, rows, cols, pitch, sx + 0.5f, sy + 1 + 0.5f) -
+                                      tex2d_literal<4>(img + c, rows, cols, pitch, sx + 0.5f, sy - 1 + 0.5f);
+                    cd[c] = lvc[c] - tex2d_literal<4>(img + c, rows, cols, pitch, sx + 0.5f, sy + 0.5f);
+                    gX[c] = gx1[c] - gx2;
+                    gY[c] = gy1[c] - gy2;
+                }
+                const float colDiff = l1_3(cd[0], cd[1], cd[2]);
+                const float gradDis = __builtin_fminf((l1_3(gX[0], gX[1], gX[2]) + l1_3(gY[0], gY[1], gY[2])) * 0.0625f, P->tau_gradient);
+                const float colDis = __builtin_fminf(colDiff, tau_color);
+                const float dis = (1.f - alpha) * colDis + alpha * gradDis;
+                cost = cost + w * dis;
+            }
+        }
+        return cost;
+    }
+#endif
     float qx = (float)(px - hr + 2 * c0);
     int col = c0;
     for (int i = -hr + 2 * c0; i <= hr && col < c1; i += 2, qx += 2.0f) {

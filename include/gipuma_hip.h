@@ -112,8 +112,9 @@ typedef struct gipuma_hip_params {
  * (config.h:44-47), unfused multiply-adds (config.h:150-162, gipuma.cu:272-274, 672) -- instead of the numerical model's
  * cheaper forms.  Results equal the reference's OWN device code (compiled for the CPU with fp32 texture-filter
  * weights, oracle/_ref; tests/golden/ref_*.npz) in every bit of every plane and cost; several times slower than the default
- * mode (float planes, five gathers of four texels per sample, none of the work-sharing kernels): a validation mode.  Gray
- * (channels == 1) only; excludes GIPUMA_HIP_FLAG_FAST. */
+ * mode (float planes, five gathers of four texels per sample, none of the work-sharing kernels): a validation mode.  Gray and
+ * colour (T = float4: the reference's float4 operators and l1_norm, vector_operations.h, gipuma.cu:174-179); excludes
+ * GIPUMA_HIP_FLAG_FAST. */
 #define GIPUMA_HIP_FLAG_LITERAL 16u
 
 /* Everything runcuda() reads out of GlobalState (globalstate.h:24-45). */

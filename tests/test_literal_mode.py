@@ -78,9 +78,23 @@ def test_literal_mode_equals_the_oracle_s_literal_flavour(hip):
         L.gipuma_oracle_set_flavour(0)
 
 
+@pytest.mark.parametrize("cfg", [dict(cols=96, rows=64, n_src=3, blocksize=9, iterations=2, n_best=2),
+                                 dict(cols=128, rows=96, n_src=4, blocksize=15, iterations=3, n_best=3)])
+def test_literal_mode_colour_equals_the_reference_s_float4_instantiation(hip, cfg):
+    """-color_processing: the reference's T = float4 kernels (gipuma.cu:1965-1968; tex2D<float4>, the float4 operators of
+    vector_operations.h, l1_norm(float4)) run on the CPU against the literal flavour: every plane and cost bit for bit"""
+    if not ref_lib.available():
+        pytest.skip("oracle/_ref not built (needs the reference tree at build time)")
+    gs, _ = synth.build_problem(synth.tiny_config(**cfg), colour=True)
+    rn, rc = ref_lib.RefState(gs, tex_mode=0).run()
+    n4, c = runcuda(gs, literal=True)
+    assert np.array_equal(bits(n4), bits(rn))
+    assert np.array_equal(bits(c), bits(rc))
+
+
 def test_literal_mode_boundaries(hip, tiny_problem):
-    """colour and the combination with the fast flag are refused with an error, not run in another mode; an exact session
-    beside a literal one is unaffected"""
+    """the combination with the fast flag is refused with an error, not run in another mode; an exact session beside a
+    literal one is unaffected"""
     import ctypes as C
     gs, _ = tiny_problem
     lib = abi.load_library()
@@ -91,9 +105,6 @@ def test_literal_mode_boundaries(hip, tiny_problem):
         assert lib.gipuma_hip_create(C.byref(gs.desc), C.byref(h)) == abi.ERR_ARG
     finally:
         gs.desc.flags = keep
-    gc, _ = synth.build_problem(synth.tiny_config(), colour=True)
-    with pytest.raises(abi.GipumaHipError):
-        Session(gc, literal=True)
     on, oc = OracleState(gs).run()
     with Session(gs, literal=True) as s:
         s.solve(timing=False)
