@@ -595,6 +595,7 @@ def main():
             from gipuma_amd.problem import GlobalState, runcuda
             # (a) the same workload with every exact work-reduction switched off (skip rules A/D/H, early
             #     termination): what a scene that defeats them would cost
+            print("bench.py: extra leg -- exhaustive schedule", file=sys.stderr, flush=True)
             exp_before = os.environ.get("GIPUMA_HIP_EXPERIMENTS")
             os.environ["GIPUMA_HIP_EXPERIMENTS"] = "1"  # (the library reads its A/B switches only under this one)
             os.environ["GIPUMA_HIP_TUNE"] = str(64 | (1 << 23) | (1 << 25))
@@ -620,6 +621,7 @@ def main():
                     del os.environ["GIPUMA_HIP_EXPERIMENTS"]
                 else:
                     os.environ["GIPUMA_HIP_EXPERIMENTS"] = exp_before
+            print("bench.py: extra leg -- fast mode", file=sys.stderr, flush=True)
             # (a') GIPUMA_HIP_FLAG_FAST: the tolerance-judged flavour of the same kernels (include/gipuma_hip.h) on the same
             #      frames, with its agreement with the exact mode's final maps of the timed solve -- the fraction of pixels
             #      inside the north_star tolerance (depth 1e-4 relative, unit normal 1e-3), the way the reference's own
@@ -644,6 +646,7 @@ def main():
                 "what": "same frames and schedule, session created with GIPUMA_HIP_FLAG_FAST: v_rcp_f32 without the Newton "
                         "step, homography from host-folded per-view products, reassociated bilinear taps, tree sums "
                         "(pm_core.h PM_APPROX); judged by tolerance, not bit-exact"}
+            print("bench.py: extra leg -- reference-order mode", file=sys.stderr, flush=True)
             # (a'') GIPUMA_HIP_FLAG_LITERAL: the reference-order flavour -- bit-identical to the reference's own code
             #       (tests/test_literal_mode.py), a validation mode -- and how far the exact mode's maps are from it
             n4l = None
@@ -663,10 +666,11 @@ def main():
                             "generic kernels; equals the reference's own code bit for bit; `exact_mode_vs_this` is therefore the "
                             "exact mode's distance from the reference on this frame"}
             del n4f, cf, n4e, ce, d_rel, n_err, n4l
+            print("bench.py: extra leg -- scene with depth steps", file=sys.stderr, flush=True)
             # (b) a scene with depth discontinuities, an occluder and sensor noise
-            if args.scene == "smooth":
+            if args.scene == "smooth" and not args.colour:  # (the stepped scene is rendered in gray only)
                 gs3, info3 = synth.build_problem(args.config, ref_view=ref_view, device=dev, keep_on_device=True,
-                                                 colour=args.colour, scene="steps", **over)
+                                                 scene="steps", **over)
                 gs3.desc.device_id = dev_index
                 with Session(gs3) as s3:
                     s3.solve(timing=True)
@@ -677,6 +681,7 @@ def main():
                                             "what": "same cameras and parameters, scene with +-30 mm depth steps, a raised "
                                                     "disc (occlusions) and sigma=2 sensor noise"}
                 del gs3, info3
+            print("bench.py: extra leg -- patchy scene", file=sys.stderr, flush=True)
             # (c) the smooth geometry with the texture taken away where real scans lose it: 30 % of the surface
             #     with a flat albedo (costs tie, bounds hold less often) and a periodic stripe band
             if args.scene == "smooth" and not args.colour:
@@ -693,6 +698,7 @@ def main():
                                                      "with a flat albedo, a diagonal band with a periodic stripe texture "
                                                      "(period 6 px), sigma=1 sensor noise"}
                 del gs4, info4
+            print("bench.py: extra leg -- views in flight", file=sys.stderr, flush=True)
             # (d) throughput of a batch runner that keeps several reference views in flight on one GPU: one
             #     session (= one HIP stream) per view, whole solves enqueued back to back, one host wait
             #     at the end.  Launch tails of one view fill with workgroups of another, and kernels bound
@@ -732,6 +738,7 @@ def main():
                                                     "in flight on this GPU (one session and stream each, solves "
                                                     "enqueued asynchronously); `value` is one view at a time")
                 del extra
+            print("bench.py: extra leg -- host boundary", file=sys.stderr, flush=True)
             # (c) the boundary as the reference's main.cpp uses it: host images in, host planes out
             #     (upload + window packing + solve + download); reported, never `value`
             gs_host = GlobalState([im.cpu().numpy() for im in gs.images], gs.cameras, gs.selected,

@@ -320,6 +320,10 @@ def build_problem(cfg, ref_view=15, scene_seed=1234, solver_seed=1, device="cpu"
         tilt = (0.04, -0.02)
     cs = get_camera_parameters(Ps, cam_scale=cam_scale)
     footprint = z0 / cs.f
+    if colour and scene != "smooth":
+        # (the stepped and patchy scenes are rendered by the marching renderer, which makes gray planes only: handing them to
+        #  a colour session would describe (rows, cols) planes as (rows, cols, 4) -- out-of-bounds reads on the device)
+        raise ValueError("scene %r is gray only; colour problems use the smooth scene" % scene)
     if scene == "steps":
         # depth steps + an occluding disc + sensor noise (gray only), in units of the scene depth
         u = z0 / 600.0

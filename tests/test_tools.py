@@ -36,3 +36,13 @@ def test_pmc_units_sums_all_matching_dispatches(tmp_path):
                                    str(tmp_path), "push_kernel"])
     res = json.loads(out)
     assert res["SQ_INSTS_VALU"] == 40.0 and res["_dispatches_per_counter"] == 2
+
+
+def test_gray_only_scenes_refuse_colour():
+    """the stepped and patchy scenes are rendered in gray; asking for them in colour must fail on the host instead of
+    describing (rows, cols) planes as float4 texels to the device (bench.py --colour found this the hard way)"""
+    import pytest
+    from gipuma_amd import synth
+    for scene in ("steps", "patchy"):
+        with pytest.raises(ValueError):
+            synth.build_problem(synth.tiny_config(), colour=True, scene=scene)
