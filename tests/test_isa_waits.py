@@ -95,3 +95,16 @@ def test_strip_loop_keeps_a_window_load_in_flight(asm, prefix, loads, depth):
 def test_no_flat_memory_instruction(asm):
     bad = [l.strip() for l in asm if re.match(r"\s+flat_(load|store|atomic)", l)]
     assert not bad, "%d flat accesses, e.g. %s" % (len(bad), bad[:3])
+
+
+@pytest.mark.parametrize("prefix", ["_ZN2pm11push_kernelILi15EE", "_ZN2pm11push_kernelILi25EE", "_ZN2pm17sweep_cols_kernelILi15ELb1ELi1EE",
+                                    "_ZN2pm17sweep_cols_kernelILi25ELb1ELi1EE", "_ZN2pm16init_cols_kernelILi15ELb1ELi1EE",
+                                    "_ZN2pm12group_kernelILi15ELi4EE"])
+def test_first_half_sweep_kernels_do_not_spill(asm, prefix):
+    """the kernels of the random-plane phase (push, column-per-lane, init) and the colour plane-keyed kernel hold everything
+    in registers: no scratch access and no scalar register spilled into a vector lane anywhere in their code.  (The fused
+    kernels -- sweep_kernel, sweep_group_kernel -- do spill: ~100 scalars into lanes and a few registers to scratch, outside
+    their sample loops)"""
+    k = kernel(asm, prefix)
+    assert not [l for l in k if re.match(r"\s+scratch_", l)], prefix
+    assert not [l for l in k if "v_writelane_b32" in l or "v_readlane_b32" in l], prefix
