@@ -71,3 +71,31 @@ def test_reference_main_cpp_compiles_unchanged_against_the_compat_layer():
     stub = open(os.path.join(ROOT, "tests", "stubs", "opencv2", "opencv_stub.hpp")).read()
     assert "TEST INFRASTRUCTURE" in stub
     assert "stubs" not in open(os.path.join(ROOT, "gipuma_amd", "csrc", "adapter", "build_adapter.sh")).read()
+
+
+@have
+@pytest.mark.gpu
+@pytest.mark.parametrize("colour", [False, True])
+def test_runcuda_in_the_reference_order_mode_equals_the_reference_s_own_code(hip, colour):
+    """the same call through the reference's structs with GIPUMA_LITERAL=1 in the environment (the adapter's way to select
+    GIPUMA_HIP_FLAG_LITERAL: GlobalState has no field for it): gs.lines holds, bit for bit, what the reference's OWN device
+    code (oracle/_ref, on the CPU, fp32 filter weights) leaves there -- the reference's signature, the reference's structs,
+    the reference's results"""
+    from tests import ref_lib
+    if not ref_lib.available():
+        pytest.skip("oracle/_ref not built (needs the reference tree at build time)")
+    lib = C.CDLL(SO, mode=C.RTLD_GLOBAL)
+    lib.gipuma_adapter_selftest.argtypes = [C.POINTER(abi.Desc), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    gs, _ = synth.build_problem(synth.tiny_config(cols=96, rows=64, n_src=3, blocksize=11, n_best=2), colour=colour)
+    n4 = np.zeros((gs.rows, gs.cols, 4), dtype=np.float32)
+    c = np.zeros((gs.rows, gs.cols), dtype=np.float32)
+    os.environ["GIPUMA_LITERAL"] = "1"
+    try:
+        rc = lib.gipuma_adapter_selftest(C.byref(gs.desc), n4.ctypes.data_as(C.POINTER(C.c_float)),
+                                         c.ctypes.data_as(C.POINTER(C.c_float)))
+    finally:
+        del os.environ["GIPUMA_LITERAL"]
+    assert rc == 0
+    rn, rc_ = ref_lib.RefState(gs, tex_mode=0).run()
+    assert np.array_equal(n4.view(np.uint32), rn.view(np.uint32))
+    assert np.array_equal(c.view(np.uint32), rc_.view(np.uint32))
