@@ -127,6 +127,10 @@ def main(argv=None):
     pa.add_argument("--seed", type=int, default=1)
     pa.add_argument("--in_flight", type=int, default=2,
                     help="reference views kept in flight per GPU (1: one at a time, with per-view device times)")
+    pa.add_argument("--mode", choices=["exact", "fast", "literal"], default="exact",
+                    help="exact: bit-identical to the numerical model (default); fast: tolerance-judged kernels "
+                         "(GIPUMA_HIP_FLAG_FAST); literal: the reference's own operation order, bit-identical to the "
+                         "reference's code, about 20x slower (GIPUMA_HIP_FLAG_LITERAL)")
     args = pa.parse_args(argv)
     # the reference parses these with sscanf("%f") into float fields (main.cpp:300-360)
     for k in ("cost_gamma", "depth_min", "depth_max", "min_angle", "max_angle", "cam_scale"):
@@ -197,7 +201,7 @@ def main(argv=None):
                              device_ptrs=[t.data_ptr() for t in imgs], rows=rows, cols=cols, device_id=dev_index,
                              flags=abi.FLAG_CACHE_IMAGES)
             tw0 = time.perf_counter()
-            s = Session(gs)
+            s = Session(gs, fast=args.mode == "fast", literal=args.mode == "literal")
             try:
                 if in_flight == 1:
                     t = s.solve(timing=True)

@@ -92,6 +92,14 @@ int parse_command_line(int argc, char **argv, InputFiles &in, OutputFiles &out, 
 #undef IOPT
         else if (starts(a, "--max_views=")) sscanf(val("--max_views="), "%u", &ap.max_views);
         else if (starts(a, "--seed=")) sscanf(val("--seed="), "%u", &ap.seed);  // extension
+        else if (starts(a, "--mode=")) {  // extension: the library's mode flags (default exact; the reference's own build
+                                          // choice is --use_fast_math, CMakeLists.txt:23)
+            const std::string m = val("--mode=");
+            if (m == "exact") ap.mode_flags = 0;
+            else if (m == "fast") ap.mode_flags = GIPUMA_HIP_FLAG_FAST;
+            else if (m == "literal") ap.mode_flags = GIPUMA_HIP_FLAG_LITERAL;
+            else { printf("--mode= takes exact, fast or literal\n"); return -1; }
+        }
         else if (starts(a, "--gtDepth_divisionFactor=")) sscanf(val("--gtDepth_divisionFactor="), "%f", &g.divFactor);
         else if (starts(a, "--gtDepth_tolerance2=")) sscanf(val("--gtDepth_tolerance2="), "%f", &g.dispTolGT2);
         else if (starts(a, "--gtDepth_tolerance=")) sscanf(val("--gtDepth_tolerance="), "%f", &g.dispTolGT);
@@ -971,6 +979,7 @@ int run_gipuma(const InputFiles &in, const OutputFiles &out, AlgorithmParameters
     d.params.min_disparity = ap.min_disparity; d.params.max_disparity = ap.max_disparity;
     d.params.good_factor = ap.good_factor;
     d.seed = ap.seed;
+    d.flags = ap.mode_flags;
     std::vector<float> norm4((size_t)rows * cols * 4), cost((size_t)rows * cols);
     gipuma_hip_timing t{};
     printf("Blocksize is %dx%d\n", ap.box_hsize, ap.box_vsize);

@@ -41,6 +41,7 @@ struct AlgorithmParameters {  // reference algorithmparameters.h:21-51 (defaults
     float no_texture_sim = 0.9f, no_texture_per = 0.6f;
     unsigned max_views = 9;
     unsigned seed = 1;  // extension: --seed=
+    unsigned mode_flags = 0;  // extension: --mode=exact|fast|literal -> GIPUMA_HIP_FLAG_FAST / _LITERAL (include/gipuma_hip.h)
 };
 
 struct InputFiles {  // reference main.h:39-54

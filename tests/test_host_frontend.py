@@ -183,8 +183,9 @@ def test_cli_without_gpu_fails_loudly(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("colour,png", [(False, False), (True, False), (False, True), (True, True)])
-def test_cli_end_to_end_dmb_matches_oracle(hip, tmp_path, colour, png):
+@pytest.mark.parametrize("colour,png,mode", [(False, False, None), (True, False, None), (False, True, None), (True, True, None),
+                                             (False, True, "literal")])
+def test_cli_end_to_end_dmb_matches_oracle(hip, tmp_path, colour, png, mode):
     """PGM / PPM / PNG + .P files in, disp.dmb / normals.dmb out, through the reference's flags; the oracle is
     fed the cameras the C++ front-end produced, so the dumps must match it bit for bit"""
     from tests.oracle_lib import OracleState
@@ -193,7 +194,8 @@ def test_cli_end_to_end_dmb_matches_oracle(hip, tmp_path, colour, png):
     ids = info["view_ids"]
     img_dir, p_dir, names = write_scene(tmp_path, gs, ids, png=png)
     out_dir = tmp_path / "out"
-    args = cli_args(cfg, img_dir, p_dir, names, out_dir) + (["-color_processing"] if colour else [])
+    args = cli_args(cfg, img_dir, p_dir, names, out_dir) + (["-color_processing"] if colour else []) + \
+        (["--mode=" + mode] if mode else [])  # (--mode=literal: the reference-order flavour, against the oracle's flavour 7)
     r = subprocess.run(args, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Total time needed for computation" in r.stdout
@@ -217,7 +219,12 @@ def test_cli_end_to_end_dmb_matches_oracle(hip, tmp_path, colour, png):
     f32 = np.float32
     gs2.desc.params.min_disparity = f32(cs.f) * f32(0.54) / f32(800.0)
     gs2.desc.params.max_disparity = f32(cs.f) * f32(0.54) / f32(300.0)
-    n4, c = OracleState(gs2).run()
+    from tests import oracle_lib
+    oracle_lib.lib().gipuma_oracle_set_flavour(7 if mode == "literal" else 0)
+    try:
+        n4, c = OracleState(gs2).run()
+    finally:
+        oracle_lib.lib().gipuma_oracle_set_flavour(0)
     assert np.array_equal(disp.view(np.uint32), n4[..., 3].view(np.uint32))
     assert np.array_equal(normals.view(np.uint32), np.ascontiguousarray(n4[..., :3]).view(np.uint32))
     assert np.array_equal(cost.view(np.uint32), c.view(np.uint32))
