@@ -310,8 +310,14 @@ static inline void go_taps3_s(const float *img, int rows, int cols, int pitch, i
     const int ix = (int)fminf(fmaxf(fx0, -2.0f), (float)cols);
     const int iy = (int)fminf(fmaxf(fy0, -2.0f), (float)rows);
     float t[4][4];
-    for (int r = 0; r < 4; r++)
-        for (int c = 0; c < 4; c++) t[r][c] = go_texel_s(img, rows, cols, pitch, stride, ix - 1 + c, iy - 1 + r);
+    if (ix >= 1 && ix <= cols - 3 && iy >= 1 && iy <= rows - 3) { /* (the whole window inside the image: no clamping; same texels) */
+        const float *p = img + (size_t)(iy - 1) * (size_t)pitch + (size_t)(ix - 1) * (size_t)stride;
+        for (int r = 0; r < 4; r++, p += pitch)
+            for (int c = 0; c < 4; c++) t[r][c] = p[c * stride];
+    } else {
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) t[r][c] = go_texel_s(img, rows, cols, pitch, stride, ix - 1 + c, iy - 1 + r);
+    }
     const float V0 = go_lerp(b, t[1][0], t[2][0]), V1 = go_lerp(b, t[1][1], t[2][1]);
     const float V2 = go_lerp(b, t[1][2], t[2][2]), V3 = go_lerp(b, t[1][3], t[2][3]);
     const float W1 = go_lerp(b, t[2][1] - t[0][1], t[3][1] - t[1][1]);
@@ -374,29 +380,97 @@ static inline float go_dis_at(const gipuma_hip_desc *d, int view, const float *H
     return fmaf(alpha, gradDis, oma * colDis);
 }
 
-static float go_view_cost(const gipuma_hip_desc *d, int view, int px, int py, const float pl[4])
+/* What a pixel's window contributes to EVERY hypothesis and view evaluated at that pixel -- the support weights
+ * (weight_cu, gipuma.cu:186-193) and the reference-side terms of pmCostComputation_shared (:254-259: the texel and its
+ * central differences) -- computed once per pixel visit instead of once per (hypothesis, view): 11 hypotheses x N views
+ * per half-sweep read them.  Same values, same operation order per sample: the results do not change by a bit; the oracle
+ * runs about twice as fast.  One cache per thread; `go_epoch` (bumped by every exported entry point) keeps a cache from
+ * outliving the images or parameters it was computed from. */
+#define GO_MAXWIN (25 * 25) /* box <= 49 */
+typedef struct {
+    const gipuma_hip_desc *d;
+    unsigned epoch;
+    int px, py;
+    float centre;
+    float w[GO_MAXWIN], I[GO_MAXWIN], gx1[GO_MAXWIN], gy1[GO_MAXWIN];
+} go_pixel_cache;
+static _Thread_local go_pixel_cache go_pc = {0, 0, -1, -1, 0.0f, {0}, {0}, {0}, {0}};
+static unsigned go_epoch = 1;
+#define GO_ENTER() (go_epoch++)
+
+static const go_pixel_cache *go_cache_for(const gipuma_hip_desc *d, int px, int py)
 {
+    go_pixel_cache *pc = &go_pc;
+    if (pc->d == d && pc->epoch == go_epoch && pc->px == px && pc->py == py) return pc;
     const gipuma_hip_params *ap = &d->params;
     const int rows = d->rows, cols = d->cols, pitch = d->pitch;
     const float *ref = d->images[0];
+    const int hRad = (ap->box_hsize - 1) / 2, vRad = (ap->box_vsize - 1) / 2;
+    const float gamma = ap->gamma;
+    pc->d = d;
+    pc->epoch = go_epoch;
+    pc->px = px;
+    pc->py = py;
+    pc->centre = go_texel(ref, rows, cols, pitch, px, py);
+    int k = 0;
+    for (int i = -hRad; i < hRad + 1; i += GO_WIN_INCREMENT) {
+        for (int j = -vRad; j < vRad + 1; j += GO_WIN_INCREMENT, k++) {
+            const int ix = px + i, iy = py + j;
+            const float leftValue = go_texel(ref, rows, cols, pitch, ix, iy);
+            const float colorDis = fabsf(leftValue - pc->centre);
+            pc->I[k] = leftValue;
+            pc->w[k] = go_exp(-colorDis / gamma);
+            pc->gx1[k] = go_texel(ref, rows, cols, pitch, ix + 1, iy) - go_texel(ref, rows, cols, pitch, ix - 1, iy);
+            pc->gy1[k] = go_texel(ref, rows, cols, pitch, ix, iy + 1) - go_texel(ref, rows, cols, pitch, ix, iy - 1);
+        }
+    }
+    return pc;
+}
+
+/* go_dis_at with the reference-side terms handed in (from the pixel cache): the same expressions */
+static inline float go_dis_cached(const gipuma_hip_desc *d, int view, const float *H, int ix, int iy, float leftValue,
+                                  float gx1, float gy1)
+{
+    const gipuma_hip_params *ap = &d->params;
+    const float alpha = ap->alpha, tau_color = ap->tau_color, tau_gradient = ap->tau_gradient;
+    const float oma = 1.f - alpha;
+    const float qx = (float)ix, qy = (float)iy;
+    const float X0 = fmaf(H[0], qx, H[2]);
+    const float Y0 = fmaf(H[3], qx, H[5]);
+    const float Z0 = fmaf(H[6], qx, H[8]);
+    const float X = fmaf(H[1], qy, X0);
+    const float Y = fmaf(H[4], qy, Y0);
+    const float Z = fmaf(H[7], qy, Z0);
+    const float rz = 1.0f / Z;
+    const float sx = X * rz, sy = Y * rz;
+    float s[3];
+    go_taps3_s(d->images[view], d->rows, d->cols, d->pitch, 1, sx, sy, s);
+    const float colDiff = fabsf(leftValue - s[0]);
+    const float gradX = gx1 - s[1];
+    const float gradY = gy1 - s[2];
+    const float gradDis = fminf((fabsf(gradX) + fabsf(gradY)) * 0.0625f, tau_gradient);
+    const float colDis = fminf(colDiff, tau_color);
+    return fmaf(alpha, gradDis, oma * colDis);
+}
+
+static float go_view_cost(const gipuma_hip_desc *d, int view, int px, int py, const float pl[4])
+{
+    const gipuma_hip_params *ap = &d->params;
     const int hRad = (ap->box_hsize - 1) / 2; /* gipuma.cu:1474 (init uses box/2, same for odd) */
     const int vRad = (ap->box_vsize - 1) / 2;
-    const float gamma = ap->gamma;
+    if ((hRad + 1) * (vRad + 1) > GO_MAXWIN) return GO_MAXCOST; /* (box <= 49, like the library: go_check) */
 
     float H[9];
     go_homography(&d->cameras[0], &d->cameras[view], pl, pl[3], H);
 
-    const float centre = go_texel(ref, rows, cols, pitch, px, py);
+    const go_pixel_cache *pc = go_cache_for(d, px, py);
     float cost = 0.0f;
+    int k = 0;
     for (int i = -hRad; i < hRad + 1; i += GO_WIN_INCREMENT) {
-        for (int j = -vRad; j < vRad + 1; j += GO_WIN_INCREMENT) {
-            const int ix = px + i, iy = py + j;
-            /* weight_cu, gipuma.cu:186-193 */
-            const float leftValue = go_texel(ref, rows, cols, pitch, ix, iy);
-            const float colorDis = fabsf(leftValue - centre);
-            const float w = go_exp(-colorDis / gamma);
-            const float dis = go_dis_at(d, view, H, ix, iy, leftValue);
-            cost = fmaf(w, dis, cost);
+        for (int j = -vRad; j < vRad + 1; j += GO_WIN_INCREMENT, k++) {
+            /* weight_cu, gipuma.cu:186-193: pc->w[k]; pmCostComputation_shared, :251-274 */
+            const float dis = go_dis_cached(d, view, H, px + i, py + j, pc->I[k], pc->gx1[k], pc->gy1[k]);
+            cost = fmaf(pc->w[k], dis, cost);
         }
     }
     return cost;
@@ -527,39 +601,72 @@ static inline float go_l1_3(const float v[3])
 /* The same functions instantiated with T = float4 (-color_processing, gipuma.cu:1965-1968):
  * images are float4 per pixel (B, G, R, unset alpha: main.cpp:943-956), every image
  * difference is per channel and reduced by l1_norm(float4). */
+/* the pixel cache for T = float4: per window sample the texel's three channels, their central differences (right - left,
+ * down - up: the reference-side terms of pmCostComputation_shared<float4>) and the support weight */
+typedef struct {
+    const gipuma_hip_desc *d;
+    unsigned epoch;
+    int px, py;
+    float w[GO_MAXWIN], lv[GO_MAXWIN][3], gx1[GO_MAXWIN][3], gy1[GO_MAXWIN][3];
+} go_pixel_cache_c4;
+static _Thread_local go_pixel_cache_c4 go_pc4 = {0, 0, -1, -1, {0}, {{0}}, {{0}}, {{0}}};
+
+static const go_pixel_cache_c4 *go_cache_c4_for(const gipuma_hip_desc *d, int px, int py)
+{
+    go_pixel_cache_c4 *pc = &go_pc4;
+    if (pc->d == d && pc->epoch == go_epoch && pc->px == px && pc->py == py) return pc;
+    const gipuma_hip_params *ap = &d->params;
+    const int rows = d->rows, cols = d->cols, pitch = d->pitch;
+    const float *ref = d->images[0];
+    const int hRad = (ap->box_hsize - 1) / 2, vRad = (ap->box_vsize - 1) / 2;
+    const float gamma = ap->gamma;
+    pc->d = d;
+    pc->epoch = go_epoch;
+    pc->px = px;
+    pc->py = py;
+    float centre[3];
+    for (int c = 0; c < 3; c++) centre[c] = go_texel_s(ref + c, rows, cols, pitch, 4, px, py);
+    int k = 0;
+    for (int i = -hRad; i < hRad + 1; i += GO_WIN_INCREMENT) {
+        for (int j = -vRad; j < vRad + 1; j += GO_WIN_INCREMENT, k++) {
+            const int ix = px + i, iy = py + j;
+            float dc[3];
+            for (int c = 0; c < 3; c++) {
+                pc->lv[k][c] = go_texel_s(ref + c, rows, cols, pitch, 4, ix, iy);
+                dc[c] = pc->lv[k][c] - centre[c];
+                pc->gx1[k][c] = go_texel_s(ref + c, rows, cols, pitch, 4, ix + 1, iy) - go_texel_s(ref + c, rows, cols, pitch, 4, ix - 1, iy);
+                pc->gy1[k][c] = go_texel_s(ref + c, rows, cols, pitch, 4, ix, iy + 1) - go_texel_s(ref + c, rows, cols, pitch, 4, ix, iy - 1);
+            }
+            pc->w[k] = go_exp(-go_l1_3(dc) / gamma);
+        }
+    }
+    return pc;
+}
+
 static float go_view_cost_c4(const gipuma_hip_desc *d, int view, int px, int py, const float pl[4])
 {
     const gipuma_hip_params *ap = &d->params;
     const int rows = d->rows, cols = d->cols, pitch = d->pitch;
-    const float *ref = d->images[0];
     const float *src = d->images[view];
     const int hRad = (ap->box_hsize - 1) / 2;
     const int vRad = (ap->box_vsize - 1) / 2;
     const float alpha = ap->alpha, tau_color = ap->tau_color, tau_gradient = ap->tau_gradient;
-    const float gamma = ap->gamma;
     const float oma = 1.f - alpha;
+    if ((hRad + 1) * (vRad + 1) > GO_MAXWIN) return GO_MAXCOST;
 
     float H[9];
     go_homography(&d->cameras[0], &d->cameras[view], pl, pl[3], H);
 
-    float centre[3];
-    for (int c = 0; c < 3; c++) centre[c] = go_texel_s(ref + c, rows, cols, pitch, 4, px, py);
+    const go_pixel_cache_c4 *pc = go_cache_c4_for(d, px, py);
     float cost = 0.0f;
+    int k = 0;
     for (int i = -hRad; i < hRad + 1; i += GO_WIN_INCREMENT) {
         const float qx = (float)(px + i);
         const float X0 = fmaf(H[0], qx, H[2]);
         const float Y0 = fmaf(H[3], qx, H[5]);
         const float Z0 = fmaf(H[6], qx, H[8]);
-        for (int j = -vRad; j < vRad + 1; j += GO_WIN_INCREMENT) {
-            const int ix = px + i, iy = py + j;
-            const float qy = (float)iy;
-            float leftValue[3], dc[3];
-            for (int c = 0; c < 3; c++) {
-                leftValue[c] = go_texel_s(ref + c, rows, cols, pitch, 4, ix, iy);
-                dc[c] = leftValue[c] - centre[c];
-            }
-            const float colorDis = go_l1_3(dc);
-            const float w = go_exp(-colorDis / gamma);
+        for (int j = -vRad; j < vRad + 1; j += GO_WIN_INCREMENT, k++) {
+            const float qy = (float)(py + j);
             const float X = fmaf(H[1], qy, X0);
             const float Y = fmaf(H[4], qy, Y0);
             const float Z = fmaf(H[7], qy, Z0);
@@ -569,21 +676,15 @@ static float go_view_cost_c4(const gipuma_hip_desc *d, int view, int px, int py,
             for (int c = 0; c < 3; c++) {
                 float s[3];
                 go_taps3_s(src + c, rows, cols, pitch, 4, sx, sy, s);
-                const float gx2 = s[1];
-                const float gy2 = s[2];
-                cd[c] = leftValue[c] - s[0];
-                const float up = go_texel_s(ref + c, rows, cols, pitch, 4, ix, iy - 1);
-                const float down = go_texel_s(ref + c, rows, cols, pitch, 4, ix, iy + 1);
-                const float left = go_texel_s(ref + c, rows, cols, pitch, 4, ix - 1, iy);
-                const float right = go_texel_s(ref + c, rows, cols, pitch, 4, ix + 1, iy);
-                gradX[c] = (right - left) - gx2;
-                gradY[c] = (down - up) - gy2;
+                cd[c] = pc->lv[k][c] - s[0];
+                gradX[c] = pc->gx1[k][c] - s[1];
+                gradY[c] = pc->gy1[k][c] - s[2];
             }
             const float colDiff = go_l1_3(cd);
             const float gradDis = fminf((go_l1_3(gradX) + go_l1_3(gradY)) * 0.0625f, tau_gradient);
             const float colDis = fminf(colDiff, tau_color);
             const float dis = fmaf(alpha, gradDis, oma * colDis);
-            cost = fmaf(w, dis, cost);
+            cost = fmaf(pc->w[k], dis, cost);
         }
     }
     return cost;
@@ -599,6 +700,7 @@ static float go_view_cost_any(const gipuma_hip_desc *d, int view, int px, int py
 float gipuma_oracle_view_cost(const gipuma_hip_desc *d, int view, int x, int y,
                               const float plane[4])
 {
+    GO_ENTER();
     return go_view_cost_any(d, view, x, y, plane);
 }
 
@@ -663,6 +765,7 @@ static float go_multiview_cost(const gipuma_hip_desc *d, int px, int py, const f
 
 float gipuma_oracle_multiview_cost(const gipuma_hip_desc *d, int x, int y, const float plane[4])
 {
+    GO_ENTER();
     return go_multiview_cost(d, x, y, plane);
 }
 
@@ -893,6 +996,8 @@ static int go_check(const gipuma_hip_desc *d)
     if (d->params.box_hsize < 1 || d->params.box_vsize < 1 || !(d->params.box_hsize & 1) ||
         !(d->params.box_vsize & 1))
         return GIPUMA_HIP_ERR_ARG;
+    if (d->params.box_hsize > 49 || d->params.box_vsize > 49) return GIPUMA_HIP_ERR_UNSUPPORTED; /* like gipuma_hip_create */
+    GO_ENTER(); /* a new call may see new images or parameters: the per-thread pixel caches start over */
     return 0;
 }
 
