@@ -549,7 +549,9 @@ static bool read_png_rgb8(const std::string &path, std::vector<unsigned char> &r
         o += 12 + (size_t)len;
     }
     const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
-    if (!ch || w < 1 || h < 1 || w > 65535 || h > 65535 || idat.empty()) return false;
+    // (a header may claim any size: nothing is allocated for more than 2^28 pixels -- the library itself refuses frames of
+    //  2^29 texels and more, include/gipuma_hip.h -- so a corrupt file is refused instead of exhausting memory)
+    if (!ch || w < 1 || h < 1 || w > 65535 || h > 65535 || (uint64_t)w * h > (1ull << 28) || idat.empty()) return false;
     if (!(depth == 8 || depth == 16 || (depth < 8 && (ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4))))
         return false;
     if (ctype == 3 && (depth > 8 || plte.size() < 3)) return false;

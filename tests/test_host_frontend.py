@@ -658,6 +658,12 @@ def test_png_reader_matches_pil_for_every_colour_type(tmp_path):
     good[8 + 8 + 13:8 + 8 + 17] = struct.pack(">I", zlib.crc32(bytes(good[12:8 + 8 + 13])))
     (tmp_path / "adam7.png").write_bytes(bytes(good))
     assert _host_read_image(tmp_path / "adam7.png") is None
+    # a header that claims 60000 x 60000 pixels is refused before anything of that size is allocated
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    (tmp_path / "huge.png").write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 60000, 60000, 8, 0, 0, 0, 0)) +
+                                        chunk(b"IDAT", zlib.compress(b"\0" * 100)) + chunk(b"IEND", b""))
+    assert _host_read_image(tmp_path / "huge.png") is None
 
 
 def test_python_runner_reads_jpeg_as_luma(tmp_path):
