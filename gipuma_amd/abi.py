@@ -79,6 +79,7 @@ SYMBOLS = [
     ("gipuma_hip_device_count", C.c_int, []),
     ("gipuma_hip_cache_clear", C.c_int, []),
     ("gipuma_hip_selftest_reciprocal", C.c_int, [C.c_int, C.POINTER(C.c_ulonglong)]),
+    ("gipuma_hip_selftest_quotient", C.c_int, [C.c_int, C.c_uint, C.c_uint, C.POINTER(C.c_ulonglong)]),
     ("gipuma_hip_create", C.c_int, [C.POINTER(Desc), C.POINTER(C.c_void_p)]),
     ("gipuma_hip_destroy", C.c_int, [C.c_void_p]),
     ("gipuma_hip_init_planes", C.c_int, [C.c_void_p]),

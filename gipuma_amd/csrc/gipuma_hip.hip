@@ -577,6 +577,29 @@ int gipuma_hip_selftest_reciprocal(int device_id, unsigned long long *mismatches
     return 0;
 }
 
+int gipuma_hip_selftest_quotient(int device_id, unsigned z_first, unsigned z_count, unsigned long long *mismatches)
+{
+    if (!mismatches) return fail(GIPUMA_HIP_ERR_ARG, "null argument");
+    if (device_id < 0 || device_id >= gipuma_hip_device_count())
+        return fail(GIPUMA_HIP_ERR_NO_DEVICE, "no such HIP device");
+    if (z_first >= (1u << 23) || z_count > (1u << 23) - z_first) return fail(GIPUMA_HIP_ERR_ARG, "significand range out of 0..2^23");
+    HIP_OK(hipSetDevice(device_id));
+    unsigned long long *d = nullptr;
+    HIP_OK(hipMalloc(&d, sizeof *d));
+    hipError_t e = hipMemset(d, 0, sizeof *d);
+    // (launches of at most 2^14 denominators: ~0.1 s each, so that no single launch runs for minutes)
+    for (unsigned done = 0; e == hipSuccess && done < z_count; done += 1u << 14) {
+        const unsigned n = std::min(z_count - done, 1u << 14);
+        hipLaunchKernelGGL(pm::quotient_selftest_kernel, dim3(n), dim3(pm::kThreads), 0, 0, d, z_first + done);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    if (e == hipSuccess) e = hipMemcpy(mismatches, d, sizeof *d, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(GIPUMA_HIP_ERR_DEVICE, "selftest: %s", hipGetErrorString(e));
+    return 0;
+}
+
 int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
 {
     if (!out) return fail(GIPUMA_HIP_ERR_ARG, "null out pointer");
@@ -643,12 +666,6 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         s->tune = (unsigned)strtoul(t, nullptr, 0);
         s->tune &= ~(Tune::kHistorySkip | Tune::kUntrustedCosts | Tune::kAccumChanged | Tune::kPushConsume);  // host-internal bits
     }
-#if PM_LITERAL
-    // the reference-order arithmetic lives in the generic sample loop on float planes (view_cost_loop): no packed 8-bit
-    // planes, no compile-time window -- and with them no push / plane-keyed / column-per-lane kernels, no bounded evaluation
-    // (all of those need the packed planes); the skip rules (A) / (D) / (H) hold for any cost that is a pure function
-    s->tune |= Tune::kNoLut | Tune::kGenericBox;
-#endif
     if (const char *t = exp_env("COLS_LAUNCHES")) s->cols_launches = atoi(t);  // experiment
     if (const char *t = exp_env("LAUNCH_TIMES")) s->launch_times = atoi(t) != 0;
     if (d->stream) {

@@ -13,6 +13,7 @@
 #define gipuma_hip_device_count gipuma_hipf_device_count
 #define gipuma_hip_cache_clear gipuma_hipf_cache_clear
 #define gipuma_hip_selftest_reciprocal gipuma_hipf_selftest_reciprocal
+#define gipuma_hip_selftest_quotient gipuma_hipf_selftest_quotient
 #define gipuma_hip_create gipuma_hipf_create
 #define gipuma_hip_destroy gipuma_hipf_destroy
 #define gipuma_hip_init_planes gipuma_hipf_init_planes

@@ -14,6 +14,7 @@
 #define gipuma_hip_device_count gipuma_hipl_device_count
 #define gipuma_hip_cache_clear gipuma_hipl_cache_clear
 #define gipuma_hip_selftest_reciprocal gipuma_hipl_selftest_reciprocal
+#define gipuma_hip_selftest_quotient gipuma_hipl_selftest_quotient
 #define gipuma_hip_create gipuma_hipl_create
 #define gipuma_hip_destroy gipuma_hipl_destroy
 #define gipuma_hip_init_planes gipuma_hipl_init_planes

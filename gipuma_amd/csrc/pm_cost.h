@@ -4,28 +4,13 @@
 // termination.  Part of the device code of the PatchMatch path (pm_device.h).
 #pragma once
 #include "pm_core.h"
+#include "pm_sample.h"
 
 namespace pm {
 
 // Patch cost of one source view: pmCost_shared + pmCostComputation_shared,
 // gipuma.cu:585-680 and :223-277.  `tp0` points at the pixel's own texel inside the LDS tile.
-// Is every warped-point denominator of the window safely inside the range where rcp_newton is
-// exact?  Z(i,j) = fmaf(H7, qy, fmaf(H6, qx, H8)) is monotone in qx and in qy (one rounding each),
-// so all window values lie between the four corner values.
-__device__ __forceinline__ bool window_z_safe(const float *H, float qx0, float qx1, float qy0, float qy1)
-{
-#if PM_APPROX
-    return true;  // (the approx flavour's reciprocal is v_rcp_f32 everywhere: nothing to prove)
-#endif
-    const float z00 = __builtin_fmaf(H[7], qy0, __builtin_fmaf(H[6], qx0, H[8]));
-    const float z01 = __builtin_fmaf(H[7], qy1, __builtin_fmaf(H[6], qx0, H[8]));
-    const float z10 = __builtin_fmaf(H[7], qy0, __builtin_fmaf(H[6], qx1, H[8]));
-    const float z11 = __builtin_fmaf(H[7], qy1, __builtin_fmaf(H[6], qx1, H[8]));
-    const float lo = __builtin_fminf(__builtin_fminf(z00, z01), __builtin_fminf(z10, z11));
-    const float hi = __builtin_fmaxf(__builtin_fmaxf(z00, z01), __builtin_fmaxf(z10, z11));
-    // same sign, and magnitudes in [2^-100, 2^100] (NaN fails every comparison)
-    return (lo >= 0x1p-100f && hi <= 0x1p100f) || (hi <= -0x1p-100f && lo >= -0x1p100f);
-}
+// The arithmetic of a sample -- warp, division, taps, dis, accumulation -- is pm_sample.h's, whatever the model.
 
 // Exponent trick used by the U8 loop: for an integer n in [0, 2^21), the float 2^21 + n has ulp 1/4,
 // so its bit pattern is 0x4a000000 + 4n -- a byte offset of 4-byte entry n, produced by a full-rate
@@ -34,6 +19,109 @@ __device__ __forceinline__ bool window_z_safe(const float *H, float qx0, float q
 constexpr uint32_t kMagicBits = 0x4a000000u;  // bits of 2^21
 constexpr float kMagicF = 0x1p21f;
 constexpr int kMagicMaxWords = (1 << 21) - 8;
+
+// ---- shared pieces of the packed-gray loops (float-encoded window offsets) ----
+struct MagicAddr {  // wave-uniform: offset of window (Xc, Yc), Xc in [-2, cols], Yc in [-2, rows] (clamped floor coordinates;
+    float colsf, rowsf, pwf, magic_c;  // entry (Yc+2)*pw + Xc+2 of V), as the bits of fma(Yc, pw, Xc + magic_c)
+};
+__device__ __forceinline__ MagicAddr magic_addr(const Problem *__restrict__ P)
+{
+    MagicAddr A;
+    A.colsf = (float)P->cols;
+    A.rowsf = (float)P->rows;
+    A.pwf = (float)P->pw;
+    A.magic_c = kMagicF + (float)(2 * P->pw + 2);
+    return A;
+}
+__device__ __forceinline__ gptr_bytes magic_base_of(const ViewCam &vc)
+{
+    return (gptr_bytes)((uintptr_t)vc.packed.raw - (uintptr_t)kMagicBits);
+}
+// (the plane behind a float-encoded base: only the literal taps' one-by-one path reads through it)
+__device__ __forceinline__ PlaneRef plane_of_magic(gptr_bytes magic_base, const Problem *__restrict__ P)
+{
+    PlaneRef pr;
+    pr.packed = (gptr_bytes)((uintptr_t)magic_base + (uintptr_t)kMagicBits);
+    pr.P = P;
+    return pr;
+}
+struct WinReq {
+    float a, b;  // what win_pos keeps: the fractions (model taps) or the sample position itself (literal taps)
+    u32x4_a4 w;
+};
+// the window of the sample (column terms wc, row qy): getCorrespondingPoint_cu, gipuma.cu:207-217, then ONE 16-byte load
+template <bool FAST>
+__device__ __forceinline__ WinReq magic_request(const MagicAddr &A, gptr_bytes magic_base, const WarpCol &wc,
+                                                const WarpRow &wr, float qy)
+{
+    const Warped p = warp_point(wc, wr, qy);
+    float sx, sy;
+    warp_divide<FAST>(p, sx, sy);
+    const WinPos wp = win_pos(sx, sy);
+    WinReq r;
+    r.a = wp.ka;
+    r.b = wp.kb;
+    // v_med3_f32 returns min3 when an input is NaN: NaN -> -2, like the saturating cvt
+    const float Xc = __builtin_amdgcn_fmed3f(wp.fx0, -2.0f, A.colsf);
+    const float Yc = __builtin_amdgcn_fmed3f(wp.fy0, -2.0f, A.rowsf);
+    const uint32_t off = __float_as_uint(__builtin_fmaf(Yc, A.pwf, Xc + A.magic_c));
+    r.w = *(gptr_u32x4)(magic_base + off);
+    return r;
+}
+// (FAST as a wave-uniform run-time flag: see GroupWalk::request)
+__device__ __forceinline__ WinReq magic_request_rt(const MagicAddr &A, gptr_bytes magic_base, const WarpCol &wc,
+                                                   const WarpRow &wr, float qy, bool fast)
+{
+    const Warped p = warp_point(wc, wr, qy);
+    float sx, sy;
+#if PM_APPROX
+    warp_divide<true>(p, sx, sy);
+    (void)fast;
+#else
+    if (fast)
+        warp_divide<true>(p, sx, sy);
+    else
+        warp_divide<false>(p, sx, sy);
+#endif
+    const WinPos wp = win_pos(sx, sy);
+    WinReq r;
+    r.a = wp.ka;
+    r.b = wp.kb;
+    const float Xc = __builtin_amdgcn_fmed3f(wp.fx0, -2.0f, A.colsf);
+    const float Yc = __builtin_amdgcn_fmed3f(wp.fy0, -2.0f, A.rowsf);
+    const uint32_t off = __float_as_uint(__builtin_fmaf(Yc, A.pwf, Xc + A.magic_c));
+    r.w = *(gptr_u32x4)(magic_base + off);
+    return r;
+}
+struct DisConst {  // wave-uniform: alpha / 16, 1 - alpha, tau_color, 16 tau_gradient (dis_fold, pm_sample.h)
+    float alpha16, oma, tau_color, taug16;
+};
+__device__ __forceinline__ DisConst dis_const(const Problem *__restrict__ P)
+{
+    DisConst K;
+    K.alpha16 = P->alpha * 0.0625f;
+    K.oma = 1.f - P->alpha;
+    K.tau_color = P->tau_color;
+    K.taug16 = P->tau_gradient * 16.0f;
+    return K;
+}
+// dis of a gray sample from its window: the taps, pmCostComputation_shared (gipuma.cu:251-274); (I, gx1, gy1): the reference
+// texel of the sample and its central differences
+__device__ __forceinline__ float gray_dis(const DisConst &K, const WinReq &cur, float I, float gx1, float gy1, const PlaneRef &pr)
+{
+    const Tex12 t = unpack12(cur.w.x, cur.w.y, cur.w.z, cur.w.w);
+    const Taps tp5 = sample_taps_gray(cur.a, cur.b, t, pr);
+    const float colDiff = I - tp5.sc;  // |.| taken in the min
+    const float gradX = gx1 - tp5.gx2;
+    const float gradY = gy1 - tp5.gy2;
+    return dis_folded<true>(__builtin_fabsf(gradX) + __builtin_fabsf(gradY), colDiff, K.alpha16, K.oma, K.tau_color, K.taug16);
+}
+// support weight of a gray sample from the 256-entry table (weight_cu, gipuma.cu:186-193; images integer valued)
+__device__ __forceinline__ float lut_weight(const char *lut_magic, float I, float centre)
+{
+    const float colorDis = __builtin_fabsf(I - centre);
+    return *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
+}
 
 template <int BOX, bool U8, bool INTERIOR, bool FAST, bool MAGIC>
 __device__ __forceinline__ float view_cost_loop(const Problem *__restrict__ P, const ViewCam &vc,
@@ -51,20 +139,19 @@ __device__ __forceinline__ float view_cost_loop(const Problem *__restrict__ P, c
     const float tau_color = P->tau_color, tau_gradient = P->tau_gradient, gamma = P->gamma;
     const float centre = tp0[0];
     const int hr = win.hrad(), vr = win.vrad();
-    // MAGIC: offset of window (Xc, Yc), Xc in [-2, cols], Yc in [-2, rows] (clamped floor
-    // coordinates; entry (Yc+2)*pw + Xc+2 of V), as the bits of fma(Yc, pw, Xc + magic_c)
-    const float pwf = (float)P->pw;
-    const float magic_c = kMagicF + (float)(2 * P->pw + 2);
-    const gptr_bytes magic_base = (gptr_bytes)((uintptr_t)packed - (uintptr_t)kMagicBits);
+    const MagicAddr MA = magic_addr(P);
+    const gptr_bytes magic_base = magic_base_of(vc);
     const char *lut_magic = (const char *)lut - kMagicBits;
+    PlaneRef pr;
+    pr.packed = (gptr_bytes)vc.packed.raw;
+    pr.P = P;
     float cost = 0.0f;
-#if PM_LITERAL
+#if PM_MODEL & 1
     if constexpr (!U8) {
-        // The reference's own operation order (pmCost_shared, gipuma.cu:633-676; getCorrespondingPoint_cu :207-217;
-        // pmCostComputation_shared :251-274), what the CPU restatement computes in its literal flavour 7 and the
-        // reference's code compiled for the CPU computes: bit for bit the same planes and costs.  Float planes only (the host
-        // forces them: the U8 instantiations of this flavour are never launched); -ffp-contract=off keeps every multiply-add
-        // unfused.
+        // Float planes, the reference's own operation order (pmCost_shared, gipuma.cu:633-676; getCorrespondingPoint_cu
+        // :207-217; pmCostComputation_shared :251-274) with one gather of four texels per tap: what the CPU restatement
+        // computes in its literal flavour 7 and the reference's code compiled for the CPU computes.  -ffp-contract=off keeps
+        // every multiply-add unfused.
         for (int i = -hr; i <= hr; i += 2) {
             for (int j = -vr; j <= vr; j += 2) {
                 const float4 t4 = *reinterpret_cast<const float4 *>(tp0 + 4 * (j * tw + i));
@@ -94,80 +181,69 @@ __device__ __forceinline__ float view_cost_loop(const Problem *__restrict__ P, c
         return cost;
     }
 #endif
+    const WarpRow wr = warp_row(H);
     // (float)(px + i) == (float)px + (float)i exactly (small integers): full-rate adds, no cvt
     float qx = (float)(px - hr);
     for (int i = -hr; i <= hr; i += 2, qx += 2.0f) {
-        const float X0 = __builtin_fmaf(H[0], qx, H[2]);
-        const float Y0 = __builtin_fmaf(H[3], qx, H[5]);
-        const float Z0 = __builtin_fmaf(H[6], qx, H[8]);
+        const WarpCol wc = warp_col(H, qx);
         float qy = (float)(py - vr);
 #pragma unroll unroll_j<BOX>()
         for (int j = -vr; j <= vr; j += 2, qy += 2.0f) {
             // one ds_read_b128: {I(q), gx1(q), gy1(q)} of the reference tile
             const float4 t4 = *reinterpret_cast<const float4 *>(tp0 + 4 * (j * tw + i));
             // weight_cu, gipuma.cu:186-193
-            const float leftValue = t4.x;
-            const float colorDis = __builtin_fabsf(leftValue - centre);
             float w;
             if (U8)  // images are integer valued in [0,255]: 256 possible weights
-                w = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
+                w = lut_weight(lut_magic, t4.x, centre);
             else
-                w = exp_model(-colorDis / gamma);
-            // getCorrespondingPoint_cu, gipuma.cu:207-217
-            const float X = __builtin_fmaf(H[1], qy, X0);
-            const float Y = __builtin_fmaf(H[4], qy, Y0);
-            const float Z = __builtin_fmaf(H[7], qy, Z0);
-            const float rz = recip<FAST>(Z);
-            const float sx = X * rz, sy = Y * rz;
-            // M1: five bilinear taps sharing one 4x4 texel window (gipuma.cu:251-253)
-            const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
-            const float a = sx - fx0, b = sy - fy0;
+                w = exp_model(-__builtin_fabsf(t4.x - centre) / gamma);
             Taps tp5;
             if (U8 && MAGIC) {  // U8 mode: the whole window is one 16-byte load
-                // v_med3_f32 returns min3 when an input is NaN: NaN -> -2, like the saturating cvt
-                const float Xc = __builtin_amdgcn_fmed3f(fx0, -2.0f, colsf);
-                const float Yc = __builtin_amdgcn_fmed3f(fy0, -2.0f, rowsf);
-                const uint32_t off = __float_as_uint(__builtin_fmaf(Yc, pwf, Xc + magic_c));
-                const u32x4_a4 wv = *(gptr_u32x4)(magic_base + off);
-                tp5 = taps_u8(a, b, wv.x, wv.y, wv.z, wv.w);
-            } else if (U8) {
-                // X = clamp(floor(sx), -2, cols) + 2, same for Y: the +2 is exact wherever the
-                // clamp does not saturate
-                const uint32_t X = min(cvt_u32_sat(fx0 + 2.0f), xmax);
-                const uint32_t Y = min(cvt_u32_sat(fy0 + 2.0f), ymax);
-                const uint32_t off = (Y * pw + X) << 2;
-                const u32x4_a4 wv = *(gptr_u32x4)((gptr_bytes)packed + off);
-                tp5 = taps_u8(a, b, wv.x, wv.y, wv.z, wv.w);
+                const WinReq r = magic_request<FAST>(MA, magic_base, wc, wr, qy);
+                tp5 = sample_taps_gray(r.a, r.b, unpack12(r.w.x, r.w.y, r.w.z, r.w.w), pr);
             } else {
-                // float planes: keep the float->int conversion defined for huge / NaN coordinates
-                const int ix = (int)__builtin_fminf(__builtin_fmaxf(fx0, -2.0f), colsf);
-                const int iy = (int)__builtin_fminf(__builtin_fmaxf(fy0, -2.0f), rowsf);
-                const bool inside = ix >= 1 && ix <= cols - 3 && iy >= 1 && iy <= rows - 3;
-                if (INTERIOR && __all(inside)) {
-                    const gptr_f32 s = img + (iy * pitch + ix);
-                    tp5 = taps12(a, b, s[-pitch], s[-pitch + 1], s[-1], s[0], s[1], s[2], s[pitch - 1], s[pitch],
-                                 s[pitch + 1], s[pitch + 2], s[2 * pitch], s[2 * pitch + 1]);
+                // getCorrespondingPoint_cu, gipuma.cu:207-217
+                const Warped p = warp_point(wc, wr, qy);
+                float sx, sy;
+                warp_divide<FAST>(p, sx, sy);
+                const WinPos wp = win_pos(sx, sy);
+                if (U8) {
+                    // X = clamp(floor(sx), -2, cols) + 2, same for Y: the +2 is exact wherever the
+                    // clamp does not saturate
+                    const uint32_t X = min(cvt_u32_sat(wp.fx0 + 2.0f), xmax);
+                    const uint32_t Y = min(cvt_u32_sat(wp.fy0 + 2.0f), ymax);
+                    const uint32_t off = (Y * pw + X) << 2;
+                    const u32x4_a4 wv = *(gptr_u32x4)((gptr_bytes)packed + off);
+                    tp5 = sample_taps_gray(wp.ka, wp.kb, unpack12(wv.x, wv.y, wv.z, wv.w), pr);
                 } else {
-                    const int c0 = clampi(ix - 1, 0, cols - 1), c1 = clampi(ix, 0, cols - 1);
-                    const int c2 = clampi(ix + 1, 0, cols - 1), c3 = clampi(ix + 2, 0, cols - 1);
-                    const int r0 = clampi(iy - 1, 0, rows - 1) * pitch, r1 = clampi(iy, 0, rows - 1) * pitch;
-                    const int r2 = clampi(iy + 1, 0, rows - 1) * pitch, r3 = clampi(iy + 2, 0, rows - 1) * pitch;
-                    tp5 = taps12(a, b, img[r0 + c1], img[r0 + c2], img[r1 + c0], img[r1 + c1], img[r1 + c2],
-                                 img[r1 + c3], img[r2 + c0], img[r2 + c1], img[r2 + c2], img[r2 + c3],
-                                 img[r3 + c1], img[r3 + c2]);
+                    // float planes (model taps; the literal ones: the branch above): keep the float->int conversion
+                    // defined for huge / NaN coordinates
+                    const float a = wp.ka, b = wp.kb;
+                    const int ix = (int)__builtin_fminf(__builtin_fmaxf(wp.fx0, -2.0f), colsf);
+                    const int iy = (int)__builtin_fminf(__builtin_fmaxf(wp.fy0, -2.0f), rowsf);
+                    const bool inside = ix >= 1 && ix <= cols - 3 && iy >= 1 && iy <= rows - 3;
+                    if (INTERIOR && __all(inside)) {
+                        const gptr_f32 s = img + (iy * pitch + ix);
+                        tp5 = taps12(a, b, s[-pitch], s[-pitch + 1], s[-1], s[0], s[1], s[2], s[pitch - 1], s[pitch],
+                                     s[pitch + 1], s[pitch + 2], s[2 * pitch], s[2 * pitch + 1]);
+                    } else {
+                        const int c0 = clampi(ix - 1, 0, cols - 1), c1 = clampi(ix, 0, cols - 1);
+                        const int c2 = clampi(ix + 1, 0, cols - 1), c3 = clampi(ix + 2, 0, cols - 1);
+                        const int r0 = clampi(iy - 1, 0, rows - 1) * pitch, r1 = clampi(iy, 0, rows - 1) * pitch;
+                        const int r2 = clampi(iy + 1, 0, rows - 1) * pitch, r3 = clampi(iy + 2, 0, rows - 1) * pitch;
+                        tp5 = taps12(a, b, img[r0 + c1], img[r0 + c2], img[r1 + c0], img[r1 + c1], img[r1 + c2],
+                                     img[r1 + c3], img[r2 + c0], img[r2 + c1], img[r2 + c2], img[r2 + c3],
+                                     img[r3 + c1], img[r3 + c2]);
+                    }
                 }
             }
-            const float sc = tp5.sc, gx2 = tp5.gx2, gy2 = tp5.gy2;
-            // pmCostComputation_shared, gipuma.cu:251-274
-            const float colDiff = t4.w - sc;  // t4.w == t4.x == I(q); |.| taken in the min below
-            const float gx1 = t4.y;
-            const float gy1 = t4.z;
-            const float gradX = gx1 - gx2;
-            const float gradY = gy1 - gy2;
-            const float gradDis = min_nc((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, tau_gradient);
-            const float colDis = min_abs_nc(colDiff, tau_color);
-            const float dis = __builtin_fmaf(alpha, gradDis, oma * colDis);
-            cost = __builtin_fmaf(w, dis, cost);
+            // pmCostComputation_shared, gipuma.cu:251-274 (the unfolded constants: this is the loop of last resort)
+            const float colDiff = t4.w - tp5.sc;  // t4.w == t4.x == I(q); |.| taken in the min
+            const float gradX = t4.y - tp5.gx2;
+            const float gradY = t4.z - tp5.gy2;
+            const float dis = dis_folded<true>((__builtin_fabsf(gradX) + __builtin_fabsf(gradY)) * 0.0625f, colDiff, alpha, oma,
+                                               tau_color, tau_gradient);
+            cost = accum(w, dis, cost);
         }
     }
     return cost;
@@ -179,17 +255,6 @@ __device__ __forceinline__ float view_cost_loop(const Problem *__restrict__ P, c
 // instead of waiting for the one it has just issued.  Per sample the arithmetic and the order of
 // the cost accumulation are those of view_cost_loop -- the results are bit-identical.  (The two
 // requests past the last sample fetch clamped, valid addresses and are dropped.)
-// dis_fold.  pmCostComputation_shared (gipuma.cu:263-274): gradDis = min((|dgx| + |dgy|) * 0.0625, tau_g) and
-// dis = fmaf(alpha, gradDis, (1 - alpha) * colDis).  Scaling by a power of two is exact, so with s = |dgx| + |dgy|
-//     min(s / 16, tau_g) = min(s, 16 tau_g) / 16      and      fmaf(alpha, m / 16, c) = fmaf(alpha / 16, m, c)
-// (the same real number is rounded once): the specialised loops take alpha / 16 and 16 tau_g as their constants and
-// save the multiplication.  Exact unless alpha / 16 is subnormal or 16 tau_g overflows -- the host checks and falls
-// back to the literal loop (view_cost_loop, BOX == 0) -- or s / 16 itself is subnormal (s < 2^-122: a gradient
-// difference that small needs a sample within 2^-97 pixels of x = 0; the literal form rounds it, this one does not).
-struct WinReq {
-    float a, b;
-    u32x4_a4 w;
-};
 template <int BOX, bool FAST, bool ET>
 __device__ __forceinline__ float view_cost_pipe(const Problem *__restrict__ P, const ViewCam &vc,
                                                 const float *__restrict__ H, const float *__restrict__ tp0,
@@ -198,78 +263,43 @@ __device__ __forceinline__ float view_cost_pipe(const Problem *__restrict__ P, c
 {
     static_assert(BOX > 0, "compile-time window only");
     constexpr int R = (BOX - 1) / 2, N = R + 1;  // offsets -R, -R+2, ..., R
-    const float colsf = (float)P->cols, rowsf = (float)P->rows;
-    const float alpha16 = P->alpha * 0.0625f, oma = 1.f - P->alpha;  // (dis_term: the 1/16 of the gradient term folded in)
-    const float tau_color = P->tau_color, taug16 = P->tau_gradient * 16.0f;
+    const MagicAddr MA = magic_addr(P);
+    const DisConst K = dis_const(P);
     const float centre = tp0[0];
-    const float pwf = (float)P->pw;
-    const float magic_c = kMagicF + (float)(2 * P->pw + 2);
-    const gptr_bytes magic_base = (gptr_bytes)((uintptr_t)vc.packed.raw - (uintptr_t)kMagicBits);
+    const gptr_bytes magic_base = magic_base_of(vc);
+    const PlaneRef pr = plane_of_magic(magic_base, P);
     const char *lut_magic = (const char *)lut - kMagicBits;
-    const float H1 = H[1], H4 = H[4], H7 = H[7];
-
-    auto request = [&](float X0, float Y0, float Z0, float qy) -> WinReq {
-        // getCorrespondingPoint_cu, gipuma.cu:207-217
-        const float X = __builtin_fmaf(H1, qy, X0);
-        const float Y = __builtin_fmaf(H4, qy, Y0);
-        const float Z = __builtin_fmaf(H7, qy, Z0);
-        const float rz = recip<FAST>(Z);
-        const float sx = X * rz, sy = Y * rz;
-        const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
-        WinReq r;
-        r.a = sx - fx0;
-        r.b = sy - fy0;
-        const float Xc = __builtin_amdgcn_fmed3f(fx0, -2.0f, colsf);
-        const float Yc = __builtin_amdgcn_fmed3f(fy0, -2.0f, rowsf);
-        const uint32_t off = __float_as_uint(__builtin_fmaf(Yc, pwf, Xc + magic_c));
-        r.w = *(gptr_u32x4)(magic_base + off);
-        return r;
-    };
+    const WarpRow wr = warp_row(H);
 
     const float qy0 = (float)(py - R);
     float qx = (float)(px - R);
-    float X0 = __builtin_fmaf(H[0], qx, H[2]);
-    float Y0 = __builtin_fmaf(H[3], qx, H[5]);
-    float Z0 = __builtin_fmaf(H[6], qx, H[8]);
-    WinReq r0 = request(X0, Y0, Z0, qy0), r1 = request(X0, Y0, Z0, qy0 + 2.0f);
+    WarpCol wc = warp_col(H, qx);
+    WinReq r0 = magic_request<FAST>(MA, magic_base, wc, wr, qy0), r1 = magic_request<FAST>(MA, magic_base, wc, wr, qy0 + 2.0f);
     float cost = 0.0f;
     const float *tcol = tp0 + 4 * (-R * tw - R);  // texel (-R, -R) of the window
     for (int c = 0; c < N; c++, tcol += 8) {
         const float qxn = qx + 2.0f;
-        const float X0n = __builtin_fmaf(H[0], qxn, H[2]);
-        const float Y0n = __builtin_fmaf(H[3], qxn, H[5]);
-        const float Z0n = __builtin_fmaf(H[6], qxn, H[8]);
+        const WarpCol wcn = warp_col(H, qxn);
 #pragma unroll
         for (int k = 0; k < N; k++) {
             const WinReq cur = r0;
             r0 = r1;
             // sample k+2 of this column, or the first two of the next one
             if (k + 2 < N)
-                r1 = request(X0, Y0, Z0, qy0 + (float)(2 * (k + 2)));
+                r1 = magic_request<FAST>(MA, magic_base, wc, wr, qy0 + (float)(2 * (k + 2)));
             else
-                r1 = request(X0n, Y0n, Z0n, qy0 + (float)(2 * (k + 2 - N)));
+                r1 = magic_request<FAST>(MA, magic_base, wcn, wr, qy0 + (float)(2 * (k + 2 - N)));
             __builtin_amdgcn_sched_barrier(0);  // keep the request ahead of this sample's reduction
             // one ds_read_b128: {I(q), gx1(q), gy1(q), I(q)} of the reference tile
             const float4 t4 = *reinterpret_cast<const float4 *>(tcol + 8 * k * tw);
-            // weight_cu, gipuma.cu:186-193: 256 possible weights
-            const float colorDis = __builtin_fabsf(t4.x - centre);
-            const float w = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
-            const Taps tp5 = taps_u8(cur.a, cur.b, cur.w.x, cur.w.y, cur.w.z, cur.w.w);
-            // pmCostComputation_shared, gipuma.cu:251-274
-            const float colDiff = t4.w - tp5.sc;
-            const float gradX = t4.y - tp5.gx2;
-            const float gradY = t4.z - tp5.gy2;
-            const float gradDis = min_nc(__builtin_fabsf(gradX) + __builtin_fabsf(gradY), taug16);
-            const float colDis = min_abs_nc(colDiff, tau_color);
-            const float dis = __builtin_fmaf(alpha16, gradDis, oma * colDis);
-            cost = __builtin_fmaf(w, dis, cost);
+            const float w = lut_weight(lut_magic, t4.x, centre);
+            const float dis = gray_dis(K, cur, t4.w, t4.y, t4.z, pr);
+            cost = accum(w, dis, cost);
             __builtin_amdgcn_sched_barrier(0);
         }
         qx = qxn;
-        X0 = X0n;
-        Y0 = Y0n;
-        Z0 = Z0n;
-        // early termination (ET): the partial sum only grows (w, dis >= 0, fmaf rounds monotonically),
+        wc = wcn;
+        // early termination (ET): the partial sum only grows (w, dis >= 0, every rounding is monotone),
         // so once every lane of the wavefront has reached its bound the rest of the view cannot
         // matter (see multiview_cost); the two windows already requested are dropped
         if (ET && __all(cost >= tau)) {
@@ -294,71 +324,39 @@ __device__ __forceinline__ float view_cost_pipe_range(const Problem *__restrict_
 {
     static_assert(BOX > 0, "compile-time window only");
     constexpr int R = (BOX - 1) / 2, N = R + 1;
-    const float colsf = (float)P->cols, rowsf = (float)P->rows;
-    const float alpha16 = P->alpha * 0.0625f, oma = 1.f - P->alpha;  // (dis_term: the 1/16 of the gradient term folded in)
-    const float tau_color = P->tau_color, taug16 = P->tau_gradient * 16.0f;
+    const MagicAddr MA = magic_addr(P);
+    const DisConst K = dis_const(P);
     const float centre = tp0[0];
-    const float pwf = (float)P->pw;
-    const float magic_c = kMagicF + (float)(2 * P->pw + 2);
+    const PlaneRef pr = plane_of_magic(magic_base, P);
     const char *lut_magic = (const char *)lut - kMagicBits;
-    const float H1 = H[1], H4 = H[4], H7 = H[7];
-
-    auto request = [&](float X0, float Y0, float Z0, float qy) -> WinReq {
-        const float X = __builtin_fmaf(H1, qy, X0);
-        const float Y = __builtin_fmaf(H4, qy, Y0);
-        const float Z = __builtin_fmaf(H7, qy, Z0);
-        const float rz = recip<FAST>(Z);
-        const float sx = X * rz, sy = Y * rz;
-        const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
-        WinReq r;
-        r.a = sx - fx0;
-        r.b = sy - fy0;
-        const float Xc = __builtin_amdgcn_fmed3f(fx0, -2.0f, colsf);
-        const float Yc = __builtin_amdgcn_fmed3f(fy0, -2.0f, rowsf);
-        const uint32_t off = __float_as_uint(__builtin_fmaf(Yc, pwf, Xc + magic_c));
-        r.w = *(gptr_u32x4)(magic_base + off);
-        return r;
-    };
+    const WarpRow wr = warp_row(H);
 
     const float qy0 = (float)(py - R);
     float qx = (float)(px - R + 2 * c0);  // (exact: small integers)
-    float X0 = __builtin_fmaf(H[0], qx, H[2]);
-    float Y0 = __builtin_fmaf(H[3], qx, H[5]);
-    float Z0 = __builtin_fmaf(H[6], qx, H[8]);
-    WinReq r0 = request(X0, Y0, Z0, qy0), r1 = request(X0, Y0, Z0, qy0 + 2.0f);
+    WarpCol wc = warp_col(H, qx);
+    WinReq r0 = magic_request<FAST>(MA, magic_base, wc, wr, qy0), r1 = magic_request<FAST>(MA, magic_base, wc, wr, qy0 + 2.0f);
     const float *tcol = tp0 + 4 * (-R * tw - R) + 8 * c0;
     int c = c0;
     for (; c < c1; c++, tcol += 8) {
         const float qxn = qx + 2.0f;
-        const float X0n = __builtin_fmaf(H[0], qxn, H[2]);
-        const float Y0n = __builtin_fmaf(H[3], qxn, H[5]);
-        const float Z0n = __builtin_fmaf(H[6], qxn, H[8]);
+        const WarpCol wcn = warp_col(H, qxn);
 #pragma unroll
         for (int k = 0; k < N; k++) {
             const WinReq cur = r0;
             r0 = r1;
             if (k + 2 < N)
-                r1 = request(X0, Y0, Z0, qy0 + (float)(2 * (k + 2)));
+                r1 = magic_request<FAST>(MA, magic_base, wc, wr, qy0 + (float)(2 * (k + 2)));
             else
-                r1 = request(X0n, Y0n, Z0n, qy0 + (float)(2 * (k + 2 - N)));
+                r1 = magic_request<FAST>(MA, magic_base, wcn, wr, qy0 + (float)(2 * (k + 2 - N)));
             __builtin_amdgcn_sched_barrier(0);
             const float4 t4 = *reinterpret_cast<const float4 *>(tcol + 8 * k * tw);
-            const float colorDis = __builtin_fabsf(t4.x - centre);
-            const float w = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
-            const Taps tp5 = taps_u8(cur.a, cur.b, cur.w.x, cur.w.y, cur.w.z, cur.w.w);
-            const float colDiff = t4.w - tp5.sc;
-            const float gradX = t4.y - tp5.gx2;
-            const float gradY = t4.z - tp5.gy2;
-            const float gradDis = min_nc(__builtin_fabsf(gradX) + __builtin_fabsf(gradY), taug16);
-            const float colDis = min_abs_nc(colDiff, tau_color);
-            const float dis = __builtin_fmaf(alpha16, gradDis, oma * colDis);
-            cost = __builtin_fmaf(w, dis, cost);
+            const float w = lut_weight(lut_magic, t4.x, centre);
+            const float dis = gray_dis(K, cur, t4.w, t4.y, t4.z, pr);
+            cost = accum(w, dis, cost);
             __builtin_amdgcn_sched_barrier(0);
         }
         qx = qxn;
-        X0 = X0n;
-        Y0 = Y0n;
-        Z0 = Z0n;
+        wc = wcn;
         if (__all(cost >= tau)) {
             c++;
             break;
@@ -404,6 +402,77 @@ __device__ __forceinline__ float l1_3(float x, float y, float z)
     return (__builtin_fabsf(x) + __builtin_fabsf(y) + __builtin_fabsf(z)) * 0.3333333f;
 }
 
+// ---- shared pieces of the packed-colour loops (three words per texel: integer window addressing) ----
+struct WinReq3 {
+    float a, b;  // what win_pos keeps (see WinReq)
+    u32x4_a4 q0, q1, q2;
+};
+struct IntAddr {
+    uint32_t pw, xmax, ymax;
+};
+__device__ __forceinline__ IntAddr int_addr(const Problem *__restrict__ P)
+{
+    IntAddr A;
+    A.pw = (uint32_t)P->pw;
+    A.xmax = (uint32_t)(P->cols + 2);
+    A.ymax = (uint32_t)(P->rows + 2);
+    return A;
+}
+__device__ __forceinline__ WinReq3 c4_window_load(const IntAddr &A, gptr_bytes packed, float sx, float sy)
+{
+    const WinPos wp = win_pos(sx, sy);
+    WinReq3 r;
+    r.a = wp.ka;
+    r.b = wp.kb;
+    // X = clamp(floor, -2, cols) + 2, same for Y: the +2 is exact wherever the clamp does not saturate
+    const uint32_t Xw = min(cvt_u32_sat(wp.fx0 + 2.0f), A.xmax);
+    const uint32_t Yw = min(cvt_u32_sat(wp.fy0 + 2.0f), A.ymax);
+    const gptr_bytes base = packed + (Yw * A.pw + Xw) * 12u;
+    r.q0 = *(gptr_u32x4)(base);
+    r.q1 = *(gptr_u32x4)(base + 16);
+    r.q2 = *(gptr_u32x4)(base + 32);
+    return r;
+}
+template <bool FAST>
+__device__ __forceinline__ WinReq3 c4_request(const IntAddr &A, gptr_bytes packed, const WarpCol &wc, const WarpRow &wr, float qy)
+{
+    const Warped p = warp_point(wc, wr, qy);
+    float sx, sy;
+    warp_divide<FAST>(p, sx, sy);
+    return c4_window_load(A, packed, sx, sy);
+}
+__device__ __forceinline__ WinReq3 c4_request_rt(const IntAddr &A, gptr_bytes packed, const WarpCol &wc, const WarpRow &wr, float qy,
+                                                 bool fast)
+{
+    const Warped p = warp_point(wc, wr, qy);
+    float sx, sy;
+#if PM_APPROX
+    warp_divide<true>(p, sx, sy);
+    (void)fast;
+#else
+    if (fast)
+        warp_divide<true>(p, sx, sy);
+    else
+        warp_divide<false>(p, sx, sy);
+#endif
+    return c4_window_load(A, packed, sx, sy);
+}
+// the taps of the three channels of a colour sample: word 3k+c of the 12-word window = column k, channel c
+__device__ __forceinline__ void c4_taps(const WinReq3 &r, const PlaneRef &pr, Taps (&t)[3])
+{
+    const Tex12 tb = unpack12(r.q0.x, r.q0.w, r.q1.z, r.q2.y);
+    const Tex12 tg = unpack12(r.q0.y, r.q1.x, r.q1.w, r.q2.z);
+    const Tex12 tr = unpack12(r.q0.z, r.q1.y, r.q2.x, r.q2.w);
+    sample_taps_c4(r.a, r.b, tb, tg, tr, pr, t);
+}
+__device__ __forceinline__ PlaneRef plane_of(gptr_bytes packed, const Problem *__restrict__ P)
+{
+    PlaneRef pr;
+    pr.packed = packed;
+    pr.P = P;
+    return pr;
+}
+
 template <int BOX, bool U8, bool FAST, bool ET = false>
 __device__ __forceinline__ float view_cost_c4_loop(const Problem *__restrict__ P, const ViewCam &vc,
                                                    const float *__restrict__ H, const float *__restrict__ tp0,
@@ -414,9 +483,9 @@ __device__ __forceinline__ float view_cost_c4_loop(const Problem *__restrict__ P
     // (c0, c1, cost0: window columns [c0, c1) only, continuing from the partial sum cost0 -- see
     //  view_cost_pipe_range / refine_two_phase)
     const gptr_f32 img = (gptr_f32)vc.img.raw;
-    const uint32_t *__restrict__ packed = vc.packed;
-    const uint32_t pw = (uint32_t)P->pw;
-    const uint32_t xmax = (uint32_t)(P->cols + 2), ymax = (uint32_t)(P->rows + 2);
+    const gptr_bytes packed = (gptr_bytes)vc.packed.raw;
+    const IntAddr IA = int_addr(P);
+    const PlaneRef pr = plane_of(packed, P);
     const int rows = P->rows, cols = P->cols, pitch = P->pitch;
     const float colsf = (float)cols, rowsf = (float)rows;
     // (compile-time boxes: the 1/16 of the gradient term folded into the constants, see dis_fold; BOX == 0 is the
@@ -427,11 +496,13 @@ __device__ __forceinline__ float view_cost_c4_loop(const Problem *__restrict__ P
     const float4 centre = *reinterpret_cast<const float4 *>(tp0);
     const int hr = win.hrad(), vr = win.vrad();
     float cost = cost0;
-#if PM_LITERAL
+#if PM_MODEL & 1
     if constexpr (!U8) {
-        // T = float4 in the reference's own operation order (see view_cost_loop): per channel one bilinear fetch per tap,
-        // l1_norm(float4) = (|x| + |y| + |z|) * 0.3333333f (gipuma.cu:174-179), the float4 operators of vector_operations.h
-        (void)c0; (void)c1; (void)cols_run; (void)tau;
+        // Float planes, T = float4 in the reference's own operation order (see view_cost_loop): per channel one bilinear fetch
+        // per tap, l1_norm(float4) = (|x| + |y| + |z|) * 0.3333333f (gipuma.cu:174-179), the float4 operators of
+        // vector_operations.h.  Whole windows only: the ranged callers (tp_item) run on packed planes.
+        (void)c1; (void)cols_run; (void)tau;
+        if (c0 != 0 || cost0 != 0.0f) __builtin_trap();
         const float alpha = P->alpha;
         for (int i = -hr; i <= hr; i += 2) {
             for (int j = -vr; j <= vr; j += 2) {
@@ -471,12 +542,11 @@ __device__ __forceinline__ float view_cost_c4_loop(const Problem *__restrict__ P
         return cost;
     }
 #endif
+    const WarpRow wr = warp_row(H);
     float qx = (float)(px - hr + 2 * c0);
     int col = c0;
     for (int i = -hr + 2 * c0; i <= hr && col < c1; i += 2, qx += 2.0f) {
-        const float X0 = __builtin_fmaf(H[0], qx, H[2]);
-        const float Y0 = __builtin_fmaf(H[3], qx, H[5]);
-        const float Z0 = __builtin_fmaf(H[6], qx, H[8]);
+        const WarpCol wc = warp_col(H, qx);
         float qy = (float)(py - vr);
         for (int j = -vr; j <= vr; j += 2, qy += 2.0f) {
             const float *tp = tp0 + 4 * (j * tw + i);
@@ -489,27 +559,17 @@ __device__ __forceinline__ float view_cost_c4_loop(const Problem *__restrict__ P
             } else {
                 w = exp_model(-l1_3(lv.x - centre.x, lv.y - centre.y, lv.z - centre.z) / gamma);
             }
-            const float X = __builtin_fmaf(H[1], qy, X0);
-            const float Y = __builtin_fmaf(H[4], qy, Y0);
-            const float Z = __builtin_fmaf(H[7], qy, Z0);
-            const float rz = recip<FAST>(Z);
-            const float sx = X * rz, sy = Y * rz;
-            const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
-            const float a = sx - fx0, b = sy - fy0;
             Taps t[3];
             if (U8) {
-                const uint32_t Xw = min(cvt_u32_sat(fx0 + 2.0f), xmax);
-                const uint32_t Yw = min(cvt_u32_sat(fy0 + 2.0f), ymax);
-                const uint32_t off = (Yw * pw + Xw) * 12u;
-                const gptr_bytes base = (gptr_bytes)packed + off;
-                const u32x4_a4 q0 = *(gptr_u32x4)(base), q1 = *(gptr_u32x4)(base + 16), q2 = *(gptr_u32x4)(base + 32);
-                // word 3k+c = column k, channel c
-                t[0] = taps_u8(a, b, q0.x, q0.w, q1.z, q2.y);
-                t[1] = taps_u8(a, b, q0.y, q1.x, q1.w, q2.z);
-                t[2] = taps_u8(a, b, q0.z, q1.y, q2.x, q2.w);
+                c4_taps(c4_request<FAST>(IA, packed, wc, wr, qy), pr, t);
             } else {
-                const int ix = (int)__builtin_fminf(__builtin_fmaxf(fx0, -2.0f), colsf);
-                const int iy = (int)__builtin_fminf(__builtin_fmaxf(fy0, -2.0f), rowsf);
+                const Warped p = warp_point(wc, wr, qy);
+                float sx, sy;
+                warp_divide<FAST>(p, sx, sy);
+                const WinPos wp = win_pos(sx, sy);  // (model taps; the literal ones on float planes: the branch above)
+                const float a = wp.ka, b = wp.kb;
+                const int ix = (int)__builtin_fminf(__builtin_fmaxf(wp.fx0, -2.0f), colsf);
+                const int iy = (int)__builtin_fminf(__builtin_fmaxf(wp.fy0, -2.0f), rowsf);
                 const int c0 = 4 * clampi(ix - 1, 0, cols - 1), c1 = 4 * clampi(ix, 0, cols - 1);
                 const int c2 = 4 * clampi(ix + 1, 0, cols - 1), c3 = 4 * clampi(ix + 2, 0, cols - 1);
                 const int r0 = clampi(iy - 1, 0, rows - 1) * pitch, r1 = clampi(iy, 0, rows - 1) * pitch;
@@ -529,10 +589,8 @@ __device__ __forceinline__ float view_cost_c4_loop(const Problem *__restrict__ P
                                   (right.z - left.z) - t[2].gx2);
             const float gY = l1_3((down.x - up.x) - t[0].gy2, (down.y - up.y) - t[1].gy2,
                                   (down.z - up.z) - t[2].gy2);
-            const float gradDis = min_nc(kFold ? gX + gY : (gX + gY) * 0.0625f, taug16);
-            const float colDis = min_nc(colDiff, tau_color);
-            const float dis = __builtin_fmaf(alpha16, gradDis, oma * colDis);
-            cost = __builtin_fmaf(w, dis, cost);
+            const float dis = dis_folded<false>(kFold ? gX + gY : (gX + gY) * 0.0625f, colDiff, alpha16, oma, tau_color, taug16);
+            cost = accum(w, dis, cost);
         }
         col++;
         if (ET && __all(cost >= tau)) break;  // early termination, see multiview_cost
@@ -681,9 +739,9 @@ __device__ __forceinline__ float multiview_cost(const Problem *__restrict__ P, c
 // each of the N row steps the 8 lanes sample the same plane at points 2 pixels apart, i.e. windows
 // that share one to three lines, and a wavefront (8 pairs) touches ~20 lines per load instead of
 // ~64.  Every sample is computed by the same instruction sequence as in view_cost_pipe.  The
-// reference's summation order (columns outer, rows inner, one fmaf per sample into a single
-// accumulator, gipuma.cu:633-676) is kept by a relay: each lane stores the N (w, dis) pairs of its
-// column; in relay step c every lane re-runs its N fmafs starting from the value its left
+// reference's summation order (columns outer, rows inner, one accumulation per sample into a single
+// accumulator, gipuma.cu:633-676) is kept by a relay: each lane stores the N terms of its
+// column; in relay step c every lane re-runs its N accumulations starting from the value its left
 // neighbour produced in step c-1, so after step c lane c holds the exact prefix over columns 0..c
 // (the other lanes' values are never used).  N*(N+1) extra instructions per N samples per lane --
 // irrelevant where the launch is bound by line fills.
@@ -731,40 +789,20 @@ __device__ __forceinline__ float view_cost_cols(const Problem *__restrict__ P, c
 {
     constexpr int R = (BOX - 1) / 2, N = R + 1;
     static_assert(BOX > 0 && N <= col_group<BOX>(), "one lane per window column");
-    const float colsf = (float)P->cols, rowsf = (float)P->rows;
-    const float alpha16 = P->alpha * 0.0625f, oma = 1.f - P->alpha;  // (dis_term: the 1/16 of the gradient term folded in)
-    const float tau_color = P->tau_color, taug16 = P->tau_gradient * 16.0f;
+    const MagicAddr MA = magic_addr(P);
+    const DisConst K = dis_const(P);
     const float centre = tp0[0];
-    const float pwf = (float)P->pw;
-    const float magic_c = kMagicF + (float)(2 * P->pw + 2);
-    const gptr_bytes magic_base = (gptr_bytes)((uintptr_t)vc.packed.raw - (uintptr_t)kMagicBits);
+    const gptr_bytes magic_base = magic_base_of(vc);
+    const PlaneRef pr = plane_of_magic(magic_base, P);
     const char *lut_magic = (const char *)lut - kMagicBits;
-    const float H1 = H[1], H4 = H[4], H7 = H[7];
+    const WarpRow wr = warp_row(H);
     const int mycol = col < N ? col : N - 1;  // spare lanes of a smaller box shadow the last column
     const float qx = (float)(px - R + 2 * mycol);
-    const float X0 = __builtin_fmaf(H[0], qx, H[2]);
-    const float Y0 = __builtin_fmaf(H[3], qx, H[5]);
-    const float Z0 = __builtin_fmaf(H[6], qx, H[8]);
-
-    auto request = [&](float qy) -> WinReq {
-        const float X = __builtin_fmaf(H1, qy, X0);
-        const float Y = __builtin_fmaf(H4, qy, Y0);
-        const float Z = __builtin_fmaf(H7, qy, Z0);
-        const float rz = recip<FAST>(Z);
-        const float sx = X * rz, sy = Y * rz;
-        const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
-        WinReq r;
-        r.a = sx - fx0;
-        r.b = sy - fy0;
-        const float Xc = __builtin_amdgcn_fmed3f(fx0, -2.0f, colsf);
-        const float Yc = __builtin_amdgcn_fmed3f(fy0, -2.0f, rowsf);
-        const uint32_t off = __float_as_uint(__builtin_fmaf(Yc, pwf, Xc + magic_c));
-        r.w = *(gptr_u32x4)(magic_base + off);
-        return r;
-    };
+    const WarpCol wc = warp_col(H, qx);
 
     const float qy0 = (float)(py - R);
     const float *tcol = tp0 + 4 * (-R * tw - R + 2 * mycol);  // texel (column, -R) of the window
+    // per row of the lane's column: the weight and dis (fused model) or their product (unfused: what the chain adds)
     float wgt[N], dis[N];
     // PD window requests in flight (these launches wait on L2 misses, and the kernel has registers
     // to spare below its 3-wavefront budget)
@@ -772,21 +810,14 @@ __device__ __forceinline__ float view_cost_cols(const Problem *__restrict__ P, c
     constexpr int PD = PDmax < N ? PDmax : N;
     WinReq req[PD];
 #pragma unroll
-    for (int p = 0; p < PD; p++) req[p] = request(qy0 + (float)(2 * p));
+    for (int p = 0; p < PD; p++) req[p] = magic_request<FAST>(MA, magic_base, wc, wr, qy0 + (float)(2 * p));
 #pragma unroll
     for (int k = 0; k < N; k++) {
         const WinReq cur = req[k % PD];
-        if (k + PD < N) req[k % PD] = request(qy0 + (float)(2 * (k + PD)));
+        if (k + PD < N) req[k % PD] = magic_request<FAST>(MA, magic_base, wc, wr, qy0 + (float)(2 * (k + PD)));
         const float4 t4 = *reinterpret_cast<const float4 *>(tcol + 8 * k * tw);
-        const float colorDis = __builtin_fabsf(t4.x - centre);
-        wgt[k] = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
-        const Taps tp5 = taps_u8(cur.a, cur.b, cur.w.x, cur.w.y, cur.w.z, cur.w.w);
-        const float colDiff = t4.w - tp5.sc;
-        const float gradX = t4.y - tp5.gx2;
-        const float gradY = t4.z - tp5.gy2;
-        const float gradDis = min_nc(__builtin_fabsf(gradX) + __builtin_fabsf(gradY), taug16);
-        const float colDis = min_abs_nc(colDiff, tau_color);
-        dis[k] = __builtin_fmaf(alpha16, gradDis, oma * colDis);
+        wgt[k] = lut_weight(lut_magic, t4.x, centre);
+        dis[k] = accum_term(wgt[k], gray_dis(K, cur, t4.w, t4.y, t4.z, pr));
     }
 #if PM_APPROX && defined(PM_APPROX_TREE_SUM)  // (A/B builds only: measured, no gain, costs agreement)
     return cols_tree_sum<BOX>(wgt, dis, col);
@@ -799,7 +830,7 @@ __device__ __forceinline__ float view_cost_cols(const Problem *__restrict__ P, c
         float acc = c == 0 ? 0.0f
                            : __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(out), 0x111, 0xf, 0xf, false));
 #pragma unroll
-        for (int k = 0; k < N; k++) acc = __builtin_fmaf(wgt[k], dis[k], acc);
+        for (int k = 0; k < N; k++) acc = accum_add(wgt[k], dis[k], acc);
         out = acc;
     }
     return out;  // exact in lane N-1 of the group
@@ -809,10 +840,6 @@ __device__ __forceinline__ float view_cost_cols(const Problem *__restrict__ P, c
 // arithmetic of view_cost_c4_loop (three 16-byte window loads and tap sets per sample, l1_norm(float4)
 // reductions, weight table indexed by |dB|+|dG|+|dR|, integer window addressing), the relay keeps the
 // reference's summation order.  `tp0` points at the pixel's own texel in the float4 {B, G, R, 0} tile.
-struct WinReq3 {
-    float a, b;
-    u32x4_a4 q0, q1, q2;
-};
 template <int BOX, bool FAST>
 __device__ __forceinline__ float view_cost_cols_c4(const Problem *__restrict__ P, const ViewCam &vc,
                                                    const float *__restrict__ H, const float *__restrict__ tp0,
@@ -821,36 +848,14 @@ __device__ __forceinline__ float view_cost_cols_c4(const Problem *__restrict__ P
     constexpr int R = (BOX - 1) / 2, N = R + 1;
     static_assert(BOX > 0 && N <= col_group<BOX>(), "one lane per window column");
     const gptr_bytes packed = (gptr_bytes)vc.packed.raw;
-    const uint32_t pw = (uint32_t)P->pw;
-    const uint32_t xmax = (uint32_t)(P->cols + 2), ymax = (uint32_t)(P->rows + 2);
-    const float alpha16 = P->alpha * 0.0625f, oma = 1.f - P->alpha;  // (dis_term: the 1/16 of the gradient term folded in)
-    const float tau_color = P->tau_color, taug16 = P->tau_gradient * 16.0f;
+    const IntAddr IA = int_addr(P);
+    const PlaneRef pr = plane_of(packed, P);
+    const DisConst K = dis_const(P);
     const float4 centre = *reinterpret_cast<const float4 *>(tp0);
-    const float H1 = H[1], H4 = H[4], H7 = H[7];
+    const WarpRow wr = warp_row(H);
     const int mycol = col < N ? col : N - 1;
     const float qx = (float)(px - R + 2 * mycol);
-    const float X0 = __builtin_fmaf(H[0], qx, H[2]);
-    const float Y0 = __builtin_fmaf(H[3], qx, H[5]);
-    const float Z0 = __builtin_fmaf(H[6], qx, H[8]);
-
-    auto request = [&](float qy) -> WinReq3 {
-        const float X = __builtin_fmaf(H1, qy, X0);
-        const float Y = __builtin_fmaf(H4, qy, Y0);
-        const float Z = __builtin_fmaf(H7, qy, Z0);
-        const float rz = recip<FAST>(Z);
-        const float sx = X * rz, sy = Y * rz;
-        const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
-        WinReq3 r;
-        r.a = sx - fx0;
-        r.b = sy - fy0;
-        const uint32_t Xw = min(cvt_u32_sat(fx0 + 2.0f), xmax);
-        const uint32_t Yw = min(cvt_u32_sat(fy0 + 2.0f), ymax);
-        const gptr_bytes base = packed + (Yw * pw + Xw) * 12u;
-        r.q0 = *(gptr_u32x4)(base);
-        r.q1 = *(gptr_u32x4)(base + 16);
-        r.q2 = *(gptr_u32x4)(base + 32);
-        return r;
-    };
+    const WarpCol wc = warp_col(H, qx);
 
     const float qy0 = (float)(py - R);
     const float *tcol = tp0 + 4 * (-R * tw - R + 2 * mycol);  // texel (column, -R) of the window
@@ -861,20 +866,18 @@ __device__ __forceinline__ float view_cost_cols_c4(const Problem *__restrict__ P
     constexpr int PD = PM_COLS_C4_PD < N ? PM_COLS_C4_PD : N;  // window requests (three loads each) in flight
     WinReq3 req[PD];
 #pragma unroll
-    for (int p = 0; p < PD; p++) req[p] = request(qy0 + (float)(2 * p));
+    for (int p = 0; p < PD; p++) req[p] = c4_request<FAST>(IA, packed, wc, wr, qy0 + (float)(2 * p));
 #pragma unroll
     for (int k = 0; k < N; k++) {
         const WinReq3 cur = req[k % PD];
-        if (k + PD < N) req[k % PD] = request(qy0 + (float)(2 * (k + PD)));
+        if (k + PD < N) req[k % PD] = c4_request<FAST>(IA, packed, wc, wr, qy0 + (float)(2 * (k + PD)));
         const float *tp = tcol + 8 * k * tw;
         const float4 lv = *reinterpret_cast<const float4 *>(tp);
         const float S = __builtin_fabsf(lv.x - centre.x) + __builtin_fabsf(lv.y - centre.y) +
                         __builtin_fabsf(lv.z - centre.z);  // exact integer 0..765
         wgt[k] = lut[(int)S];
-        Taps t[3];  // word 3k+c = column k, channel c
-        t[0] = taps_u8(cur.a, cur.b, cur.q0.x, cur.q0.w, cur.q1.z, cur.q2.y);
-        t[1] = taps_u8(cur.a, cur.b, cur.q0.y, cur.q1.x, cur.q1.w, cur.q2.z);
-        t[2] = taps_u8(cur.a, cur.b, cur.q0.z, cur.q1.y, cur.q2.x, cur.q2.w);
+        Taps t[3];
+        c4_taps(cur, pr, t);
         const float4 up = *reinterpret_cast<const float4 *>(tp - 4 * tw);
         const float4 down = *reinterpret_cast<const float4 *>(tp + 4 * tw);
         const float4 left = *reinterpret_cast<const float4 *>(tp - 4);
@@ -884,9 +887,7 @@ __device__ __forceinline__ float view_cost_cols_c4(const Problem *__restrict__ P
                               (right.z - left.z) - t[2].gx2);
         const float gY = l1_3((down.x - up.x) - t[0].gy2, (down.y - up.y) - t[1].gy2,
                               (down.z - up.z) - t[2].gy2);
-        const float gradDis = min_nc(gX + gY, taug16);
-        const float colDis = min_nc(colDiff, tau_color);
-        dis[k] = __builtin_fmaf(alpha16, gradDis, oma * colDis);
+        dis[k] = accum_term(wgt[k], dis_folded<false>(gX + gY, colDiff, K.alpha16, K.oma, K.tau_color, K.taug16));
     }
 #if PM_APPROX && defined(PM_APPROX_TREE_SUM)  // (A/B builds only: measured, no gain, costs agreement)
     return cols_tree_sum<BOX>(wgt, dis, col);
@@ -898,7 +899,7 @@ __device__ __forceinline__ float view_cost_cols_c4(const Problem *__restrict__ P
         float acc = c == 0 ? 0.0f
                            : __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(out), 0x111, 0xf, 0xf, false));
 #pragma unroll
-        for (int k = 0; k < N; k++) acc = __builtin_fmaf(wgt[k], dis[k], acc);
+        for (int k = 0; k < N; k++) acc = accum_add(wgt[k], dis[k], acc);
         out = acc;
     }
     return out;  // exact in lane N-1 of the group

@@ -176,14 +176,11 @@ __device__ __forceinline__ uint32_t plane_hash(float4 pl, int cls)
     return (h + (uint32_t)cls) & (kGrpHashSize - 1);
 }
 
-// One strip of one view for the walk below: the per-column terms of view_cost_pipe (X0, Y0, Z0 of getCorrespondingPoint_cu,
+// One strip of one view for the walk below: the per-column terms of view_cost_pipe (warp_col: getCorrespondingPoint_cu,
 // gipuma.cu:207-217) and the row coefficients of the view's homography
 struct StripView {
-    float X0, Y0, Z0, H1, H4, H7;
-};
-// the twelve texels of a 4x4 window the five taps read (corners unused), t<row><col>
-struct Tex12 {
-    float t01, t02, t10, t11, t12, t13, t20, t21, t22, t23, t31, t32;
+    WarpCol wc;
+    WarpRow wr;
 };
 
 // The strip of one lane for one view.  Per sample the arithmetic is view_cost_pipe's (getCorrespondingPoint_cu
@@ -200,7 +197,9 @@ template <int BOX>
 struct GroupWalk {
     using LY = GroupLayout<BOX>;
     static constexpr int tw = LY::tw;
-    float colsf, rowsf, pwf, magic_c, alpha, oma, tau_color, tau_gradient;  // wave-uniform
+    MagicAddr MA;  // wave-uniform
+    DisConst K;    // (alpha / 16 and 16 tau_g: dis_fold, pm_sample.h)
+    const Problem *P;
     // this lane's strip: first sample point, reference texel of that point in the plane, where its dis values go,
     // and its group's slot in the batch tables
     float qx, qy0;
@@ -215,16 +214,11 @@ struct GroupWalk {
         WinReq req;        // the window it holds (or that is on its way)
     };
 
-    __device__ __forceinline__ void init(const Problem *__restrict__ P)
+    __device__ __forceinline__ void init(const Problem *__restrict__ P_)
     {
-        colsf = (float)P->cols;
-        rowsf = (float)P->rows;
-        pwf = (float)P->pw;
-        magic_c = kMagicF + (float)(2 * P->pw + 2);
-        alpha = P->alpha * 0.0625f;  // (dis_fold, pm_cost.h: alpha / 16 and 16 tau_g)
-        oma = 1.f - P->alpha;
-        tau_color = P->tau_color;
-        tau_gradient = P->tau_gradient * 16.0f;
+        P = P_;
+        MA = magic_addr(P_);
+        K = dis_const(P_);
     }
     __device__ __forceinline__ StripView view_of(const float *__restrict__ hb) const
     {
@@ -232,68 +226,33 @@ struct GroupWalk {
         const float4 a = *reinterpret_cast<const float4 *>(hb + 12 * grp);
         const float4 b = *reinterpret_cast<const float4 *>(hb + 12 * grp + 4);
         const float4 c = *reinterpret_cast<const float4 *>(hb + 12 * grp + 8);
+        const float H[9] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x};
         StripView s;
-        s.X0 = __builtin_fmaf(a.x, qx, a.z);  // H0 qx + H2
-        s.Y0 = __builtin_fmaf(a.w, qx, b.y);  // H3 qx + H5
-        s.Z0 = __builtin_fmaf(b.z, qx, c.x);  // H6 qx + H8
-        s.H1 = a.y;
-        s.H4 = b.x;
-        s.H7 = b.w;
+        s.wc = warp_col(H, qx);
+        s.wr = warp_row(H);
         return s;
     }
-    // (`fast`, wave-uniform: the fast reciprocal is exact on the batch's boxes for this view.  ONE loop with a scalar branch
+    // (`fast`, wave-uniform: the cheap division is exact on the batch's boxes for this view.  ONE loop with a scalar branch
     //  per sample instead of two specialised loops: with two, the waits the compiler placed in the second one drained
     //  both window loads at the top of every iteration -- vmcnt(0) where the first has vmcnt(1) twice --, which left a
     //  load only the other set's reduce to arrive in.)
     __device__ __forceinline__ WinReq request(gptr_bytes magic_base, const StripView &s, float qy, bool fast) const
     {
-        const float X = __builtin_fmaf(s.H1, qy, s.X0);
-        const float Y = __builtin_fmaf(s.H4, qy, s.Y0);
-        const float Z = __builtin_fmaf(s.H7, qy, s.Z0);
-        float rz;
-#if PM_APPROX
-        rz = rcp_newton(Z);
-        (void)fast;
-#else
-        if (fast)
-            rz = rcp_newton(Z);
-        else
-            rz = 1.0f / Z;
-#endif
-        const float sx = X * rz, sy = Y * rz;
-        const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
-        WinReq r;
-        r.a = sx - fx0;
-        r.b = sy - fy0;
-        const float Xc = __builtin_amdgcn_fmed3f(fx0, -2.0f, colsf);
-        const float Yc = __builtin_amdgcn_fmed3f(fy0, -2.0f, rowsf);
-        const uint32_t off = __float_as_uint(__builtin_fmaf(Yc, pwf, Xc + magic_c));
-        r.w = *(gptr_u32x4)(magic_base + off);
-        return r;
+        return magic_request_rt(MA, magic_base, s.wc, s.wr, qy, fast);
     }
-    // window words w0..w3 = columns X..X+3, byte r = row Y+r (taps_u8)
-    static __device__ __forceinline__ Tex12 unpack(const u32x4_a4 &w)
-    {
-        Tex12 t;
-        t.t01 = ub0(w.y); t.t02 = ub0(w.z);
-        t.t10 = ub1(w.x); t.t11 = ub1(w.y); t.t12 = ub1(w.z); t.t13 = ub1(w.w);
-        t.t20 = ub2(w.x); t.t21 = ub2(w.y); t.t22 = ub2(w.z); t.t23 = ub2(w.w);
-        t.t31 = ub3(w.y); t.t32 = ub3(w.z);
-        return t;
-    }
+    // window words w0..w3 = columns X..X+3, byte r = row Y+r
+    static __device__ __forceinline__ Tex12 unpack(const u32x4_a4 &w) { return unpack12(w.x, w.y, w.z, w.w); }
     // (I: the reference texel of the sample; xr, xl, yd, yu: its right / left / lower / upper neighbours)
-    __device__ __forceinline__ void reduce(const Tex12 &t, float a, float b, float I, float xr, float xl, float yd,
-                                           float yu, float *__restrict__ o) const
+    __device__ __forceinline__ void reduce(gptr_bytes magic_base, const Tex12 &t, float a, float b, float I, float xr, float xl,
+                                           float yd, float yu, float *__restrict__ o) const
     {
         const float gx1 = xr - xl;
         const float gy1 = yd - yu;
-        const Taps tp5 = taps12(a, b, t.t01, t.t02, t.t10, t.t11, t.t12, t.t13, t.t20, t.t21, t.t22, t.t23, t.t31, t.t32);
+        const Taps tp5 = sample_taps_gray(a, b, t, plane_of_magic(magic_base, P));
         const float colDiff = I - tp5.sc;
         const float gradX = gx1 - tp5.gx2;
         const float gradY = gy1 - tp5.gy2;
-        const float gradDis = min_nc(__builtin_fabsf(gradX) + __builtin_fabsf(gradY), tau_gradient);
-        const float colDis = min_abs_nc(colDiff, tau_color);
-        *o = __builtin_fmaf(alpha, gradDis, oma * colDis);
+        *o = dis_folded<true>(__builtin_fabsf(gradX) + __builtin_fabsf(gradY), colDiff, K.alpha16, K.oma, K.tau_color, K.taug16);
     }
     // the first two window requests of a view (rows 0 and 1)
     __device__ __forceinline__ void first(gptr_bytes magic_base, const float *__restrict__ hb, StripView &sv, Set &A,
@@ -327,7 +286,7 @@ struct GroupWalk {
             S.o = o + 2;
         }
         __builtin_amdgcn_sched_barrier(0);
-        reduce(t, a, b, I, xr, xl, yd, yu, o);
+        reduce(magic_base, t, a, b, I, xr, xl, yd, yu, o);
         __builtin_amdgcn_sched_barrier(0);
     }
     // the nr rows (wave-uniform, >= 3) of this lane's strip for the view whose first two requests are in (A, B):
@@ -362,17 +321,15 @@ template <int BOX>
 struct GroupWalkC4 {
     using LY = GroupLayout<BOX, 4>;
     static constexpr int tw = LY::tw;
-    float alpha, oma, tau_color, tau_gradient;  // wave-uniform (alpha / 16 and 16 tau_g: dis_fold, pm_cost.h)
-    uint32_t pw, xmax, ymax;
+    DisConst K;  // wave-uniform (alpha / 16 and 16 tau_g: dis_fold, pm_sample.h)
+    IntAddr IA;
+    const Problem *P;
     float qx, qy0;
     const float *tcol;  // the float4 texel of the strip's first sample point
     float *out;
     int grp;
 
-    struct Req {
-        float a, b;
-        u32x4_a4 q0, q1, q2;
-    };
+    typedef WinReq3 Req;
     struct Set {
         float qy;
         const float *tq;
@@ -380,57 +337,26 @@ struct GroupWalkC4 {
         Req req;
     };
 
-    __device__ __forceinline__ void init(const Problem *__restrict__ P)
+    __device__ __forceinline__ void init(const Problem *__restrict__ P_)
     {
-        alpha = P->alpha * 0.0625f;
-        oma = 1.f - P->alpha;
-        tau_color = P->tau_color;
-        tau_gradient = P->tau_gradient * 16.0f;
-        pw = (uint32_t)P->pw;
-        xmax = (uint32_t)(P->cols + 2);
-        ymax = (uint32_t)(P->rows + 2);
+        P = P_;
+        K = dis_const(P_);
+        IA = int_addr(P_);
     }
     __device__ __forceinline__ StripView view_of(const float *__restrict__ hb) const
     {
         const float4 a = *reinterpret_cast<const float4 *>(hb + 12 * grp);
         const float4 b = *reinterpret_cast<const float4 *>(hb + 12 * grp + 4);
         const float4 c = *reinterpret_cast<const float4 *>(hb + 12 * grp + 8);
+        const float H[9] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x};
         StripView s;
-        s.X0 = __builtin_fmaf(a.x, qx, a.z);
-        s.Y0 = __builtin_fmaf(a.w, qx, b.y);
-        s.Z0 = __builtin_fmaf(b.z, qx, c.x);
-        s.H1 = a.y;
-        s.H4 = b.x;
-        s.H7 = b.w;
+        s.wc = warp_col(H, qx);
+        s.wr = warp_row(H);
         return s;
     }
     __device__ __forceinline__ Req request(gptr_bytes packed, const StripView &s, float qy, bool fast) const
     {
-        const float X = __builtin_fmaf(s.H1, qy, s.X0);
-        const float Y = __builtin_fmaf(s.H4, qy, s.Y0);
-        const float Z = __builtin_fmaf(s.H7, qy, s.Z0);
-        float rz;
-#if PM_APPROX
-        rz = rcp_newton(Z);
-        (void)fast;
-#else
-        if (fast)
-            rz = rcp_newton(Z);
-        else
-            rz = 1.0f / Z;
-#endif
-        const float sx = X * rz, sy = Y * rz;
-        const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
-        Req r;
-        r.a = sx - fx0;
-        r.b = sy - fy0;
-        const uint32_t Xw = min(cvt_u32_sat(fx0 + 2.0f), xmax);
-        const uint32_t Yw = min(cvt_u32_sat(fy0 + 2.0f), ymax);
-        const gptr_bytes base = packed + (Yw * pw + Xw) * 12u;
-        r.q0 = *(gptr_u32x4)(base);
-        r.q1 = *(gptr_u32x4)(base + 16);
-        r.q2 = *(gptr_u32x4)(base + 32);
-        return r;
+        return c4_request_rt(IA, packed, s.wc, s.wr, qy, fast);
     }
     __device__ __forceinline__ void first(gptr_bytes packed, const float *__restrict__ hb, StripView &sv, Set &A, Set &B,
                                           bool fast) const
@@ -455,9 +381,9 @@ struct GroupWalkC4 {
         const float4 up = *reinterpret_cast<const float4 *>(tq - 4 * tw), down = *reinterpret_cast<const float4 *>(tq + 4 * tw);
         // word 3k+c = column k, channel c (view_cost_c4_loop)
         const Req &q = S.req;
-        const Tex12 tb = GroupWalk<BOX>::unpack(u32x4_a4{q.q0.x, q.q0.w, q.q1.z, q.q2.y});
-        const Tex12 tg = GroupWalk<BOX>::unpack(u32x4_a4{q.q0.y, q.q1.x, q.q1.w, q.q2.z});
-        const Tex12 tr = GroupWalk<BOX>::unpack(u32x4_a4{q.q0.z, q.q1.y, q.q2.x, q.q2.w});
+        const Tex12 tb = unpack12(q.q0.x, q.q0.w, q.q1.z, q.q2.y);
+        const Tex12 tg = unpack12(q.q0.y, q.q1.x, q.q1.w, q.q2.z);
+        const Tex12 tr = unpack12(q.q0.z, q.q1.y, q.q2.x, q.q2.w);
         const float a = q.a, b = q.b;
         __builtin_amdgcn_sched_barrier(0);
         if (!LAST) {
@@ -467,17 +393,14 @@ struct GroupWalkC4 {
             S.o = o + 2;
         }
         __builtin_amdgcn_sched_barrier(0);
-        auto taps = [&](const Tex12 &t) -> Taps {
-            return taps12(a, b, t.t01, t.t02, t.t10, t.t11, t.t12, t.t13, t.t20, t.t21, t.t22, t.t23, t.t31, t.t32);
-        };
-        const Taps t0 = taps(tb), t1 = taps(tg), t2 = taps(tr);
+        Taps t[3];
+        sample_taps_c4(a, b, tb, tg, tr, plane_of(packed, P), t);
+        const Taps &t0 = t[0], &t1 = t[1], &t2 = t[2];
         // pmCostComputation_shared for T = float4, gipuma.cu:251-274
         const float colDiff = l1_3(lv.x - t0.sc, lv.y - t1.sc, lv.z - t2.sc);
         const float gX = l1_3((right.x - left.x) - t0.gx2, (right.y - left.y) - t1.gx2, (right.z - left.z) - t2.gx2);
         const float gY = l1_3((down.x - up.x) - t0.gy2, (down.y - up.y) - t1.gy2, (down.z - up.z) - t2.gy2);
-        const float gradDis = min_nc(gX + gY, tau_gradient);
-        const float colDis = min_nc(colDiff, tau_color);
-        *o = __builtin_fmaf(alpha, gradDis, oma * colDis);
+        *o = dis_folded<false>(gX + gY, colDiff, K.alpha16, K.oma, K.tau_color, K.taug16);
         __builtin_amdgcn_sched_barrier(0);
     }
     __device__ __forceinline__ void body(gptr_bytes packed, int nr, const StripView &sv, Set &A, Set &B, bool fast) const
@@ -892,8 +815,7 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
                             const int ci = (kDual && N % 2 != 0 && i == NH - 1 && half != 0) ? 0 : i;
 #pragma unroll
                             for (int jj = 0; jj < N; jj++) {
-                                const float colorDis = __builtin_fabsf(tc[2 * jj * tw + 2 * ci] - centre);  // an integer 0..255
-                                wst[i * N + jj] = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
+                                wst[i * N + jj] = lut_weight(lut_magic, tc[2 * jj * tw + 2 * ci], centre);  // |dI|: an integer 0..255
                             }
                         }
                     }
@@ -959,7 +881,7 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int jj = 0; jj < N; jj++) cst = __builtin_fmaf(wst[i * N + jj], dv[i & 1][jj], cst);
+                        for (int jj = 0; jj < N; jj++) cst = accum(wst[i * N + jj], dv[i & 1][jj], cst);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 };
@@ -985,7 +907,7 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
                         }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int jj = 0; jj < N; jj++) cst = __builtin_fmaf(wv[i & 1][jj], dv[i & 1][jj], cst);
+                        for (int jj = 0; jj < N; jj++) cst = accum(wv[i & 1][jj], dv[i & 1][jj], cst);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 };

@@ -18,17 +18,19 @@ namespace pm {
 // them once per solve (kLbMax per pixel); lb_item sums the first K of them for one (candidate, view)
 // item, each term by the instruction sequence of view_cost_pipe (same bits per term).
 //
-// Rigour against rounding.  Let C be the reference's chain value (64 fmaf's in window order), T the exact
-// real sum of its terms, l the value lb_item accumulates over S of the terms (|S| <= 16, any order) and
-// T_S <= T their exact sum, u = 2^-24.  Every fmaf rounds a non-negative exact value to nearest, so
-// C >= T (1-u)^64 - 64 * 2^-150 and l <= T_S (1+u)^16 + 16 * 2^-150 (the absolute terms cover subnormal
-// partial sums).  Hence C >= l (1 - 81u) - 2^-143, and for l >= 2^-60
-//     L' = l * (1 - 2^-16)   (one more rounding, 2^-16 = 256 u)
+// Rigour against rounding.  Let C be the reference's chain value (n <= 169 accumulations in window order: box <= 25),
+// T the exact real sum of its terms, l the value lb_item accumulates over S of the terms (|S| = k <= 32, any order) and
+// T_S <= T their exact sum, u = 2^-24.  Every accumulation rounds non-negative exact values to nearest -- once (fmaf, model
+// bit 2 clear) or twice (the product, then the sum: the unfused models; r = 1 or 2 roundings) --, so
+// C >= T (1-u)^(r n) - r n 2^-150 and l <= T_S (1+u)^(r k) + r k 2^-150 (the absolute terms cover subnormal partial sums).
+// Hence C >= l (1 - r (n + k + 1) u) - 2^-140, and for l >= 2^-60
+//     L' = l * (1 - 2^-16)   fused: r (n + k + 1) u <= 202 u < 256 u = 2^-16 (one more rounding included)
+//     L' = l * (1 - 2^-15)   unfused: 404 u < 512 u
 // satisfies L' <= C.  An item with L' >= thr is decided: its view cost is at least L', which is what
 // the ViewCombiner gets -- "a lower bound >= thr", the case multiview_cost's proof calls an abandoned
 // view.  Everything else about refine_two_phase is unchanged.
 // ---------------------------------------------------------------------------------------------
-constexpr float kLbShrink = 0.9999847412109375f;  // 1 - 2^-16
+constexpr float kLbShrink = kUnfused ? 0.999969482421875f : 0.9999847412109375f;  // 1 - 2^-15 : 1 - 2^-16
 constexpr float kLbFloor = 0x1p-60f;
 
 // one lane per pixel; order[d * np + pixel] = {col, row} of samples 2d and 2d+1 (bytes 0..3), heaviest first.
@@ -113,14 +115,12 @@ __device__ __forceinline__ float lb_item(const Problem *__restrict__ P, gptr_byt
     // rolled loop was 2.5 % slower per view than the unrolled one (90.8 vs 88.5 ms).
     static_assert(BOX > 0, "compile-time window only");
     constexpr int R = (BOX - 1) / 2;
-    const float colsf = (float)P->cols, rowsf = (float)P->rows;
-    const float alpha16 = P->alpha * 0.0625f, oma = 1.f - P->alpha;  // (dis_fold, pm_cost.h)
-    const float tau_color = P->tau_color, taug16 = P->tau_gradient * 16.0f;
+    const MagicAddr MA = magic_addr(P);
+    const DisConst K = dis_const(P);
+    const PlaneRef pr = plane_of_magic(magic_base, P);
     const float centre = tp0[0];
-    const float pwf = (float)P->pw;
-    const float magic_c = kMagicF + (float)(2 * P->pw + 2);
     const char *lut_magic = (const char *)lut - kMagicBits;
-    const float H1 = H[1], H4 = H[4], H7 = H[7];
+    const WarpRow wr = warp_row(H);
     const float pxR = (float)(px - R), pyR = (float)(py - R);
     // byte offset of texel (col, row) of the window from tp0: 16 * ((2 row - R) * tw + 2 col - R), as the
     // low bits of the float 2^23 + 2^15 + offset (|offset| < 2^15: ulp 1, bits = 0x4b008000 + offset)
@@ -133,37 +133,22 @@ __device__ __forceinline__ float lb_item(const Problem *__restrict__ P, gptr_byt
     auto request = [&](float cif, float rif) -> LbReq {
         // window coordinates as view_cost_pipe forms them (exact small integers)
         const float qx = __builtin_fmaf(cif, 2.0f, pxR), qy = __builtin_fmaf(rif, 2.0f, pyR);
-        const float X0 = __builtin_fmaf(H[0], qx, H[2]);
-        const float Y0 = __builtin_fmaf(H[3], qx, H[5]);
-        const float Z0 = __builtin_fmaf(H[6], qx, H[8]);
-        const float X = __builtin_fmaf(H1, qy, X0);
-        const float Y = __builtin_fmaf(H4, qy, Y0);
-        const float Z = __builtin_fmaf(H7, qy, Z0);
-        const float rz = recip<FAST>(Z);
-        const float sx = X * rz, sy = Y * rz;
-        const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
+        const WinReq q = magic_request<FAST>(MA, magic_base, warp_col(H, qx), wr, qy);
         LbReq r;
-        r.a = sx - fx0;
-        r.b = sy - fy0;
-        const float Xc = __builtin_amdgcn_fmed3f(fx0, -2.0f, colsf);
-        const float Yc = __builtin_amdgcn_fmed3f(fy0, -2.0f, rowsf);
-        const uint32_t off = __float_as_uint(__builtin_fmaf(Yc, pwf, Xc + magic_c));
-        r.w = *(gptr_u32x4)(magic_base + off);
+        r.a = q.a;
+        r.b = q.b;
+        r.w = q.w;
         r.taddr = __float_as_uint(__builtin_fmaf(rif, trow, __builtin_fmaf(cif, 32.0f, tbias)));
         return r;
     };
     auto reduce = [&](const LbReq &cur, float acc) -> float {
         const float4 t4 = *reinterpret_cast<const float4 *>(tile_magic + cur.taddr);
-        const float colorDis = __builtin_fabsf(t4.x - centre);
-        const float w = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
-        const Taps tp5 = taps_u8(cur.a, cur.b, cur.w.x, cur.w.y, cur.w.z, cur.w.w);
-        const float colDiff = t4.w - tp5.sc;
-        const float gradX = t4.y - tp5.gx2;
-        const float gradY = t4.z - tp5.gy2;
-        const float gradDis = min_nc(__builtin_fabsf(gradX) + __builtin_fabsf(gradY), taug16);
-        const float colDis = min_abs_nc(colDiff, tau_color);
-        const float dis = __builtin_fmaf(alpha16, gradDis, oma * colDis);
-        return __builtin_fmaf(w, dis, acc);
+        const float w = lut_weight(lut_magic, t4.x, centre);
+        WinReq q;
+        q.a = cur.a;
+        q.b = cur.b;
+        q.w = cur.w;
+        return accum(w, gray_dis(K, q, t4.w, t4.y, t4.z, pr), acc);
     };
 
     float lb = 0.0f, prev = 0.0f;
@@ -232,40 +217,23 @@ __device__ __forceinline__ float lb_item_c4(const Problem *__restrict__ P, const
     static_assert(BOX > 0, "compile-time window only");
     constexpr int R = (BOX - 1) / 2;
     const gptr_bytes packed = (gptr_bytes)vc.packed.raw;
-    const uint32_t pw = (uint32_t)P->pw;
-    const uint32_t xmax = (uint32_t)(P->cols + 2), ymax = (uint32_t)(P->rows + 2);
-    const float alpha16 = P->alpha * 0.0625f, oma = 1.f - P->alpha;  // (dis_fold, pm_cost.h)
-    const float tau_color = P->tau_color, taug16 = P->tau_gradient * 16.0f;
+    const IntAddr IA = int_addr(P);
+    const PlaneRef pr = plane_of(packed, P);
+    const DisConst K = dis_const(P);
     const float4 centre = *reinterpret_cast<const float4 *>(tp0);
+    const WarpRow wr = warp_row(H);
     typedef const __attribute__((address_space(1))) uint32_t *gptr_u32;
     const gptr_u32 op = (gptr_u32)ordp;
     struct Req3 {
-        float a, b;
-        u32x4_a4 q0, q1, q2;
+        WinReq3 q;
         const float *tp;
     };
     auto request = [&](uint32_t cw, int e) -> Req3 {
         const int ci = (int)((cw >> (16 * e)) & 255u), ri = (int)((cw >> (16 * e + 8)) & 255u);
         const int i = 2 * ci - R, j = 2 * ri - R;
         const float qx = (float)(px + i), qy = (float)(py + j);
-        const float X0 = __builtin_fmaf(H[0], qx, H[2]);
-        const float Y0 = __builtin_fmaf(H[3], qx, H[5]);
-        const float Z0 = __builtin_fmaf(H[6], qx, H[8]);
-        const float X = __builtin_fmaf(H[1], qy, X0);
-        const float Y = __builtin_fmaf(H[4], qy, Y0);
-        const float Z = __builtin_fmaf(H[7], qy, Z0);
-        const float rz = recip<FAST>(Z);
-        const float sx = X * rz, sy = Y * rz;
-        const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
         Req3 r;
-        r.a = sx - fx0;
-        r.b = sy - fy0;
-        const uint32_t Xw = min(cvt_u32_sat(fx0 + 2.0f), xmax);
-        const uint32_t Yw = min(cvt_u32_sat(fy0 + 2.0f), ymax);
-        const gptr_bytes base = packed + (Yw * pw + Xw) * 12u;
-        r.q0 = *(gptr_u32x4)(base);
-        r.q1 = *(gptr_u32x4)(base + 16);
-        r.q2 = *(gptr_u32x4)(base + 32);
+        r.q = c4_request<FAST>(IA, packed, warp_col(H, qx), wr, qy);
         r.tp = tp0 + 4 * (j * tw + i);
         return r;
     };
@@ -275,10 +243,8 @@ __device__ __forceinline__ float lb_item_c4(const Problem *__restrict__ P, const
         const float S = __builtin_fabsf(lv.x - centre.x) + __builtin_fabsf(lv.y - centre.y) +
                         __builtin_fabsf(lv.z - centre.z);  // exact integer 0..765
         const float w = lut[(int)S];
-        Taps t[3];  // word 3k+c = column k, channel c
-        t[0] = taps_u8(c.a, c.b, c.q0.x, c.q0.w, c.q1.z, c.q2.y);
-        t[1] = taps_u8(c.a, c.b, c.q0.y, c.q1.x, c.q1.w, c.q2.z);
-        t[2] = taps_u8(c.a, c.b, c.q0.z, c.q1.y, c.q2.x, c.q2.w);
+        Taps t[3];
+        c4_taps(c.q, pr, t);
         const float4 up = *reinterpret_cast<const float4 *>(tp - 4 * tw);
         const float4 down = *reinterpret_cast<const float4 *>(tp + 4 * tw);
         const float4 left = *reinterpret_cast<const float4 *>(tp - 4);
@@ -288,10 +254,7 @@ __device__ __forceinline__ float lb_item_c4(const Problem *__restrict__ P, const
                               (right.z - left.z) - t[2].gx2);
         const float gY = l1_3((down.x - up.x) - t[0].gy2, (down.y - up.y) - t[1].gy2,
                               (down.z - up.z) - t[2].gy2);
-        const float gradDis = min_nc(gX + gY, taug16);
-        const float colDis = min_nc(colDiff, tau_color);
-        const float dis = __builtin_fmaf(alpha16, gradDis, oma * colDis);
-        return __builtin_fmaf(w, dis, acc);
+        return accum(w, dis_folded<false>(gX + gY, colDiff, K.alpha16, K.oma, K.tau_color, K.taug16), acc);
     };
     float lb = 0.0f, prev = 0.0f;
     // (requesting sample s + 1 before sample s is reduced was measured level on the colour workload: 231.5 vs 230.9 ms)

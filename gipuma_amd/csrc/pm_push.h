@@ -127,20 +127,17 @@ template <int BOX>
 struct PushEval {
     using LY = PushLayout<BOX>;
     static constexpr int FWH = LY::FWH, twc = LY::twc, S = 2 * FWH, PD = kPushPD;
-    float colsf, rowsf, pwf, magic_c, alpha, oma, tau_color, tau_gradient;  // wave-uniform
+    MagicAddr MA;       // wave-uniform
+    DisConst K;         // (alpha / 16 and 16 tau_g: dis_fold, pm_sample.h)
+    const Problem *P;
     float qx_v, qx_h, nyf;  // (float)(n + d) == (float)n + (float)d exactly (small integers)
     int l, base_v, base_h;
 
-    __device__ __forceinline__ void init(const Problem *__restrict__ P, int lane_in_group)
+    __device__ __forceinline__ void init(const Problem *__restrict__ P_, int lane_in_group)
     {
-        colsf = (float)P->cols;
-        rowsf = (float)P->rows;
-        pwf = (float)P->pw;
-        magic_c = kMagicF + (float)(2 * P->pw + 2);
-        alpha = P->alpha * 0.0625f;  // (dis_fold, pm_cost.h: alpha / 16 and 16 tau_g)
-        oma = 1.f - P->alpha;
-        tau_color = P->tau_color;
-        tau_gradient = P->tau_gradient * 16.0f;
+        P = P_;
+        MA = magic_addr(P_);
+        K = dis_const(P_);
         l = lane_in_group;
     }
     __device__ __forceinline__ void producer(float nxf, float nyf_, int tnx, int tny)
@@ -155,24 +152,11 @@ struct PushEval {
     template <bool FAST>
     __device__ __forceinline__ WinReq request(const float *__restrict__ H, gptr_bytes magic_base, float qx, float qy) const
     {
-        // getCorrespondingPoint_cu, gipuma.cu:207-217, the fmaf nesting of view_cost_pipe
+        // getCorrespondingPoint_cu, gipuma.cu:207-217, the arithmetic of view_cost_pipe (pm_sample.h)
 #ifdef PM_PUSH_EXP_ONE_WINDOW_PER_GROUP  // (timing experiment, wrong results: the 8 lanes of a group fetch ONE window --
         qx = qx - (float)(2 * l);        //  the vector L1's cost if a group's window bytes were fetched once)
 #endif
-        const float X = __builtin_fmaf(H[1], qy, __builtin_fmaf(H[0], qx, H[2]));
-        const float Y = __builtin_fmaf(H[4], qy, __builtin_fmaf(H[3], qx, H[5]));
-        const float Z = __builtin_fmaf(H[7], qy, __builtin_fmaf(H[6], qx, H[8]));
-        const float rz = recip<FAST>(Z);
-        const float sx = X * rz, sy = Y * rz;
-        const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
-        WinReq r;
-        r.a = sx - fx0;
-        r.b = sy - fy0;
-        const float Xc = __builtin_amdgcn_fmed3f(fx0, -2.0f, colsf);
-        const float Yc = __builtin_amdgcn_fmed3f(fy0, -2.0f, rowsf);
-        const uint32_t off = __float_as_uint(__builtin_fmaf(Yc, pwf, Xc + magic_c));
-        r.w = *(gptr_u32x4)(magic_base + off);
-        return r;
+        return magic_request<FAST>(MA, magic_base, warp_col(H, qx), warp_row(H), qy);
     }
     template <bool FAST>
     __device__ __forceinline__ WinReq issue(const float *__restrict__ H, gptr_bytes magic_base, int s) const
@@ -220,14 +204,8 @@ struct PushEval {
             if (s + PD < S) req[s % PD] = issue<FAST>(H, magic_base, s + PD);
             // {I(q), gx1(q), gy1(q), I(q)} of the reference tile
             const float4 t4 = *reinterpret_cast<const float4 *>(tile4 + 4 * tile_index(s));
-            const Taps tp5 = taps_u8(cur.a, cur.b, cur.w.x, cur.w.y, cur.w.z, cur.w.w);
-            // pmCostComputation_shared, gipuma.cu:251-274
-            const float colDiff = t4.w - tp5.sc;
-            const float gradX = t4.y - tp5.gx2;
-            const float gradY = t4.z - tp5.gy2;
-            const float gradDis = min_nc(__builtin_fabsf(gradX) + __builtin_fabsf(gradY), tau_gradient);
-            const float colDis = min_abs_nc(colDiff, tau_color);
-            dgrp[slot(s)] = __builtin_fmaf(alpha, gradDis, oma * colDis);
+            // the taps and pmCostComputation_shared, gipuma.cu:251-274
+            dgrp[slot(s)] = gray_dis(K, cur, t4.w, t4.y, t4.z, plane_of_magic(magic_base, P));
 #ifndef PM_PUSH_NO_SCHED_BARRIER
             // keep the steps apart: left alone, the scheduler interleaves many of them and spills
             __builtin_amdgcn_sched_barrier(0);
@@ -299,14 +277,9 @@ struct PushEval {
                 advance(pi);
                 if (s < SF) {
                     const float4 t4 = *reinterpret_cast<const float4 *>(tile4 + 4 * tile_at(pr));
-                    const Taps tp5 = taps_u8(cur.a, cur.b, cur.w.x, cur.w.y, cur.w.z, cur.w.w);
-                    const float colDiff = t4.w - tp5.sc;
-                    const float gradX = t4.y - tp5.gx2;
-                    const float gradY = t4.z - tp5.gy2;
-                    const float gradDis = min_nc(__builtin_fabsf(gradX) + __builtin_fabsf(gradY), tau_gradient);
-                    const float colDis = min_abs_nc(colDiff, tau_color);
+                    const float dv = gray_dis(K, cur, t4.w, t4.y, t4.z, plane_of_magic(magic_base, P));
                     const int e = kPushLanes * s + l;
-                    if (e < NFp) dfam[e] = __builtin_fmaf(alpha, gradDis, oma * colDis);
+                    if (e < NFp) dfam[e] = dv;
                 }
                 advance(pr);
 #ifndef PM_PUSH_NO_SCHED_BARRIER
@@ -329,7 +302,7 @@ struct PushEval {
     }
 };
 
-// the reference's summation for one consumer: columns outer, rows inner, one fmaf per sample
+// the reference's summation for one consumer: columns outer, rows inner, one accumulation per sample
 // (gipuma.cu:633-676); `ipl` = the compressed I plane at the consumer's window corner, `dch` = the
 // group's sample buffer at the consumer's first sample, rows `jstride` apart
 template <int BOX>
@@ -347,9 +320,8 @@ __device__ __forceinline__ float push_chain(const float *__restrict__ ipl, float
 #pragma unroll
         for (int j = 0; j < LY::N; j++) {
             // weight_cu, gipuma.cu:186-193: 256 possible weights
-            const float colorDis = __builtin_fabsf(ipl[2 * j * LY::ips + i] - centre);
-            const float w = *(const float *)(lut_magic + __float_as_uint(colorDis + kMagicF));
-            cost = __builtin_fmaf(w, dch[j * jstride + i], cost);
+            const float w = lut_weight(lut_magic, ipl[2 * j * LY::ips + i], centre);
+            cost = accum(w, dch[j * jstride + i], cost);
         }
     return cost;
 }
@@ -576,50 +548,27 @@ struct PushLayoutC4 {
     static_assert(total * 4 <= 80 * 1024, "two workgroups per CU");
 };
 
-struct WinReqC4 {
-    float a, b;
-    u32x4_a4 q0, q1, q2;
-};
-
 template <int BOX>
 struct PushEvalC4 {
     using LY = PushLayoutC4<BOX>;
     static constexpr int FWH = LY::FWH, twc = LY::twc;
-    float alpha, oma, tau_color, tau_gradient;
-    uint32_t pw, xmax, ymax;
+    DisConst K;  // (alpha / 16 and 16 tau_g: dis_fold, pm_sample.h)
+    IntAddr IA;
+    const Problem *P;
     float nyf;
     int l;
 
-    __device__ __forceinline__ void init(const Problem *__restrict__ P, int lane_in_group)
+    __device__ __forceinline__ void init(const Problem *__restrict__ P_, int lane_in_group)
     {
-        alpha = P->alpha * 0.0625f;  // (dis_fold, pm_cost.h: alpha / 16 and 16 tau_g)
-        oma = 1.f - P->alpha;
-        tau_color = P->tau_color;
-        tau_gradient = P->tau_gradient * 16.0f;
-        pw = (uint32_t)P->pw;
-        xmax = (uint32_t)(P->cols + 2);
-        ymax = (uint32_t)(P->rows + 2);
+        P = P_;
+        K = dis_const(P_);
+        IA = int_addr(P_);
         l = lane_in_group;
     }
     template <bool FAST>
-    __device__ __forceinline__ WinReqC4 request(const float *__restrict__ H, gptr_bytes packed, float qx, float qy) const
+    __device__ __forceinline__ WinReq3 request(const float *__restrict__ H, gptr_bytes packed, float qx, float qy) const
     {
-        const float X = __builtin_fmaf(H[1], qy, __builtin_fmaf(H[0], qx, H[2]));
-        const float Y = __builtin_fmaf(H[4], qy, __builtin_fmaf(H[3], qx, H[5]));
-        const float Z = __builtin_fmaf(H[7], qy, __builtin_fmaf(H[6], qx, H[8]));
-        const float rz = recip<FAST>(Z);
-        const float sx = X * rz, sy = Y * rz;
-        const float fx0 = __builtin_floorf(sx), fy0 = __builtin_floorf(sy);
-        WinReqC4 r;
-        r.a = sx - fx0;
-        r.b = sy - fy0;
-        const uint32_t Xw = min(cvt_u32_sat(fx0 + 2.0f), xmax);
-        const uint32_t Yw = min(cvt_u32_sat(fy0 + 2.0f), ymax);
-        const gptr_bytes base = packed + (Yw * pw + Xw) * 12u;
-        r.q0 = *(gptr_u32x4)(base);
-        r.q1 = *(gptr_u32x4)(base + 16);
-        r.q2 = *(gptr_u32x4)(base + 32);
-        return r;
+        return c4_request<FAST>(IA, packed, warp_col(H, qx), warp_row(H), qy);
     }
     // one family of the stencil: the stream of PushEval::family with the colour request / reduction
     template <bool FAST, int W, int HH, int OX, int OY>
@@ -641,7 +590,7 @@ struct PushEvalC4 {
                 p.j0++;
             }
         };
-        auto issue_at = [&](const Pos &p) -> WinReqC4 {
+        auto issue_at = [&](const Pos &p) -> WinReq3 {
             const bool w1 = l >= W - p.r0;
             const float qx = qx0 + (float)(2 * p.r0) - (w1 ? (float)(2 * W) : 0.0f);
             const float qy = qy0 + (float)(2 * p.j0) + (w1 ? 2.0f : 0.0f);
@@ -653,7 +602,7 @@ struct PushEvalC4 {
         };
         constexpr int PD = kPushPDFamily;
         Pos pi{0, 0}, pr{0, 0};
-        WinReqC4 req[PD];
+        WinReq3 req[PD];
 #pragma unroll
         for (int p = 0; p < PD; p++) {
             req[p] = issue_at(pi);
@@ -664,7 +613,7 @@ struct PushEvalC4 {
 #pragma unroll
             for (int p = 0; p < PD; p++) {
                 const int s = sb + p;
-                const WinReqC4 cur = req[p];
+                const WinReq3 cur = req[p];
                 req[p] = issue_at(pi);  // (unconditional: clamped, valid addresses past the end, dropped)
                 advance(pi);
                 if (s < SF) {
@@ -674,17 +623,13 @@ struct PushEvalC4 {
                     const float tc = lds[LY::tile_c + k];                                           // gyR
                     // word 3k+c = column k, channel c (view_cost_c4_loop)
                     Taps t[3];
-                    t[0] = taps_u8(cur.a, cur.b, cur.q0.x, cur.q0.w, cur.q1.z, cur.q2.y);
-                    t[1] = taps_u8(cur.a, cur.b, cur.q0.y, cur.q1.x, cur.q1.w, cur.q2.z);
-                    t[2] = taps_u8(cur.a, cur.b, cur.q0.z, cur.q1.y, cur.q2.x, cur.q2.w);
+                    c4_taps(cur, plane_of(packed, P), t);
                     // pmCostComputation_shared for T = float4, gipuma.cu:251-274
                     const float colDiff = l1_3(ta.x - t[0].sc, ta.y - t[1].sc, ta.z - t[2].sc);
                     const float gX = l1_3(ta.w - t[0].gx2, tb.x - t[1].gx2, tb.y - t[2].gx2);
                     const float gY = l1_3(tb.z - t[0].gy2, tb.w - t[1].gy2, tc - t[2].gy2);
-                    const float gradDis = min_nc(gX + gY, tau_gradient);
-                    const float colDis = min_nc(colDiff, tau_color);
                     const int e = kPushLanes * s + l;
-                    if (e < NFp) dfam[e] = __builtin_fmaf(alpha, gradDis, oma * colDis);
+                    if (e < NFp) dfam[e] = dis_folded<false>(gX + gY, colDiff, K.alpha16, K.oma, K.tau_color, K.taug16);
                 }
                 advance(pr);
 #ifndef PM_PUSH_NO_SCHED_BARRIER
@@ -709,7 +654,7 @@ __device__ __forceinline__ float push_chain_c4(const float *__restrict__ ta, flo
             const float4 lv = *reinterpret_cast<const float4 *>(ta + 4 * (2 * j * LY::twc + i));
             const float S = __builtin_fabsf(lv.x - centre.x) + __builtin_fabsf(lv.y - centre.y) +
                             __builtin_fabsf(lv.z - centre.z);  // exact integer 0..765
-            cost = __builtin_fmaf(lut[(int)S], dch[j * jstride + i], cost);
+            cost = accum(lut[(int)S], dch[j * jstride + i], cost);
         }
     return cost;
 }

@@ -160,6 +160,13 @@ int gipuma_hip_cache_clear(void);
  * exhaustive comparison (2^32 inputs, ~1 s) on `device_id` and returns the number of mismatches in
  * that range through *mismatches (0 expected); the gpu tests call it. */
 int gipuma_hip_selftest_reciprocal(int device_id, unsigned long long *mismatches);
+/* The default and the reference-order flavour form x / z, y / z of the warped point (vecdiv4, /root/reference/config.h:44-47;
+ * getCorrespondingPoint_cu, gipuma.cu:207-217) as  r = RN(1/z), q = RN(x r), q' = RN(q + RN(x - q z) r)  where the window's
+ * operands are provably in range -- the correctly rounded IEEE quotient for every pair of fp32 significands.  This runs the
+ * proof by exhaustion for the denominators with significand bits z_first .. z_first + z_count - 1 (of 2^23) against all 2^23
+ * numerators and returns the number of pairs whose result differs from the IEEE division (0 expected; the whole range takes
+ * about a minute on an MI355X: profiles/r06_selftest_quotient.txt; the gpu tests run a slice). */
+int gipuma_hip_selftest_quotient(int device_id, unsigned z_first, unsigned z_count, unsigned long long *mismatches);
 
 /* ---- session: the pieces of gipuma<T>() (gipuma.cu:1825-1960), one call per launch ---- */
 /* validates the descriptor, uploads/binds images and cameras, allocates norm4/cost in HBM

@@ -20,10 +20,13 @@
  *       the reference's own code, which of these orders is used does not matter (flavours below).
  *   M2  expf / rsqrtf / division are approximate in the reference build (--use_fast_math,
  *       CMakeLists.txt:23).  Model: exp is go_exp() below (Cephes-style, ~1 ulp), rsqrtf(x) is
- *       1/sqrtf(x), x/z and y/z of the warped point are x*(1/z), y*(1/z) with an IEEE 1/z.
- *   M3  nvcc contracts a*b+c to FMA at will; the model fixes the contractions in the per-sample
- *       loop (homography application, lerps, dis, cost accumulation) as explicit fmaf() and
- *       leaves everything evaluated once per hypothesis unfused, in source order.
+ *       1/sqrtf(x).  x/z and y/z of the warped point: IEEE divisions since round 6 (the source's own
+ *       operation; flavour bit 2 clear: x*(1/z), y*(1/z) with an IEEE 1/z, the model of rounds 1-5).
+ *   M3  nvcc contracts a*b+c to FMA at will.  Since round 6 the default is NO contraction anywhere (the
+ *       source order as g++ compiles it; flavour bit 4 clear: the fmaf nesting rounds 1-5 fixed for the
+ *       per-sample loop -- homography application, dis, cost accumulation); the bilinear lerps are fmaf
+ *       in every flavour (they stand for the texture unit), everything evaluated once per hypothesis is
+ *       unfused, in source order.
  *   M4  random numbers: the reference's cuRAND state is never initialised; the
  *       model is a stateless counter hash keyed by (seed, phase, x, y, draw) -> (0,1].
  */
@@ -333,51 +336,128 @@ void gipuma_oracle_taps3(const float *img, int rows, int cols, int pitch, float 
 }
 
 /* ------------------------------------------------------------------------------------------
+ * FLAVOURS of the per-sample arithmetic.
+ * The reference's source leaves three things to nvcc and the texture unit; each has a "model" form (rounds 1-5: M1-M3 above)
+ * and the LITERAL form -- the operation order of the source as g++ compiles it in oracle/_ref (no contraction, IEEE division,
+ * one tex2D call per tap):
+ *   GO_LIT_TAPS (1)  every one of the five taps of gipuma.cu:251-253 is its own bilinear fetch at the coordinates the source
+ *                    writes, (pt.x +- 1 + 0.5f, pt.y + 0.5f), with xB = x - 0.5f, i = floor(xB), a = xB - i recomputed per tap:
+ *                    the +-1 taps' fractions differ from the centre's in the last bits (two roundings each)  [else M1];
+ *   GO_LIT_DIV  (2)  x / z and y / z as IEEE divisions (vecdiv4, config.h:44-47)  [else M2: x * (1/z)];
+ *   GO_LIT_FMA  (4)  H*(x,y,1) as m0*x + m1*y + m2 (matvecmul4noz, config.h:150-162), dis = (1-alpha)*colDis + alpha*gradDis
+ *                    (gipuma.cu:272), cost = cost + w*dis (:274, :672), all unfused  [else M3: the fmaf nesting].
+ * Flavour 7 is the reference's own source order: it reproduces oracle/_ref in every bit (tests/test_oracle_vs_ref.py).
+ * Flavour 6 -- division and multiply-adds literal, the model's taps -- is the DEFAULT since round 6: it is what the kernels'
+ * default mode computes (pm_sample.h, PM_MODEL 6); flavour 0 is the model of rounds 1-5, what GIPUMA_HIP_FLAG_FAST's kernels
+ * approximate.  gipuma_oracle_set_flavour(mask) selects; gray and colour alike.  The bilinear lerp itself
+ * (fmaf(a, t1 - t0, t0), exact fp32 weights) is the shim's stand-in for the texture unit in all of them.
+ * ---------------------------------------------------------------------------------------- */
+#define GO_LIT_TAPS 1
+#define GO_LIT_DIV 2
+#define GO_LIT_FMA 4
+#define GO_DEFAULT_FLAVOUR (GO_LIT_DIV | GO_LIT_FMA)
+static int go_flavour = GO_DEFAULT_FLAVOUR;
+void gipuma_oracle_set_flavour(int mask) { go_flavour = mask < 0 ? GO_DEFAULT_FLAVOUR : (mask & 7); }
+int gipuma_oracle_get_flavour(void) { return go_flavour; }
+int gipuma_oracle_default_flavour(void) { return GO_DEFAULT_FLAVOUR; }
+
+/* one bilinear fetch tex2D(r, x, y) of the shim's texture model (ref_harness.cpp: ref_tex_channel); `stride` floats per texel */
+static inline float go_tex2d_s(const float *img, int rows, int cols, int pitch, int stride, float x, float y)
+{
+    const float xb = x - 0.5f, yb = y - 0.5f;
+    const float fx = floorf(xb), fy = floorf(yb);
+    const float a = xb - fx, b = yb - fy;
+    const int ix = (int)fminf(fmaxf(fx, -2.0f), (float)cols);
+    const int iy = (int)fminf(fmaxf(fy, -2.0f), (float)rows);
+    const float t00 = go_texel_s(img, rows, cols, pitch, stride, ix, iy), t10 = go_texel_s(img, rows, cols, pitch, stride, ix + 1, iy);
+    const float t01 = go_texel_s(img, rows, cols, pitch, stride, ix, iy + 1), t11 = go_texel_s(img, rows, cols, pitch, stride, ix + 1, iy + 1);
+    const float r0 = fmaf(a, t10 - t00, t00), r1 = fmaf(a, t11 - t01, t01);
+    return fmaf(b, r1 - r0, r0);
+}
+
+/* getCorrespondingPoint_cu, gipuma.cu:207-217: the warp of q = (qx, qy) through H */
+static inline void go_warp(const float *H, float qx, float qy, int fl, float *sx, float *sy)
+{
+    float X, Y, Z;
+    if (fl & GO_LIT_FMA) { /* matvecmul4noz, config.h:150-162 */
+        X = H[0] * qx + H[1] * qy + H[2];
+        Y = H[3] * qx + H[4] * qy + H[5];
+        Z = H[6] * qx + H[7] * qy + H[8];
+    } else { /* M3 */
+        X = fmaf(H[1], qy, fmaf(H[0], qx, H[2]));
+        Y = fmaf(H[4], qy, fmaf(H[3], qx, H[5]));
+        Z = fmaf(H[7], qy, fmaf(H[6], qx, H[8]));
+    }
+    if (fl & GO_LIT_DIV) { /* vecdiv4, config.h:44-47 */
+        *sx = X / Z;
+        *sy = Y / Z;
+    } else { /* M2 */
+        const float rz = 1.0f / Z;
+        *sx = X * rz;
+        *sy = Y * rz;
+    }
+}
+
+/* the source-side terms of pmCostComputation_shared at (sx, sy): out = { I2(x, y), I2(x+1, y) - I2(x-1, y), I2(x, y+1) - I2(x, y-1) } */
+static inline void go_source_terms(const float *img, int rows, int cols, int pitch, int stride, float sx, float sy, int fl,
+                                   float out[3])
+{
+    if (fl & GO_LIT_TAPS) { /* gipuma.cu:251-253, argument expressions as written */
+        out[1] = go_tex2d_s(img, rows, cols, pitch, stride, sx + 1 + 0.5f, sy + 0.5f) -
+                 go_tex2d_s(img, rows, cols, pitch, stride, sx - 1 + 0.5f, sy + 0.5f);
+        out[2] = go_tex2d_s(img, rows, cols, pitch, stride, sx + 0.5f, sy + 1 + 0.5f) -
+                 go_tex2d_s(img, rows, cols, pitch, stride, sx + 0.5f, sy - 1 + 0.5f);
+        out[0] = go_tex2d_s(img, rows, cols, pitch, stride, sx + 0.5f, sy + 0.5f);
+    } else { /* M1 */
+        go_taps3_s(img, rows, cols, pitch, stride, sx, sy, out);
+    }
+}
+
+/* dis = (1 - alpha) colDis + alpha gradDis (gipuma.cu:272) and cost + w dis (:274, :672) */
+static inline float go_dis_mix(float alpha, float colDis, float gradDis, int fl)
+{
+    if (fl & GO_LIT_FMA) return (1.f - alpha) * colDis + alpha * gradDis;
+    return fmaf(alpha, gradDis, (1.f - alpha) * colDis);
+}
+static inline float go_accum(float w, float dis, float cost, int fl)
+{
+    if (fl & GO_LIT_FMA) return cost + w * dis;
+    return fmaf(w, dis, cost);
+}
+
+/* ------------------------------------------------------------------------------------------
  * patch cost of one view: pmCost_shared + pmCostComputation_shared, gipuma.cu:585-680, 223-277
  * (pmCost/pmCostComputation, :455-518/:278-320, used by the init kernel, are the same function
  * of the images -- SURVEY 3.4)
  * ---------------------------------------------------------------------------------------- */
-/* dis of one window sample: the warp of q = (ix, iy) through H (getCorrespondingPoint_cu, gipuma.cu:207-217),
- * the five bilinear taps and the truncated colour / gradient differences of pmCostComputation_shared
- * (gipuma.cu:251-274).  A function of (q, H, view) only -- not of the pixel whose window q belongs to
- * (what pm_push.h builds on, see gipuma_oracle_push_costs). */
+/* dis of one window sample with the reference-side terms handed in: the warp of q = (ix, iy) through H
+ * (getCorrespondingPoint_cu, gipuma.cu:207-217), the five bilinear taps and the truncated colour / gradient differences of
+ * pmCostComputation_shared (gipuma.cu:251-274).  A function of (q, H, view) only -- not of the pixel whose window q belongs
+ * to (what pm_push.h builds on, see gipuma_oracle_push_costs). */
+static inline float go_dis_cached(const gipuma_hip_desc *d, int view, const float *H, int ix, int iy, float leftValue,
+                                  float gx1, float gy1, int fl)
+{
+    const gipuma_hip_params *ap = &d->params;
+    float sx, sy, s[3];
+    go_warp(H, (float)ix, (float)iy, fl, &sx, &sy);
+    go_source_terms(d->images[view], d->rows, d->cols, d->pitch, 1, sx, sy, fl, s);
+    const float colDiff = fabsf(leftValue - s[0]);
+    const float gradX = gx1 - s[1];
+    const float gradY = gy1 - s[2];
+    const float gradDis = fminf((fabsf(gradX) + fabsf(gradY)) * 0.0625f, ap->tau_gradient);
+    const float colDis = fminf(colDiff, ap->tau_color);
+    return go_dis_mix(ap->alpha, colDis, gradDis, fl);
+}
 static inline float go_dis_at(const gipuma_hip_desc *d, int view, const float *H, int ix, int iy,
                               float leftValue)
 {
-    const gipuma_hip_params *ap = &d->params;
     const int rows = d->rows, cols = d->cols, pitch = d->pitch;
     const float *ref = d->images[0];
-    const float *src = d->images[view];
-    const float alpha = ap->alpha, tau_color = ap->tau_color, tau_gradient = ap->tau_gradient;
-    const float oma = 1.f - alpha;
-    const float qx = (float)ix, qy = (float)iy;
-    /* M3: H*(qx,qy,1) as fmaf(h1, qy, fmaf(h0, qx, h2)) (matvecmul4noz, config.h:150-162) */
-    const float X0 = fmaf(H[0], qx, H[2]);
-    const float Y0 = fmaf(H[3], qx, H[5]);
-    const float Z0 = fmaf(H[6], qx, H[8]);
-    /* getCorrespondingPoint_cu, gipuma.cu:207-217 (M2: multiply by 1/z) */
-    const float X = fmaf(H[1], qy, X0);
-    const float Y = fmaf(H[4], qy, Y0);
-    const float Z = fmaf(H[7], qy, Z0);
-    const float rz = 1.0f / Z;
-    const float sx = X * rz, sy = Y * rz;
-    /* pmCostComputation_shared, gipuma.cu:251-274 */
-    float s[3];
-    go_taps3_s(src, rows, cols, pitch, 1, sx, sy, s);
-    const float gx2 = s[1];
-    const float gy2 = s[2];
-    const float colDiff = fabsf(leftValue - s[0]);
     const float up = go_texel(ref, rows, cols, pitch, ix, iy - 1);
     const float down = go_texel(ref, rows, cols, pitch, ix, iy + 1);
     const float left = go_texel(ref, rows, cols, pitch, ix - 1, iy);
     const float right = go_texel(ref, rows, cols, pitch, ix + 1, iy);
-    const float gx1 = right - left;
-    const float gy1 = down - up;
-    const float gradX = gx1 - gx2;
-    const float gradY = gy1 - gy2;
-    const float gradDis = fminf((fabsf(gradX) + fabsf(gradY)) * 0.0625f, tau_gradient);
-    const float colDis = fminf(colDiff, tau_color);
-    return fmaf(alpha, gradDis, oma * colDis);
+    return go_dis_cached(d, view, H, ix, iy, leftValue, right - left, down - up, go_flavour);
 }
 
 /* What a pixel's window contributes to EVERY hypothesis and view evaluated at that pixel -- the support weights
@@ -427,37 +507,12 @@ static const go_pixel_cache *go_cache_for(const gipuma_hip_desc *d, int px, int 
     return pc;
 }
 
-/* go_dis_at with the reference-side terms handed in (from the pixel cache): the same expressions */
-static inline float go_dis_cached(const gipuma_hip_desc *d, int view, const float *H, int ix, int iy, float leftValue,
-                                  float gx1, float gy1)
-{
-    const gipuma_hip_params *ap = &d->params;
-    const float alpha = ap->alpha, tau_color = ap->tau_color, tau_gradient = ap->tau_gradient;
-    const float oma = 1.f - alpha;
-    const float qx = (float)ix, qy = (float)iy;
-    const float X0 = fmaf(H[0], qx, H[2]);
-    const float Y0 = fmaf(H[3], qx, H[5]);
-    const float Z0 = fmaf(H[6], qx, H[8]);
-    const float X = fmaf(H[1], qy, X0);
-    const float Y = fmaf(H[4], qy, Y0);
-    const float Z = fmaf(H[7], qy, Z0);
-    const float rz = 1.0f / Z;
-    const float sx = X * rz, sy = Y * rz;
-    float s[3];
-    go_taps3_s(d->images[view], d->rows, d->cols, d->pitch, 1, sx, sy, s);
-    const float colDiff = fabsf(leftValue - s[0]);
-    const float gradX = gx1 - s[1];
-    const float gradY = gy1 - s[2];
-    const float gradDis = fminf((fabsf(gradX) + fabsf(gradY)) * 0.0625f, tau_gradient);
-    const float colDis = fminf(colDiff, tau_color);
-    return fmaf(alpha, gradDis, oma * colDis);
-}
-
 static float go_view_cost(const gipuma_hip_desc *d, int view, int px, int py, const float pl[4])
 {
     const gipuma_hip_params *ap = &d->params;
     const int hRad = (ap->box_hsize - 1) / 2; /* gipuma.cu:1474 (init uses box/2, same for odd) */
     const int vRad = (ap->box_vsize - 1) / 2;
+    const int fl = go_flavour;
     if ((hRad + 1) * (vRad + 1) > GO_MAXWIN) return GO_MAXCOST; /* (box <= 49, like the library: go_check) */
 
     float H[9];
@@ -469,123 +524,8 @@ static float go_view_cost(const gipuma_hip_desc *d, int view, int px, int py, co
     for (int i = -hRad; i < hRad + 1; i += GO_WIN_INCREMENT) {
         for (int j = -vRad; j < vRad + 1; j += GO_WIN_INCREMENT, k++) {
             /* weight_cu, gipuma.cu:186-193: pc->w[k]; pmCostComputation_shared, :251-274 */
-            const float dis = go_dis_cached(d, view, H, px + i, py + j, pc->I[k], pc->gx1[k], pc->gy1[k]);
-            cost = fmaf(pc->w[k], dis, cost);
-        }
-    }
-    return cost;
-}
-
-/* ------------------------------------------------------------------------------------------
- * LITERAL flavours of the gray patch cost.
- * The numerical model M1-M3 above is ONE choice among the orderings the reference's source leaves to
- * nvcc and the texture unit.  These switches replace one model choice at a time by the literal
- * operation order of the reference's source as g++ compiles it in oracle/_ref (no contraction,
- * IEEE division, one tex2D call per tap), so that the cause of every oracle <-> _ref difference can
- * be named (scripts/ref_vs_oracle_fraction.py --flavour, tests/test_oracle_vs_ref.py):
- *   GO_LIT_TAPS (1)  M1 -> every one of the five taps of gipuma.cu:251-253 is its own bilinear
- *                    fetch at the coordinates the source writes, (pt.x +- 1 + 0.5f, pt.y + 0.5f),
- *                    with xB = x - 0.5f, i = floor(xB), a = xB - i recomputed per tap: the +-1 taps'
- *                    fractions differ from the centre's in the last bits (two roundings each);
- *   GO_LIT_DIV  (2)  M2 -> x / z and y / z as IEEE divisions (vecdiv4, config.h:44-47);
- *   GO_LIT_FMA  (4)  M3 -> H*(x,y,1) as m0*x + m1*y + m2 (matvecmul4noz, config.h:150-162),
- *                    dis = (1-alpha)*colDis + alpha*gradDis (gipuma.cu:272), cost = cost + w*dis
- *                    (:274, :672), all unfused.
- * Flavour 7 is the reference's own source order; 0 is the model the kernels implement.  The
- * bilinear lerp itself (fmaf(a, t1 - t0, t0), exact fp32 weights) is the shim's stand-in for the
- * texture unit in both and is not part of the switch.  Gray only.
- * ---------------------------------------------------------------------------------------- */
-#define GO_LIT_TAPS 1
-#define GO_LIT_DIV 2
-#define GO_LIT_FMA 4
-static int go_flavour = 0;
-void gipuma_oracle_set_flavour(int mask) { go_flavour = mask & 7; }
-int gipuma_oracle_get_flavour(void) { return go_flavour; }
-
-/* one bilinear fetch tex2D(r, x, y) of the shim's texture model (ref_harness.cpp: ref_tex_channel) */
-static inline float go_tex2d(const float *img, int rows, int cols, int pitch, float x, float y)
-{
-    const float xb = x - 0.5f, yb = y - 0.5f;
-    const float fx = floorf(xb), fy = floorf(yb);
-    const float a = xb - fx, b = yb - fy;
-    const int ix = (int)fminf(fmaxf(fx, -2.0f), (float)cols);
-    const int iy = (int)fminf(fmaxf(fy, -2.0f), (float)rows);
-    const float t00 = go_texel(img, rows, cols, pitch, ix, iy), t10 = go_texel(img, rows, cols, pitch, ix + 1, iy);
-    const float t01 = go_texel(img, rows, cols, pitch, ix, iy + 1), t11 = go_texel(img, rows, cols, pitch, ix + 1, iy + 1);
-    const float r0 = fmaf(a, t10 - t00, t00), r1 = fmaf(a, t11 - t01, t01);
-    return fmaf(b, r1 - r0, r0);
-}
-
-static float go_view_cost_flavoured(const gipuma_hip_desc *d, int view, int px, int py, const float pl[4], int fl)
-{
-    const gipuma_hip_params *ap = &d->params;
-    const int rows = d->rows, cols = d->cols, pitch = d->pitch;
-    const float *ref = d->images[0];
-    const float *src = d->images[view];
-    const int hRad = (ap->box_hsize - 1) / 2;
-    const int vRad = (ap->box_vsize - 1) / 2;
-    const float alpha = ap->alpha, tau_color = ap->tau_color, tau_gradient = ap->tau_gradient;
-    const float gamma = ap->gamma;
-    float H[9];
-    go_homography(&d->cameras[0], &d->cameras[view], pl, pl[3], H);
-    const float centre = go_texel(ref, rows, cols, pitch, px, py);
-    float cost = 0.0f;
-    for (int i = -hRad; i < hRad + 1; i += GO_WIN_INCREMENT) {
-        for (int j = -vRad; j < vRad + 1; j += GO_WIN_INCREMENT) {
-            const int ix = px + i, iy = py + j;
-            const float leftValue = go_texel(ref, rows, cols, pitch, ix, iy);
-            const float colorDis = fabsf(leftValue - centre);
-            const float w = go_exp(-colorDis / gamma);
-            const float qx = (float)ix, qy = (float)iy;
-            float X, Y, Z;
-            if (fl & GO_LIT_FMA) { /* matvecmul4noz, config.h:150-162 */
-                X = H[0] * qx + H[1] * qy + H[2];
-                Y = H[3] * qx + H[4] * qy + H[5];
-                Z = H[6] * qx + H[7] * qy + H[8];
-            } else {
-                X = fmaf(H[1], qy, fmaf(H[0], qx, H[2]));
-                Y = fmaf(H[4], qy, fmaf(H[3], qx, H[5]));
-                Z = fmaf(H[7], qy, fmaf(H[6], qx, H[8]));
-            }
-            float sx, sy;
-            if (fl & GO_LIT_DIV) { /* vecdiv4, config.h:44-47 */
-                sx = X / Z;
-                sy = Y / Z;
-            } else {
-                const float rz = 1.0f / Z;
-                sx = X * rz;
-                sy = Y * rz;
-            }
-            float sc, gx2, gy2;
-            if (fl & GO_LIT_TAPS) { /* gipuma.cu:251-253, argument expressions as written */
-                gx2 = go_tex2d(src, rows, cols, pitch, sx + 1 + 0.5f, sy + 0.5f) -
-                      go_tex2d(src, rows, cols, pitch, sx - 1 + 0.5f, sy + 0.5f);
-                gy2 = go_tex2d(src, rows, cols, pitch, sx + 0.5f, sy + 1 + 0.5f) -
-                      go_tex2d(src, rows, cols, pitch, sx + 0.5f, sy - 1 + 0.5f);
-                sc = go_tex2d(src, rows, cols, pitch, sx + 0.5f, sy + 0.5f);
-            } else { /* the model's taps */
-                float m[3];
-                go_taps3_s(src, rows, cols, pitch, 1, sx, sy, m);
-                sc = m[0];
-                gx2 = m[1];
-                gy2 = m[2];
-            }
-            const float colDiff = fabsf(leftValue - sc);
-            const float up = go_texel(ref, rows, cols, pitch, ix, iy - 1);
-            const float down = go_texel(ref, rows, cols, pitch, ix, iy + 1);
-            const float left = go_texel(ref, rows, cols, pitch, ix - 1, iy);
-            const float right = go_texel(ref, rows, cols, pitch, ix + 1, iy);
-            const float gradX = (right - left) - gx2;
-            const float gradY = (down - up) - gy2;
-            const float gradDis = fminf((fabsf(gradX) + fabsf(gradY)) * 0.0625f, tau_gradient);
-            const float colDis = fminf(colDiff, tau_color);
-            if (fl & GO_LIT_FMA) {
-                const float dis = (1.f - alpha) * colDis + alpha * gradDis; /* gipuma.cu:272 */
-                cost = cost + w * dis;                                      /* :274, :672 */
-            } else {
-                const float dis = fmaf(alpha, gradDis, (1.f - alpha) * colDis);
-                cost = fmaf(w, dis, cost);
-            }
+            const float dis = go_dis_cached(d, view, H, px + i, py + j, pc->I[k], pc->gx1[k], pc->gy1[k], fl);
+            cost = go_accum(pc->w[k], dis, cost, fl);
         }
     }
     return cost;
@@ -651,31 +591,23 @@ static float go_view_cost_c4(const gipuma_hip_desc *d, int view, int px, int py,
     const int hRad = (ap->box_hsize - 1) / 2;
     const int vRad = (ap->box_vsize - 1) / 2;
     const float alpha = ap->alpha, tau_color = ap->tau_color, tau_gradient = ap->tau_gradient;
-    const float oma = 1.f - alpha;
     if ((hRad + 1) * (vRad + 1) > GO_MAXWIN) return GO_MAXCOST;
 
     float H[9];
     go_homography(&d->cameras[0], &d->cameras[view], pl, pl[3], H);
 
     const go_pixel_cache_c4 *pc = go_cache_c4_for(d, px, py);
+    const int fl = go_flavour;
     float cost = 0.0f;
     int k = 0;
     for (int i = -hRad; i < hRad + 1; i += GO_WIN_INCREMENT) {
-        const float qx = (float)(px + i);
-        const float X0 = fmaf(H[0], qx, H[2]);
-        const float Y0 = fmaf(H[3], qx, H[5]);
-        const float Z0 = fmaf(H[6], qx, H[8]);
         for (int j = -vRad; j < vRad + 1; j += GO_WIN_INCREMENT, k++) {
-            const float qy = (float)(py + j);
-            const float X = fmaf(H[1], qy, X0);
-            const float Y = fmaf(H[4], qy, Y0);
-            const float Z = fmaf(H[7], qy, Z0);
-            const float rz = 1.0f / Z;
-            const float sx = X * rz, sy = Y * rz;
+            float sx, sy;
+            go_warp(H, (float)(px + i), (float)(py + j), fl, &sx, &sy);
             float cd[3], gradX[3], gradY[3];
             for (int c = 0; c < 3; c++) {
                 float s[3];
-                go_taps3_s(src + c, rows, cols, pitch, 4, sx, sy, s);
+                go_source_terms(src + c, rows, cols, pitch, 4, sx, sy, fl, s);
                 cd[c] = pc->lv[k][c] - s[0];
                 gradX[c] = pc->gx1[k][c] - s[1];
                 gradY[c] = pc->gy1[k][c] - s[2];
@@ -683,8 +615,7 @@ static float go_view_cost_c4(const gipuma_hip_desc *d, int view, int px, int py,
             const float colDiff = go_l1_3(cd);
             const float gradDis = fminf((go_l1_3(gradX) + go_l1_3(gradY)) * 0.0625f, tau_gradient);
             const float colDis = fminf(colDiff, tau_color);
-            const float dis = fmaf(alpha, gradDis, oma * colDis);
-            cost = fmaf(pc->w[k], dis, cost);
+            cost = go_accum(pc->w[k], go_dis_mix(alpha, colDis, gradDis, fl), cost, fl);
         }
     }
     return cost;
@@ -693,7 +624,6 @@ static float go_view_cost_c4(const gipuma_hip_desc *d, int view, int px, int py,
 static float go_view_cost_any(const gipuma_hip_desc *d, int view, int px, int py, const float pl[4])
 {
     if (d->channels == 4) return go_view_cost_c4(d, view, px, py, pl);
-    if (go_flavour) return go_view_cost_flavoured(d, view, px, py, pl, go_flavour);
     return go_view_cost(d, view, px, py, pl);
 }
 
@@ -823,7 +753,7 @@ int gipuma_oracle_push_costs(const gipuma_hip_desc *d, int nx, int ny, const flo
                     const float w = go_exp(-fabsf(leftValue - centre) / ap->gamma);
                     const float dis = cdx[c] == 0 ? disV[((cdy[c] + 5) / 2 + j) * N + i]
                                                   : disH[j * FW + (cdx[c] + 5) / 2 + i];
-                    cost = fmaf(w, dis, cost);
+                    cost = go_accum(w, dis, cost, go_flavour);
                 }
             cv[c][v] = cost;
         }

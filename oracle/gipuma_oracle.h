@@ -44,11 +44,14 @@ int gipuma_oracle_time(const gipuma_hip_desc *d, int n_iter_timed, double *sec_i
 int gipuma_oracle_time_band(const gipuma_hip_desc *d, int y0, int y1, double *sec_init_band,
                             double *sec_iter_band);
 int gipuma_oracle_num_threads(void);
-/* Literal flavours of the gray patch cost (see gipuma_oracle.c): bit 0 = one bilinear fetch per tap at the coordinates
- * the source writes (M1), bit 1 = IEEE x/z, y/z (M2), bit 2 = unfused multiply-adds (M3).  0 (default) = the model the
- * kernels implement; 7 = the operation order of the reference's source.  Process-wide; tests restore 0. */
+/* Flavours of the per-sample arithmetic (see gipuma_oracle.c), gray and colour: bit 0 = one bilinear fetch per tap at the
+ * coordinates the source writes (else M1), bit 1 = IEEE x/z, y/z (else M2), bit 2 = unfused multiply-adds (else M3).
+ * 6 (DEFAULT since round 6) = what the kernels' default mode computes (pm_sample.h, PM_MODEL 6); 7 = the operation order of
+ * the reference's source (GIPUMA_HIP_FLAG_LITERAL); 0 = the model of rounds 1-5 (what GIPUMA_HIP_FLAG_FAST approximates).
+ * Process-wide; tests restore the default with set_flavour(-1). */
 void gipuma_oracle_set_flavour(int mask);
 int gipuma_oracle_get_flavour(void);
+int gipuma_oracle_default_flavour(void); /* 6: what the kernels' default mode computes; set_flavour(-1) returns to it */
 void gipuma_oracle_set_threads(int n);
 
 /* ---- unit pieces, exported for the known-answer tests ---- */

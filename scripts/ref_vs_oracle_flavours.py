@@ -57,7 +57,7 @@ def main():
             print("%d %-50s %11.4f%% %13.4f%% %13.4f%% %8.0f" % (f, NAMES[f], 100 * ok, 100 * same, 100 * csame,
                                                               time.time() - t2), flush=True)
     finally:
-        L.gipuma_oracle_set_flavour(0)
+        L.gipuma_oracle_set_flavour(-1)
 
 
 if __name__ == "__main__":

@@ -220,11 +220,11 @@ def test_cli_end_to_end_dmb_matches_oracle(hip, tmp_path, colour, png, mode):
     gs2.desc.params.min_disparity = f32(cs.f) * f32(0.54) / f32(800.0)
     gs2.desc.params.max_disparity = f32(cs.f) * f32(0.54) / f32(300.0)
     from tests import oracle_lib
-    oracle_lib.lib().gipuma_oracle_set_flavour(7 if mode == "literal" else 0)
+    oracle_lib.lib().gipuma_oracle_set_flavour({"literal": 7, "fast": 0}.get(mode, -1))
     try:
         n4, c = OracleState(gs2).run()
     finally:
-        oracle_lib.lib().gipuma_oracle_set_flavour(0)
+        oracle_lib.lib().gipuma_oracle_set_flavour(-1)
     assert np.array_equal(disp.view(np.uint32), n4[..., 3].view(np.uint32))
     assert np.array_equal(normals.view(np.uint32), np.ascontiguousarray(n4[..., :3]).view(np.uint32))
     assert np.array_equal(cost.view(np.uint32), c.view(np.uint32))

@@ -75,7 +75,7 @@ def test_literal_mode_equals_the_oracle_s_literal_flavour(hip):
             n4, c = s.get_state()
             assert np.array_equal(bits(n4), bits(o.norm4))
     finally:
-        L.gipuma_oracle_set_flavour(0)
+        L.gipuma_oracle_set_flavour(-1)
 
 
 @pytest.mark.parametrize("cfg", [dict(cols=96, rows=64, n_src=3, blocksize=9, iterations=2, n_best=2),

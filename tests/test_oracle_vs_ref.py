@@ -267,7 +267,7 @@ def _tolerance_fraction(rn, on):
 def flavour():
     L = olib()
     yield L.gipuma_oracle_set_flavour
-    L.gipuma_oracle_set_flavour(0)
+    L.gipuma_oracle_set_flavour(-1)
 
 
 @needs_ref
