@@ -316,7 +316,7 @@ def main():
         barrier()
         if rank == 0:
             print(json.dumps({"metric": "dry run", "value": 0.0, "unit": "Mpix/s", "n_gpus": world, "steps": 0,
-                              "warmup": 0, "dry_run": True, "ranks": ident,
+                              "warmup": 0, "dry_run": True, "scaling": "weak", "ranks": ident,
                               "config": {"workload": "none (plumbing test)"}}))
         if world > 1:
             dist.destroy_process_group()
@@ -643,9 +643,11 @@ def main():
                     "frac_bit_identical_planes": float((n4f.view(np.uint32) == n4e.view(np.uint32)).all(-1).mean()),
                     "tolerance": "depth 1e-4 relative, unit normal 1e-3 (BASELINE.json north_star)"},
                 "quality": qf,
-                "what": "same frames and schedule, session created with GIPUMA_HIP_FLAG_FAST: v_rcp_f32 without the Newton "
-                        "step, homography from host-folded per-view products, reassociated bilinear taps, tree sums "
-                        "(pm_core.h PM_APPROX); judged by tolerance, not bit-exact"}
+                "what": "same frames and schedule, session created with GIPUMA_HIP_FLAG_FAST: the numerical model of rounds 1-5 "
+                        "(x * (1/z) for x / z, fused multiply-adds in the sample loop: pm_sample.h PM_MODEL 0) with v_rcp_f32 "
+                        "without the Newton step, no proof of the reciprocal's range, and the nine divisions of the homography "
+                        "by the plane offset as one reciprocal + a Markstein step each (pm_core.h PM_APPROX); judged by "
+                        "tolerance, not bit-exact"}
             print("bench.py: extra leg -- reference-order mode", file=sys.stderr, flush=True)
             # (a'') GIPUMA_HIP_FLAG_LITERAL: the reference-order flavour -- bit-identical to the reference's own code
             #       (tests/test_literal_mode.py), a validation mode -- and how far the exact mode's maps are from it
@@ -662,9 +664,11 @@ def main():
                     "exact_mode_vs_this": {"frac_within_tolerance": float(((d_rel < 1e-4) & (n_err < 1e-3)).mean()),
                                            "frac_bit_identical_planes": float((n4e.view(np.uint32) == n4l.view(np.uint32)).all(-1).mean())},
                     "what": "session created with GIPUMA_HIP_FLAG_LITERAL: the per-sample arithmetic in the reference's own operation "
-                            "order (one bilinear fetch per tap, IEEE divisions, unfused multiply-adds) on float planes through the "
-                            "generic kernels; equals the reference's own code bit for bit; `exact_mode_vs_this` is therefore the "
-                            "exact mode's distance from the reference on this frame"}
+                            "order (every tap its own bilinear fetch with its own fraction, correctly rounded x / z, unfused "
+                            "multiply-adds: pm_sample.h PM_MODEL 7) through the same push / column-per-lane / plane-keyed / bounded "
+                            "kernels and schedule as the default mode; equals the reference's own code bit for bit "
+                            "(tests/test_headline_parity.py, tests/test_literal_mode.py); `exact_mode_vs_this` is therefore the "
+                            "default mode's distance from the reference on this frame"}
             del n4f, cf, n4e, ce, d_rel, n_err, n4l
             print("bench.py: extra leg -- scene with depth steps", file=sys.stderr, flush=True)
             # (b) a scene with depth discontinuities, an occluder and sensor noise

@@ -70,7 +70,9 @@ def read_image(path):
     single-channel files as they are (16-bit: the high byte); colour PNG / PPM by the rule of the C++ front-end
     (gipuma_host.cpp read_image_gray: libpng's 15-bit 9797 / 19234 / 3737 for PNG, OpenCV's 14-bit BGR2GRAY for PPM);
     JPEG decoded to luma by libjpeg itself (PIL draft mode 'L'), which is what OpenCV's JPEG reader does for
-    IMREAD_GRAYSCALE."""
+    IMREAD_GRAYSCALE.  One known deviation: a 16-bit RGB / RGBA PNG reaches this function as PIL's 8-bit RGB, so its gray
+    is formed on the high bytes; libpng (and the C++ front-end, read_png_rgb8) forms it on the 16-bit samples and then
+    takes the high byte -- the last bit may differ for such files."""
     with open(path, "rb") as f:
         head = f.read(4)
     if head[:2] == b"P5":

@@ -510,8 +510,12 @@ bool read_pnm_colour(const std::string &path, std::vector<float> &img, int &rows
 // signature, IHDR / PLTE / IDAT / IEND chunks, one zlib stream, five scanline filters (PNG specification 1.2, section 6 and
 // 9).  Bit depths 1-16, colour types gray / RGB / palette / gray+alpha / RGBA, non-interlaced.  16-bit samples keep their
 // high byte and alpha is dropped, as imread without IMREAD_ANYDEPTH / IMREAD_UNCHANGED does.  out: rows*cols*3 bytes
-// R, G, B (gray images replicated), `was_gray` = the file had no colour channels.
-static bool read_png_rgb8(const std::string &path, std::vector<unsigned char> &rgb, int &rows, int &cols, bool &was_gray)
+// R, G, B (gray images replicated), `was_gray` = the file had no colour channels.  `gray16` (optional): for 16-bit
+// colour files the gray value libpng forms BEFORE it chops to 8 bits -- its transform order for IMREAD_GRAYSCALE:
+// rgb_to_gray on the 16-bit samples, (9797 r + 19234 g + 3737 b + 16384) >> 15, then the high byte -- one byte per pixel;
+// left empty for every other file.
+static bool read_png_rgb8(const std::string &path, std::vector<unsigned char> &rgb, int &rows, int &cols, bool &was_gray,
+                          std::vector<unsigned char> *gray16 = nullptr)
 {
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return false;
@@ -587,9 +591,19 @@ static bool read_png_rgb8(const std::string &path, std::vector<unsigned char> &r
     was_gray = ctype == 0 || ctype == 4;
     rgb.resize((size_t)h * w * 3);
     const int maxv = (1 << (depth < 8 ? depth : 8)) - 1;
+    const bool want16 = gray16 && depth == 16 && (ctype == 2 || ctype == 6);
+    if (gray16) gray16->clear();
+    if (want16) gray16->resize((size_t)h * w);
     for (size_t y = 0; y < h; y++) {
         const unsigned char *row = &raw[y * (stride + 1) + 1];
         for (size_t x = 0; x < w; x++) {
+            if (want16) {
+                auto s16 = [&](int k) -> uint32_t { return ((uint32_t)row[(x * ch + k) * 2] << 8) | row[(x * ch + k) * 2 + 1]; };
+                const uint32_t r = s16(0), g = s16(1), b = s16(2);
+                // (libpng leaves a pixel with r == g == b as it is)
+                const uint32_t g16 = (r == g && g == b) ? r : (9797u * r + 19234u * g + 3737u * b + 16384u) >> 15;
+                (*gray16)[y * w + x] = (unsigned char)(g16 >> 8);
+            }
             auto sample = [&](int k) -> int {  // k-th sample of pixel x, reduced to 8 bits
                 if (depth == 8) return row[x * ch + k];
                 if (depth == 16) return row[(x * ch + k) * 2];  // high byte
@@ -631,13 +645,16 @@ static bool is_png(const std::string &path)
 bool read_image_gray(const std::string &path, std::vector<float> &img, int &rows, int &cols)
 {
     if (!is_png(path)) return read_pnm_gray(path, img, rows, cols);
-    std::vector<unsigned char> rgb;
+    std::vector<unsigned char> rgb, gray16;
     bool was_gray = false;
-    if (!read_png_rgb8(path, rgb, rows, cols, was_gray)) return false;
+    if (!read_png_rgb8(path, rgb, rows, cols, was_gray, &gray16)) return false;
     img.resize((size_t)rows * cols);
     for (size_t k = 0; k < img.size(); k++) {
         const int r = rgb[3 * k], g = rgb[3 * k + 1], b = rgb[3 * k + 2];
-        img[k] = was_gray ? (float)r : (float)((9797 * r + 19234 * g + 3737 * b) >> 15);
+        if (!gray16.empty())  // 16-bit colour: gray formed on the 16-bit samples, then the high byte (libpng's order)
+            img[k] = (float)gray16[k];
+        else
+            img[k] = was_gray ? (float)r : (float)((9797 * r + 19234 * g + 3737 * b) >> 15);
     }
     return true;
 }

@@ -6,32 +6,29 @@
 #include <stdint.h>
 
 // PM_APPROX = 1 builds the TOLERANCE-JUDGED flavour of every kernel (GIPUMA_HIP_FLAG_FAST, gipuma_hip_fast.hip): the
-// same algorithm, schedule, memory layout and random numbers, with arithmetic shortcuts of the kind the reference takes by
-// being built with --use_fast_math (CMakeLists.txt:23).  What it may contain is bounded by its parity floor -- at least
-// the agreement the reference's own code has with the exact flavour (measured per ingredient on an MI355X:
-// profiles/r05_fast_mode_ingredients.txt):
+// same algorithm, schedule, memory layout and random numbers, with the numerical model of rounds 1-5 (pm_sample.h,
+// PM_MODEL 0: x * (1/z) for x / z, fused multiply-adds in the sample loop) and arithmetic shortcuts of the kind the
+// reference takes by being built with --use_fast_math (CMakeLists.txt:23), measured per ingredient on an MI355X
+// (profiles/r05_fast_mode_ingredients.txt):
 //   * v_rcp_f32 without the correcting Newton step for 1/z of the warped point (1 ulp instead of correctly rounded);
 //   * no proof that the window's denominators are in the range where that reciprocal is exact -- one instantiation of
 //     every sample loop instead of two;
-//   * the nine divisions by the plane offset in getHomography_cu as one reciprocal + a Markstein correction each (the
-//     bits of the IEEE quotient on every operand pair tried; unproven, hence not in the exact flavour).
+//   * the nine divisions by the plane offset in getHomography_cu as one reciprocal + a Markstein correction each.
 // Measured and rejected (compile options for A/B builds only): -DPM_APPROX_HFOLD, the homography from host-folded per-view
 // products (22 instead of ~200 instructions, but its rounding moves a whole window coherently by ~1e-4 px: 0.5 % of
 // config C's and 7.6 % of config B's pixels leave the tolerance); -DPM_APPROX_TREE_SUM, butterfly sums instead of the
 // column-per-lane kernels' relay (no time gained, 4 % of a 320x256 frame lost: the early half-sweeps decide trajectories).
-// Its results are NOT bit-identical to the exact flavour's; they are judged like the reference's own code is (fraction of
-// pixels inside 1e-4 / 1e-3, tests/test_fast_mode.py).  PM_APPROX = 0 (default) is the exact flavour.
+// Its results are NOT bit-identical to the default flavour's; they are judged by the fraction of pixels inside 1e-4 / 1e-3
+// (tests/test_fast_mode.py, tests/test_headline_parity.py).  PM_APPROX = 0 (default) is the exact flavour.
 #ifndef PM_APPROX
 #define PM_APPROX 0
 #endif
-// PM_LITERAL = 1 builds the REFERENCE-ORDER flavour (GIPUMA_HIP_FLAG_LITERAL, gipuma_hip_literal.hip): the per-sample
-// arithmetic of the patch cost in the literal operation order of the reference's source -- one bilinear fetch per tap at the
-// coordinates gipuma.cu:251-253 writes, x / z and y / z as IEEE divisions (config.h:44-47), H*(x, y, 1), dis and the cost
-// accumulation as unfused multiply-adds (config.h:150-162, gipuma.cu:272-274, 672) -- instead of the numerical model's
-// M1-M3.  Everything else already is the reference's order.  Its results equal the reference's OWN code
-// (compiled for the CPU with fp32 filter weights: the test infrastructure's _ref build) in every bit, at several times the
-// exact flavour's cost: a validation mode.  The host
-// forces the generic kernels (float planes, runtime-sized window); see view_cost_loop.
+// PM_LITERAL = 1 builds the REFERENCE-ORDER flavour (GIPUMA_HIP_FLAG_LITERAL, gipuma_hip_literal.hip): pm_sample.h's
+// PM_MODEL 7 -- every tap its own bilinear fetch at the coordinates gipuma.cu:251-253 writes, x / z and y / z correctly
+// rounded (config.h:44-47), H*(x, y, 1), dis and the cost accumulation as unfused multiply-adds (config.h:150-162,
+// gipuma.cu:272-274, 672).  Everything else already is the reference's order.  Its results equal the reference's OWN code
+// (compiled for the CPU with fp32 filter weights: the test infrastructure's _ref build) in every bit, through the same
+// kernels and schedule as the default flavour (PM_MODEL 6, which differs in the taps only).
 #ifndef PM_LITERAL
 #define PM_LITERAL 0
 #endif
@@ -380,8 +377,9 @@ __host__ __device__ constexpr int work_floats(int tile_texels, bool sweep)
     // gray staging plane (tile_texels floats, dead after stage_tile) and the sweep kernel's
     // per-wavefront task scratch share one region
     const int plane = CH == 1 ? tile_texels : 0;
-    // dense kernels: 256 planes + 256 costs exchanged by the column-per-lane evaluation
-    const int tasks = sweep ? kTaskScratchFloats : 5 * kThreads;
+    // dense kernels: 256 planes + 256 costs exchanged by the column-per-lane evaluation, the evaluation order (256 u16)
+    // and its bucket counters (disparity_order, pm_sweep.h)
+    const int tasks = sweep ? kTaskScratchFloats : 6 * kThreads;
     return plane > tasks ? plane : tasks;
 }
 
@@ -409,6 +407,7 @@ struct Tune {  // experiment switches (GIPUMA_HIP_TUNE), all default off
                               kGenericCombine = 16, kRowMajorTiles = 32, kNoSkip = 64,
                               kUntrustedCosts = 128,  // set by the host after gipuma_hip_set_state
                               kPushConsume = 1u << 18,   // host-internal: propagation costs come from Problem::push_cost
+                              kNoDispSort = 1u << 20,    // push / column-per-lane kernels: tasks in lane order, not by disparity bucket
                               kNoSeen = 1u << 22,        // no skip rule (S) (planes this pixel evaluated before)
                               kNoTwoPhase = 1u << 19,    // refinement bounded per wavefront (v11) instead of two-phase (refine_two_phase)
                               kNoMagicAddr = 1u << 30,  // integer window addressing (bits 8..17: band height)

@@ -4,7 +4,7 @@
 // accumulation (:274, :672).  Part of the device code of the PatchMatch path (pm_device.h).
 //
 // PM_MODEL selects the numerical model of a translation unit, as a mask of the choices the reference's source leaves to
-// nvcc and the texture unit (the same mask as the CPU restatement's gipuma_oracle_set_flavour):
+// nvcc and the texture unit (the same mask as the CPU restatement's flavour switch):
 //     bit 0 (1)  every tap its own bilinear fetch at the coordinates the source writes, (pt.x +- 1 + 0.5f, pt.y + 0.5f),
 //                with its own fraction, and the taps in the reference's order (gipuma.cu:251-253)  -- else model M1: one
 //                4x4 window, the centre tap's fractions, the +-1 differences taken on the texels (taps12);
@@ -30,6 +30,10 @@
 #define PM_MODEL 0
 #elif !defined(PM_MODEL)
 #define PM_MODEL 6
+#endif
+
+#if (PM_MODEL & 1) && !PM_LITERAL
+#error "the literal taps (PM_MODEL bit 0) are built through PM_LITERAL = 1 (gipuma_hip_literal.hip): tex2d_literal lives under it"
 #endif
 
 namespace pm {

@@ -166,6 +166,34 @@ __global__ __launch_bounds__(kThreads) void init_kernel(const Problem *__restric
     cost[center] = c;
 }
 
+// The 256 (pixel, plane) pairs of a column-per-lane step ordered by DISPARITY bucket (performance only: a pair's cost does
+// not depend on when it is evaluated): the 32 pairs a workgroup evaluates together then see the source views at similar
+// offsets along the epipolar lines, so their windows fall into a region the CU's vector L1 holds (see pm_push.h).
+// `order[k]` = lane whose pair is evaluated k-th; `counters`: kDispBuckets ints.  All lanes call it (two barriers).
+constexpr int kDispBuckets = 16;
+__device__ __forceinline__ void disparity_order(const Problem *__restrict__ P, float depth, bool sort, unsigned short *order,
+                                                int *counters)
+{
+    const int tid = threadIdx.x;
+    if (!sort) {
+        order[tid] = (unsigned short)tid;
+        __syncthreads();
+        return;
+    }
+    if (tid < kDispBuckets) counters[tid] = 0;
+    const float disp = disp_depth(P->rc.f, P->rc.baseline, depth);
+    const float t = (disp - P->min_disp) / (P->max_disp - P->min_disp) * (float)kDispBuckets;
+    const int bucket = (int)__builtin_fminf(__builtin_fmaxf(t, 0.0f), (float)(kDispBuckets - 1));  // (NaN -> 0)
+    __syncthreads();
+    const int rank = atomicAdd(&counters[bucket], 1);
+    __syncthreads();
+    int start = 0;
+#pragma unroll
+    for (int b = 0; b < kDispBuckets; b++) start += b < bucket ? counters[b] : 0;
+    order[start + rank] = (unsigned short)tid;
+    __syncthreads();
+}
+
 // init_kernel with the column-per-lane evaluation (view_cost_cols): every lane draws / reads the
 // plane of its own pixel as above, the 256 planes of the tile go through LDS and are evaluated by
 // groups of col_group<BOX>() lanes -- random planes are the worst case for one lane per pixel.
@@ -202,11 +230,14 @@ __global__ __launch_bounds__(kThreads) void init_cols_kernel(const Problem *__re
         }
     }
     candbuf[threadIdx.x] = pl;
-    __syncthreads();
+    // (evaluation order: by disparity bucket, see disparity_order; the order array and its counters lie behind the results)
+    unsigned short *order = reinterpret_cast<unsigned short *>(bres + kThreads);
+    disparity_order(P, depth_from_plane(P->rc, pl, min(px, P->cols - 1), min(py, P->rows - 1)), !(tune & Tune::kNoDispSort), order,
+                    reinterpret_cast<int *>(bres + kThreads + kThreads / 2));
     constexpr int kColGroup = col_group<BOX>(), kColTasks = col_tasks<BOX>();
     const int grp = threadIdx.x / kColGroup, col = threadIdx.x % kColGroup;
     for (int r = 0; r < kThreads / kColTasks; r++) {
-        const int owner = r * kColTasks + grp;
+        const int owner = (int)order[r * kColTasks + grp];
         // pixels outside the image evaluate their dummy plane at the clamped position (never stored)
         const int epx = min(x0 + (owner & 31), P->cols - 1), epy = min(y0 + (owner >> 5), P->rows - 1);
         const float4 ecand = candbuf[owner];
@@ -1106,9 +1137,11 @@ __global__ __launch_bounds__(kThreads) void sweep_cols_kernel(const Problem *__r
         refine_next_step(R);
         __syncthreads();  // the previous step's reads of bres / candbuf are done
         candbuf[threadIdx.x] = cand;
-        __syncthreads();
+        // (evaluation order: by disparity bucket, see disparity_order; rows 1.. of bres are free during the refinement)
+        unsigned short *order = reinterpret_cast<unsigned short *>(L.bres + kThreads);
+        disparity_order(P, L.active ? d_new : P->rc.depth_max, !(tune & Tune::kNoDispSort), order, L.wcnt);
         for (int r = 0; r < kThreads / kColTasks; r++) {
-            const int owner = r * kColTasks + grp;
+            const int owner = (int)order[r * kColTasks + grp];
             int olx, oly;
             owner_pixel(L, owner, colour, olx, oly);
             // pixels outside the image (ragged last tile) evaluate their dummy plane at the clamped

@@ -99,22 +99,27 @@ typedef struct gipuma_hip_params {
  * views (the reference re-uploads every image for every view, main.cpp:960-968).  The caller promises not
  * to change or free those planes before gipuma_hip_cache_clear(). */
 #define GIPUMA_HIP_FLAG_CACHE_IMAGES 4u
-/* Mode flag (SURVEY.md 8b "mode flags (bit-exact/fast)"): without it every result is bit-identical to the CPU oracle of
- * the stated numerical model.  With it the session runs the TOLERANCE-JUDGED flavour of the same kernels --
- * the operation-order freedoms the reference takes by being built with --use_fast_math (CMakeLists.txt:23): hardware
- * reciprocal without the correcting step, the homography of getHomography_cu (gipuma.cu:339-356) from per-view products
- * folded on the host, reassociated bilinear taps, tree sums.  Same algorithm, schedule and random numbers; results agree
- * with the exact mode's like the reference's own code does (fraction of pixels inside 1e-4 relative depth / 1e-3 normal:
- * tests/test_fast_mode.py), not bit for bit. */
+/* Mode flag (SURVEY.md 8b "mode flags (bit-exact/fast)"): without it every result is bit-identical to the CPU restatement of
+ * the stated numerical model (since round 6 correctly rounded x/z, y/z and unfused multiply-adds like the
+ * reference's source; the model's bilinear taps).  With it the session runs the TOLERANCE-JUDGED flavour of the same kernels
+ * -- the operation-order freedoms the reference takes by being built with --use_fast_math (CMakeLists.txt:23) and nvcc's
+ * contraction: the numerical model of rounds 1-5 (x * (1/z) for x / z, fused multiply-adds in the sample loop) with the
+ * hardware reciprocal without its correcting step, no proof that the window's denominators are in the exact reciprocal's
+ * range, and the nine divisions by the plane offset in getHomography_cu (gipuma.cu:339-356) as one reciprocal and a Markstein
+ * step each.  (Measured and rejected, compiled only by A/B builds: a host-folded homography, tree sums -- pm_core.h.)  Same
+ * algorithm, schedule and random numbers; results are judged by the fraction of pixels inside 1e-4 relative depth / 1e-3
+ * normal of the default mode's and of the reference's (tests/test_fast_mode.py, tests/test_headline_parity.py,
+ * DESIGN.md 3a), not bit for bit. */
 #define GIPUMA_HIP_FLAG_FAST 8u
 /* Mode flag: the REFERENCE-ORDER flavour.  The per-sample arithmetic of the patch cost in the literal operation order of the
- * reference's source -- one bilinear fetch per tap at the coordinates gipuma.cu:251-253 writes, IEEE x/z and y/z
- * (config.h:44-47), unfused multiply-adds (config.h:150-162, gipuma.cu:272-274, 672) -- instead of the numerical model's
- * cheaper forms.  Results equal the reference's OWN device code (compiled for the CPU with fp32 texture-filter
- * weights, oracle/_ref; tests/golden/ref_*.npz) in every bit of every plane and cost; several times slower than the default
- * mode (float planes, five gathers of four texels per sample, none of the work-sharing kernels): a validation mode.  Gray and
- * colour (T = float4: the reference's float4 operators and l1_norm, vector_operations.h, gipuma.cu:174-179); excludes
- * GIPUMA_HIP_FLAG_FAST. */
+ * reference's source -- one bilinear fetch per tap at the coordinates gipuma.cu:251-253 writes, each with its own fraction;
+ * correctly rounded x/z and y/z (config.h:44-47); unfused multiply-adds (config.h:150-162, gipuma.cu:272-274, 672).  Results
+ * equal the reference's OWN device code (compiled for the CPU with fp32 texture-filter weights, oracle/_ref;
+ * tests/golden/ref_*.npz) in every bit of every plane and cost -- up to BASELINE's headline frame (tests/test_headline_parity.py).
+ * Since round 6 it runs through the same kernels and schedule as the default mode (packed 8-bit windows, push / column-per-lane
+ * / plane-keyed propagation, bounded refinement): about 1.3x the default mode's time.  The default mode differs from it in the
+ * taps only (one window, the centre tap's fractions, differences taken on the texels).  Gray and colour (T = float4: the
+ * reference's float4 operators and l1_norm, vector_operations.h, gipuma.cu:174-179); excludes GIPUMA_HIP_FLAG_FAST. */
 #define GIPUMA_HIP_FLAG_LITERAL 16u
 
 /* Everything runcuda() reads out of GlobalState (globalstate.h:24-45). */

@@ -33,6 +33,12 @@
 #include "gipuma_oracle.h"
 
 #include <math.h>
+#if defined(__AVX2__) && defined(__FMA__)
+#include <immintrin.h>
+#define GO_HAVE_AVX2 1
+#else
+#define GO_HAVE_AVX2 0
+#endif
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -472,7 +478,7 @@ typedef struct {
     unsigned epoch;
     int px, py;
     float centre;
-    float w[GO_MAXWIN], I[GO_MAXWIN], gx1[GO_MAXWIN], gy1[GO_MAXWIN];
+    float w[GO_MAXWIN + 8], I[GO_MAXWIN + 8], gx1[GO_MAXWIN + 8], gy1[GO_MAXWIN + 8]; /* (+8: the 8-wide path reads whole vectors) */
 } go_pixel_cache;
 static _Thread_local go_pixel_cache go_pc = {0, 0, -1, -1, 0.0f, {0}, {0}, {0}, {0}};
 static unsigned go_epoch = 1;
@@ -507,6 +513,116 @@ static const go_pixel_cache *go_cache_for(const gipuma_hip_desc *d, int px, int 
     return pc;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * The same sample arithmetic eight window rows at a time (AVX2 + FMA: the flags this file is built with).  Every lane
+ * executes the operations of go_warp / go_taps3_s / go_dis_cached in their order -- IEEE add, mul, div, fma, floor and
+ * min/max with the scalar functions' NaN behaviour (vmaxps / vminps return their SECOND operand when one is NaN, as
+ * fmaxf(x, c) / fminf(x, c) return c) -- so a lane's dis equals the scalar function's bit for bit; the chain over the
+ * window (columns outer, rows inner, gipuma.cu:633-676) stays scalar and sequential.  Flavours with the literal taps
+ * (bit 0) keep the scalar path.  gipuma_oracle_set_simd(0) switches back to the scalar functions (tests compare the two).
+ * ---------------------------------------------------------------------------------------- */
+static int go_simd = GO_HAVE_AVX2;
+void gipuma_oracle_set_simd(int on) { go_simd = on && GO_HAVE_AVX2; }
+int gipuma_oracle_get_simd(void) { return go_simd; }
+
+#if GO_HAVE_AVX2
+typedef struct {
+    __m256 sx, sy;
+} go_v2;
+static inline go_v2 go_warp8(const float *H, float qx, __m256 qy, int fl)
+{
+    __m256 X, Y, Z;
+    if (fl & GO_LIT_FMA) {
+        X = _mm256_add_ps(_mm256_add_ps(_mm256_set1_ps(H[0] * qx), _mm256_mul_ps(_mm256_set1_ps(H[1]), qy)), _mm256_set1_ps(H[2]));
+        Y = _mm256_add_ps(_mm256_add_ps(_mm256_set1_ps(H[3] * qx), _mm256_mul_ps(_mm256_set1_ps(H[4]), qy)), _mm256_set1_ps(H[5]));
+        Z = _mm256_add_ps(_mm256_add_ps(_mm256_set1_ps(H[6] * qx), _mm256_mul_ps(_mm256_set1_ps(H[7]), qy)), _mm256_set1_ps(H[8]));
+    } else {
+        X = _mm256_fmadd_ps(_mm256_set1_ps(H[1]), qy, _mm256_set1_ps(fmaf(H[0], qx, H[2])));
+        Y = _mm256_fmadd_ps(_mm256_set1_ps(H[4]), qy, _mm256_set1_ps(fmaf(H[3], qx, H[5])));
+        Z = _mm256_fmadd_ps(_mm256_set1_ps(H[7]), qy, _mm256_set1_ps(fmaf(H[6], qx, H[8])));
+    }
+    go_v2 o;
+    if (fl & GO_LIT_DIV) {
+        o.sx = _mm256_div_ps(X, Z);
+        o.sy = _mm256_div_ps(Y, Z);
+    } else {
+        const __m256 rz = _mm256_div_ps(_mm256_set1_ps(1.0f), Z);
+        o.sx = _mm256_mul_ps(X, rz);
+        o.sy = _mm256_mul_ps(Y, rz);
+    }
+    return o;
+}
+static inline __m256 go_lerp8(__m256 a, __m256 t0, __m256 t1) { return _mm256_fmadd_ps(a, _mm256_sub_ps(t1, t0), t0); }
+static inline __m256 go_abs8(__m256 x) { return _mm256_andnot_ps(_mm256_set1_ps(-0.0f), x); }
+/* go_taps3_s for eight positions: out = { centre, d/dx, d/dy } (model M1) */
+static inline void go_taps3_8(const float *img, int rows, int cols, int pitch, int stride, __m256 x, __m256 y, __m256 out[3])
+{
+    const __m256 fx0 = _mm256_floor_ps(x), fy0 = _mm256_floor_ps(y);
+    const __m256 a = _mm256_sub_ps(x, fx0), b = _mm256_sub_ps(y, fy0);
+    const __m256i ix = _mm256_cvttps_epi32(_mm256_min_ps(_mm256_max_ps(fx0, _mm256_set1_ps(-2.0f)), _mm256_set1_ps((float)cols)));
+    const __m256i iy = _mm256_cvttps_epi32(_mm256_min_ps(_mm256_max_ps(fy0, _mm256_set1_ps(-2.0f)), _mm256_set1_ps((float)rows)));
+    const __m256i zero = _mm256_setzero_si256(), cmax = _mm256_set1_epi32(cols - 1), rmax = _mm256_set1_epi32(rows - 1);
+    __m256i cx[4], ry[4];
+    for (int c = 0; c < 4; c++) {
+        const __m256i xc = _mm256_min_epi32(_mm256_max_epi32(_mm256_add_epi32(ix, _mm256_set1_epi32(c - 1)), zero), cmax);
+        cx[c] = _mm256_mullo_epi32(xc, _mm256_set1_epi32(stride));
+        const __m256i yc = _mm256_min_epi32(_mm256_max_epi32(_mm256_add_epi32(iy, _mm256_set1_epi32(c - 1)), zero), rmax);
+        ry[c] = _mm256_mullo_epi32(yc, _mm256_set1_epi32(pitch));
+    }
+#define GO_T(r, c) _mm256_i32gather_ps(img, _mm256_add_epi32(ry[r], cx[c]), 4)
+    const __m256 t01 = GO_T(0, 1), t02 = GO_T(0, 2);
+    const __m256 t10 = GO_T(1, 0), t11 = GO_T(1, 1), t12 = GO_T(1, 2), t13 = GO_T(1, 3);
+    const __m256 t20 = GO_T(2, 0), t21 = GO_T(2, 1), t22 = GO_T(2, 2), t23 = GO_T(2, 3);
+    const __m256 t31 = GO_T(3, 1), t32 = GO_T(3, 2);
+#undef GO_T
+    const __m256 V0 = go_lerp8(b, t10, t20), V1 = go_lerp8(b, t11, t21), V2 = go_lerp8(b, t12, t22), V3 = go_lerp8(b, t13, t23);
+    const __m256 W1 = go_lerp8(b, _mm256_sub_ps(t21, t01), _mm256_sub_ps(t31, t11));
+    const __m256 W2 = go_lerp8(b, _mm256_sub_ps(t22, t02), _mm256_sub_ps(t32, t12));
+    out[0] = go_lerp8(a, V1, V2);
+    out[1] = go_lerp8(a, _mm256_sub_ps(V2, V0), _mm256_sub_ps(V3, V1));
+    out[2] = go_lerp8(a, W1, W2);
+}
+static inline __m256 go_dis_mix8(float alpha, __m256 colDis, __m256 gradDis, int fl)
+{
+    const __m256 oma = _mm256_set1_ps(1.f - alpha), al = _mm256_set1_ps(alpha);
+    if (fl & GO_LIT_FMA) return _mm256_add_ps(_mm256_mul_ps(oma, colDis), _mm256_mul_ps(al, gradDis));
+    return _mm256_fmadd_ps(al, gradDis, _mm256_mul_ps(oma, colDis));
+}
+/* the eight row coordinates (float)(py + j), j = j0, j0 + 2, ..., exact small integers */
+static inline __m256 go_rows8(int py, int j0)
+{
+    return _mm256_cvtepi32_ps(_mm256_add_epi32(_mm256_set1_epi32(py + j0), _mm256_setr_epi32(0, 2, 4, 6, 8, 10, 12, 14)));
+}
+
+static float go_view_cost_simd(const gipuma_hip_desc *d, int view, int px, int py, const float *H, const go_pixel_cache *pc, int fl)
+{
+    const gipuma_hip_params *ap = &d->params;
+    const int hRad = (ap->box_hsize - 1) / 2, vRad = (ap->box_vsize - 1) / 2;
+    const int nj = vRad + 1; /* rows of the window: j = -vRad, -vRad + 2, ..., vRad */
+    const __m256 tau_g = _mm256_set1_ps(ap->tau_gradient), tau_c = _mm256_set1_ps(ap->tau_color);
+    float cost = 0.0f;
+    int k = 0;
+    for (int i = -hRad; i < hRad + 1; i += GO_WIN_INCREMENT) {
+        const float qx = (float)(px + i);
+        for (int jb = 0; jb < nj; jb += 8) {
+            const go_v2 s = go_warp8(H, qx, go_rows8(py, -vRad + 2 * jb), fl);
+            __m256 t[3];
+            go_taps3_8(d->images[view], d->rows, d->cols, d->pitch, 1, s.sx, s.sy, t);
+            const __m256 colDiff = go_abs8(_mm256_sub_ps(_mm256_loadu_ps(pc->I + k), t[0]));
+            const __m256 gradX = _mm256_sub_ps(_mm256_loadu_ps(pc->gx1 + k), t[1]);
+            const __m256 gradY = _mm256_sub_ps(_mm256_loadu_ps(pc->gy1 + k), t[2]);
+            const __m256 gradDis = _mm256_min_ps(_mm256_mul_ps(_mm256_add_ps(go_abs8(gradX), go_abs8(gradY)), _mm256_set1_ps(0.0625f)), tau_g);
+            const __m256 colDis = _mm256_min_ps(colDiff, tau_c);
+            float dis[8];
+            _mm256_storeu_ps(dis, go_dis_mix8(ap->alpha, colDis, gradDis, fl));
+            const int n = nj - jb < 8 ? nj - jb : 8;
+            for (int l = 0; l < n; l++, k++) cost = go_accum(pc->w[k], dis[l], cost, fl);
+        }
+    }
+    return cost;
+}
+#endif
+
 static float go_view_cost(const gipuma_hip_desc *d, int view, int px, int py, const float pl[4])
 {
     const gipuma_hip_params *ap = &d->params;
@@ -519,6 +635,9 @@ static float go_view_cost(const gipuma_hip_desc *d, int view, int px, int py, co
     go_homography(&d->cameras[0], &d->cameras[view], pl, pl[3], H);
 
     const go_pixel_cache *pc = go_cache_for(d, px, py);
+#if GO_HAVE_AVX2
+    if (go_simd && !(fl & GO_LIT_TAPS)) return go_view_cost_simd(d, view, px, py, H, pc, fl);
+#endif
     float cost = 0.0f;
     int k = 0;
     for (int i = -hRad; i < hRad + 1; i += GO_WIN_INCREMENT) {
@@ -547,7 +666,7 @@ typedef struct {
     const gipuma_hip_desc *d;
     unsigned epoch;
     int px, py;
-    float w[GO_MAXWIN], lv[GO_MAXWIN][3], gx1[GO_MAXWIN][3], gy1[GO_MAXWIN][3];
+    float w[GO_MAXWIN + 8], lv[GO_MAXWIN + 8][3], gx1[GO_MAXWIN + 8][3], gy1[GO_MAXWIN + 8][3]; /* (+8: whole vectors) */
 } go_pixel_cache_c4;
 static _Thread_local go_pixel_cache_c4 go_pc4 = {0, 0, -1, -1, {0}, {{0}}, {{0}}, {{0}}};
 
@@ -583,6 +702,47 @@ static const go_pixel_cache_c4 *go_cache_c4_for(const gipuma_hip_desc *d, int px
     return pc;
 }
 
+#if GO_HAVE_AVX2
+static inline __m256 go_l1_3_8(__m256 x, __m256 y, __m256 z)
+{
+    return _mm256_mul_ps(_mm256_add_ps(_mm256_add_ps(go_abs8(x), go_abs8(y)), go_abs8(z)), _mm256_set1_ps(0.3333333f));
+}
+static float go_view_cost_c4_simd(const gipuma_hip_desc *d, int view, int px, int py, const float *H, const go_pixel_cache_c4 *pc, int fl)
+{
+    const gipuma_hip_params *ap = &d->params;
+    const float *src = d->images[view];
+    const int hRad = (ap->box_hsize - 1) / 2, vRad = (ap->box_vsize - 1) / 2;
+    const int nj = vRad + 1;
+    const __m256 tau_g = _mm256_set1_ps(ap->tau_gradient), tau_c = _mm256_set1_ps(ap->tau_color);
+    const __m256i k3 = _mm256_setr_epi32(0, 3, 6, 9, 12, 15, 18, 21);
+    float cost = 0.0f;
+    int k = 0;
+    for (int i = -hRad; i < hRad + 1; i += GO_WIN_INCREMENT) {
+        const float qx = (float)(px + i);
+        for (int jb = 0; jb < nj; jb += 8) {
+            const go_v2 s = go_warp8(H, qx, go_rows8(py, -vRad + 2 * jb), fl);
+            __m256 cd[3], gX[3], gY[3];
+            for (int c = 0; c < 3; c++) {
+                __m256 t[3];
+                go_taps3_8(src + c, d->rows, d->cols, d->pitch, 4, s.sx, s.sy, t);
+                cd[c] = _mm256_sub_ps(_mm256_i32gather_ps(&pc->lv[k][c], k3, 4), t[0]);
+                gX[c] = _mm256_sub_ps(_mm256_i32gather_ps(&pc->gx1[k][c], k3, 4), t[1]);
+                gY[c] = _mm256_sub_ps(_mm256_i32gather_ps(&pc->gy1[k][c], k3, 4), t[2]);
+            }
+            const __m256 colDiff = go_l1_3_8(cd[0], cd[1], cd[2]);
+            const __m256 gradDis = _mm256_min_ps(_mm256_mul_ps(_mm256_add_ps(go_l1_3_8(gX[0], gX[1], gX[2]), go_l1_3_8(gY[0], gY[1], gY[2])),
+                                                               _mm256_set1_ps(0.0625f)), tau_g);
+            const __m256 colDis = _mm256_min_ps(colDiff, tau_c);
+            float dis[8];
+            _mm256_storeu_ps(dis, go_dis_mix8(ap->alpha, colDis, gradDis, fl));
+            const int n = nj - jb < 8 ? nj - jb : 8;
+            for (int l = 0; l < n; l++, k++) cost = go_accum(pc->w[k], dis[l], cost, fl);
+        }
+    }
+    return cost;
+}
+#endif
+
 static float go_view_cost_c4(const gipuma_hip_desc *d, int view, int px, int py, const float pl[4])
 {
     const gipuma_hip_params *ap = &d->params;
@@ -598,6 +758,9 @@ static float go_view_cost_c4(const gipuma_hip_desc *d, int view, int px, int py,
 
     const go_pixel_cache_c4 *pc = go_cache_c4_for(d, px, py);
     const int fl = go_flavour;
+#if GO_HAVE_AVX2
+    if (go_simd && !(fl & GO_LIT_TAPS)) return go_view_cost_c4_simd(d, view, px, py, H, pc, fl);
+#endif
     float cost = 0.0f;
     int k = 0;
     for (int i = -hRad; i < hRad + 1; i += GO_WIN_INCREMENT) {

@@ -53,6 +53,9 @@ void gipuma_oracle_set_flavour(int mask);
 int gipuma_oracle_get_flavour(void);
 int gipuma_oracle_default_flavour(void); /* 6: what the kernels' default mode computes; set_flavour(-1) returns to it */
 void gipuma_oracle_set_threads(int n);
+/* the sample loop eight window rows at a time (AVX2; the same operations per sample, bit-identical: tests compare) or scalar */
+void gipuma_oracle_set_simd(int on);
+int gipuma_oracle_get_simd(void);
 
 /* ---- unit pieces, exported for the known-answer tests ---- */
 float gipuma_oracle_exp(float x);

@@ -12,10 +12,18 @@ if ROOT not in sys.path:
 # GIPUMA_HIP_EXPERIMENTS is set; a production process never sets it.  The tests set it -- and start from a clean slate:
 # any other GIPUMA_HIP_* variable a developer's or CI's shell happens to carry would silently change what the
 # default-schedule tests exercise, so everything but the switch itself is dropped here (tests that want a knob set it
-# themselves, scoped: tests/test_parity_gpu.py::_with_env).
-for _k in [k for k in os.environ if k.startswith("GIPUMA_HIP_") and k != "GIPUMA_HIP_EXPERIMENTS"]:
+# themselves, scoped: tests/test_parity_gpu.py::_with_env).  ONE variable is kept on purpose: GIPUMA_HIP_LIB, the way an
+# A/B run points the whole suite at a differently built library (scripts/build_variant.sh) -- dropping it made such a run
+# test the default library instead; which library the suite loaded is printed in the report header.
+_KEEP = ("GIPUMA_HIP_EXPERIMENTS", "GIPUMA_HIP_LIB")
+for _k in [k for k in os.environ if k.startswith("GIPUMA_HIP_") and k not in _KEEP]:
     del os.environ[_k]
 os.environ["GIPUMA_HIP_EXPERIMENTS"] = "1"
+
+
+def pytest_report_header(config):
+    from gipuma_amd import abi
+    return "gipuma_hip library under test: %s" % (os.environ.get("GIPUMA_HIP_LIB") or abi.LIB_PATH)
 
 
 def pytest_configure(config):

@@ -664,6 +664,17 @@ def test_png_reader_matches_pil_for_every_colour_type(tmp_path):
     (tmp_path / "huge.png").write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 60000, 60000, 8, 0, 0, 0, 0)) +
                                         chunk(b"IDAT", zlib.compress(b"\0" * 100)) + chunk(b"IEND", b""))
     assert _host_read_image(tmp_path / "huge.png") is None
+    # 16-bit colour (PIL cannot write it: by hand, filter 0): libpng's order for IMREAD_GRAYSCALE is rgb_to_gray on the
+    # 16-bit samples -- (9797 r + 19234 g + 3737 b + 16384) >> 15 -- and THEN the 16-to-8 chop
+    rgb16 = rng.integers(0, 65536, size=(h, w, 3), dtype=np.uint16)
+    rows16 = b"".join(b"\0" + rgb16[y].astype(">u2").tobytes() for y in range(h))
+    (tmp_path / "rgb16.png").write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 2, 0, 0, 0)) +
+                                         chunk(b"IDAT", zlib.compress(rows16)) + chunk(b"IEND", b""))
+    r6, g6, b6 = (rgb16[..., k].astype(np.int64) for k in range(3))
+    want16 = ((9797 * r6 + 19234 * g6 + 3737 * b6 + 16384) >> 15) >> 8
+    assert np.array_equal(_host_read_image(tmp_path / "rgb16.png"), want16.astype(np.float32))
+    col16 = _host_read_image(tmp_path / "rgb16.png", colour=True)  # (colour reads keep the high bytes)
+    assert np.array_equal(col16[..., 2], (rgb16[..., 0] >> 8).astype(np.float32))
 
 
 def test_python_runner_reads_jpeg_as_luma(tmp_path):

@@ -1,7 +1,10 @@
 """GIPUMA_HIP_FLAG_LITERAL (include/gipuma_hip.h): the reference-order flavour of the kernels.  Its results must equal the
 reference's OWN device code -- /root/reference/gipuma.cu compiled for the CPU with fp32 texture-filter weights (oracle/_ref,
 which travels with the snapshot; its committed outputs tests/golden/ref_*.npz where it does not) -- in EVERY bit of every plane
-and every cost, launch by launch and free-running, and the oracle's literal flavour 7 likewise."""
+and every cost, launch by launch and free-running, and the oracle's literal flavour 7 likewise.  Since round 6 the flavour
+runs through the same kernels as the default mode (push, column-per-lane, plane-keyed, bounded refinement): the sizes below
+are chosen so that each family is reached; the real frame sizes are in tests/test_headline_parity.py."""
+import os
 import numpy as np
 import pytest
 
@@ -110,3 +113,43 @@ def test_literal_mode_boundaries(hip, tiny_problem):
         s.solve(timing=False)
         n4, c = runcuda(gs)
     assert np.array_equal(bits(n4), bits(on)) and np.array_equal(bits(c), bits(oc))
+
+
+@pytest.mark.parametrize("what", ["gray_box15_all_families", "gray_box25", "gray_box11_small", "colour_box15", "runtime_window"])
+def test_literal_taps_one_by_one_path(hip, what):
+    """The five taps of a sample normally come from ONE 4x4 window (their separately rounded coordinates land on the centre
+    tap's neighbours); a sample for which they do not -- about one in a million on real data -- fetches every tap by itself
+    (pm_sample.h: taps_gather).  variants/libgipuma_hip_gather.so is the same library with -DPM_LITERAL_FORCE_GATHER: every
+    8th sample takes that path.  Both must give the reference's bits: the variant's maps and costs equal the shipped
+    library's, and the oracle's flavour 7."""
+    path = os.path.join(os.path.dirname(abi.LIB_PATH), "variants", "libgipuma_hip_gather.so")
+    assert os.path.exists(path), "built by __graft_entry__.build()"
+    kw = {}
+    if what == "gray_box15_all_families":  # >= 1024 tiles: push, column-per-lane, fused plane-keyed launches, prefilter
+        cfg, kw = "C", dict(cols=832, rows=640, iterations=3)
+    elif what == "gray_box25":
+        cfg, kw = "D", dict(cols=832, rows=640, iterations=2, n_src=6)
+    elif what == "gray_box11_small":
+        cfg, kw = "B", dict(cols=320, rows=256, iterations=3)
+    elif what == "colour_box15":
+        cfg, kw = "C", dict(cols=832, rows=640, iterations=2, n_src=5, colour=True)
+    else:
+        cfg = synth.tiny_config(cols=150, rows=100, n_src=4, blocksize=9, iterations=2, n_best=3)
+    gs, _ = synth.build_problem(cfg, **kw)
+    n4, c = runcuda(gs, literal=True)
+    forced = abi.load_library(path)
+    keep = abi._lib
+    abi._lib = forced
+    try:
+        g4, gc = runcuda(gs, literal=True)
+    finally:
+        abi._lib = keep
+    assert np.array_equal(bits(g4), bits(n4)) and np.array_equal(bits(gc), bits(c))
+    if gs.rows * gs.cols <= 320 * 256:
+        L = oracle_lib.lib()
+        L.gipuma_oracle_set_flavour(7)
+        try:
+            on, oc = OracleState(gs).run()
+        finally:
+            L.gipuma_oracle_set_flavour(-1)
+        assert np.array_equal(bits(n4), bits(on)) and np.array_equal(bits(c), bits(oc))

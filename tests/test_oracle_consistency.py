@@ -44,3 +44,32 @@ def test_solver_reconstructs_the_analytic_surface():
     assert (rel < 0.01).mean() > 0.95
     nn = np.linalg.norm(n4[..., :3], axis=-1)
     assert np.abs(nn - 1).max() < 1e-4
+
+
+def test_vectorised_sample_loop_equals_the_scalar_one():
+    """the oracle evaluates eight window rows at a time (AVX2; gipuma_oracle_set_simd) with the scalar functions' operations
+    in their order: whole solves are bit-identical to the scalar path's -- the default flavour and the model of rounds 1-5,
+    gray and colour, windows of 8 rows, fewer (box 11) and more (box 25: 13), a ragged frame"""
+    from tests import oracle_lib
+    L = oracle_lib.lib()
+    L.gipuma_oracle_set_simd.argtypes = [__import__("ctypes").c_int]
+    if not L.gipuma_oracle_get_simd():
+        return  # (built without AVX2: there is only the scalar path)
+    cases = [(synth.tiny_config(), {}),
+             (synth.tiny_config(cols=70, rows=50, n_src=3, blocksize=25, iterations=1, n_best=3), {}),
+             (synth.tiny_config(cols=75, rows=50, n_src=3, blocksize=11, iterations=2, n_best=2), {}),
+             (synth.tiny_config(cols=64, rows=48, n_src=3, blocksize=15, iterations=2, n_best=2), dict(colour=True))]
+    try:
+        for cfg, kw in cases:
+            gs, _ = synth.build_problem(cfg, **kw)
+            for fl in (-1, 0):
+                L.gipuma_oracle_set_flavour(fl)
+                L.gipuma_oracle_set_simd(0)
+                a = OracleState(gs).run()
+                a = (a[0].copy(), a[1].copy())
+                L.gipuma_oracle_set_simd(1)
+                b = OracleState(gs).run()
+                assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(bits(a[1]), bits(b[1])), (cfg, kw, fl)
+    finally:
+        L.gipuma_oracle_set_simd(1)
+        L.gipuma_oracle_set_flavour(-1)

@@ -953,6 +953,21 @@ def test_fast_reciprocal_is_exact_on_this_device(hip):
     assert n.value == 0
 
 
+def test_markstein_quotient_is_the_ieee_quotient(hip):
+    """x / z of the warped point (getCorrespondingPoint_cu, gipuma.cu:207-217; vecdiv4, config.h:44-47) in the default and the
+    reference-order flavour: r = RN(1/z), q = RN(x r), q' = RN(q + RN(x - q z) r).  The proof is by exhaustion over all
+    2^23 x 2^23 significand pairs (31 s on an MI355X: profiles/r06_selftest_quotient.txt); here three slices of the
+    denominators -- the first, one across the middle, the last 2^13 -- against all 2^23 numerators each: 2 * 10^11 pairs"""
+    n = C.c_ulonglong(1)
+    total = 0
+    for z0 in (0, (1 << 22) - (1 << 12), (1 << 23) - (1 << 13)):
+        assert hip.gipuma_hip_selftest_quotient(0, z0, 1 << 13, C.byref(n)) == 0
+        total += n.value
+    assert total == 0
+    assert hip.gipuma_hip_selftest_quotient(0, 1 << 23, 1, C.byref(n)) == abi.ERR_ARG  # out of the significand range
+
+
+
 def test_degenerate_planes_take_the_safe_divide_path(hip, tiny_problem):
     """planes through / near the source camera centres make some warped denominators tiny, zero or
     negative: the window guard must fall back to the IEEE divide and still match the oracle"""

@@ -92,6 +92,24 @@ def test_bench_launches_its_own_ranks():
     assert len({r["device"] for r in d["ranks"]}) == 2        # bound to two different devices
 
 
+def test_bench_eight_rank_dry_run():
+    """the command shape the driver's scaling run has at its widest (`bench.py --gpus 8`, config E of BASELINE.json: eight
+    reference views, one per GPU, /root/reference/scripts/dtu_fast.sh:30-55): eight processes, one rendezvous, eight distinct
+    reference views = synth.DTU_REF_VIEWS, eight device ids, ONE JSON line"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["dry_run"] and d["scaling"] == "weak"
+    assert [r["rank"] for r in d["ranks"]] == list(range(8))
+    assert sorted(r["ref_view"] for r in d["ranks"]) == sorted(synth.DTU_REF_VIEWS[:8]) and len(synth.DTU_REF_VIEWS) >= 8
+    assert len({r["device"] for r in d["ranks"]}) == 8
+
+
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     import subprocess
     import sys
@@ -159,3 +177,23 @@ def test_bench_two_ranks_on_hardware(hip):
     # whole-job value = both ranks' pixels over the slower rank's time
     assert d["value"] <= sum(r["value"] for r in d["ranks"]) * 1.0001
     assert d["quality"]["frac_within_1pct_of_gt"] > 0.5
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_on_hardware(hip):
+    """the eight-rank path on the one-GPU box before an 8-GPU node ever runs it: eight processes, each with its own
+    reference view's config-C problem resident (8 x 325 MB), rendezvous, barrier, MAX over ranks, one JSON line whose value
+    is the eight views over the slowest rank's time"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--oversubscribe", "--steps", "1",
+                        "--warmup", "0", "--no-extras", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["value"] > 0
+    assert [r["rank"] for r in d["ranks"]] == list(range(8))
+    assert len({r["ref_view"] for r in d["ranks"]}) == 8
+    assert d["value"] <= sum(r["value"] for r in d["ranks"]) * 1.0001
