@@ -245,9 +245,8 @@ sweep_fn pick_sweep_ch(const gipuma_hip_session *s)
     switch (s->box) {
     case 11: return pick_sweep_box<11, CH>(s->u8, s->combine_reg);
     case 15: return pick_sweep_box<15, CH>(s->u8, s->combine_reg);
-    case 19:  // the reference's default window (algorithmparameters.h:25-26), gray: compile-time loops of the sweep and
-              // init kernels (pipelined sample loop, two-phase refinement, prefilter); no push / plane-keyed / column-per-lane
-              // instantiation (the reference's scripts pass 11, 15 or 25)
+    case 19:  // the reference's default window (algorithmparameters.h:25-26), gray: since round 6 with every kernel family of
+              // boxes 15 and 25 (push, column-per-lane in groups of 16 lanes, plane-keyed, prefilter)
         if constexpr (CH == 1) return pick_sweep_box<19, 1>(s->u8, s->combine_reg);
         return pick_sweep_box<0, CH>(s->u8, s->combine_reg);
     case 25: return pick_sweep_box<25, CH>(s->u8, s->combine_reg);
@@ -333,10 +332,12 @@ int launch_push(gipuma_hip_session *s, int colour, bool hist)
     typedef void (*push_fn)(const pm::Problem *, const float4 *, int, int, unsigned);
     const push_fn k = s->ch == 4    ? pm::push_kernel_c4<15>
                       : s->box == 15 ? pm::push_kernel<15>
+                      : s->box == 19 ? pm::push_kernel<19>
                       : s->box == 25 ? pm::push_kernel<25>
                                      : pm::push_kernel<11>;
     size_t lds = sizeof(float) * (size_t)(s->ch == 4      ? pm::PushLayoutC4<15>::total
                                           : s->box == 15 ? pm::PushLayout<15>::total
+                                          : s->box == 19 ? pm::PushLayout<19>::total
                                           : s->box == 25 ? pm::PushLayout<25>::total
                                                          : pm::PushLayout<11>::total);
     if (const char *t = exp_env("PUSH_LDS_KB")) lds = std::max(lds, (size_t)atoi(t) * 1024);  // experiment: fewer workgroups per CU
@@ -360,10 +361,12 @@ int launch_group(gipuma_hip_session *s, int colour, bool hist, unsigned tune)
     typedef void (*group_fn)(const pm::Problem *, const float4 *, const float *, int, int, unsigned);
     const group_fn k = s->ch == 4     ? pm::group_kernel<15, 4>
                        : s->box == 15 ? pm::group_kernel<15>
+                       : s->box == 19 ? pm::group_kernel<19>
                        : s->box == 25 ? pm::group_kernel<25>
                                       : pm::group_kernel<11>;
     const size_t lds = sizeof(float) * (size_t)(s->ch == 4     ? pm::GroupLayout<15, 4>::total
                                                 : s->box == 15 ? pm::GroupLayout<15>::total
+                                                : s->box == 19 ? pm::GroupLayout<19>::total
                                                 : s->box == 25 ? pm::GroupLayout<25>::total
                                                                : pm::GroupLayout<11>::total);
     if (!s->group_attr_set) {
@@ -436,18 +439,20 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
     // (pixel, plane) pair, pm::sweep_cols_kernel) when the problem has that instantiation
     // (box 15 only: its 8 window columns fill the 8 lanes of a group; box 11, 6 of 8 lanes, measured
     // slower than one lane per pixel on config B: 18.0 vs 19.8 Mpix/s)
-    const bool cols_ok = s->u8 && ((s->ch == 1 && s->hp.magic_addr && (s->box == 15 || s->box == 25)) ||
+    const bool cols_ok = s->u8 && ((s->ch == 1 && s->hp.magic_addr && (s->box == 15 || s->box == 19 || s->box == 25)) ||
                                    (s->ch == 4 && s->box == 15)) &&
                          !(tune & (Tune::kNoColsKernel | Tune::kNoInterior));
     size_t lds = s->lds_sweep;
     // measured: box 15 (groups of 8 lanes) wins the first four half-sweeps of config C, box 25 (13 of 16
     // lanes) the first three of config D (128.7 / 90.9 / 73.7 -> 88.3 / 78.7 / 72.0 ms, the fourth loses)
-    const int cols_launches = s->cols_launches >= 0 ? s->cols_launches : (s->box == 25 ? 3 : 4);
+    const int cols_launches = s->cols_launches >= 0 ? s->cols_launches : ((s->box == 19 || s->box == 25) ? 3 : 4);
     if (cols_ok && (2 * iteration + colour < cols_launches || (tune & Tune::kColsAlways))) {
         if (s->ch == 4)
             k = s->combine_reg ? pm::sweep_cols_kernel<15, true, 4> : pm::sweep_cols_kernel<15, false, 4>;
         else if (s->box == 15)
             k = s->combine_reg ? pm::sweep_cols_kernel<15, true> : pm::sweep_cols_kernel<15, false>;
+        else if (s->box == 19)
+            k = s->combine_reg ? pm::sweep_cols_kernel<19, true> : pm::sweep_cols_kernel<19, false>;
         else
             k = s->combine_reg ? pm::sweep_cols_kernel<25, true> : pm::sweep_cols_kernel<25, false>;
     }
@@ -476,8 +481,12 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
                                                      : s->box == 25 ? pm::GroupLayout<25>::total
                                                                     : pm::GroupLayout<11>::total);
 #else
-        const fused_fn fk = s->box == 15 ? pm::sweep_group_kernel<15> : s->box == 25 ? pm::sweep_group_kernel<25> : pm::sweep_group_kernel<11>;
+        const fused_fn fk = s->box == 15   ? pm::sweep_group_kernel<15>
+                            : s->box == 19 ? pm::sweep_group_kernel<19>
+                            : s->box == 25 ? pm::sweep_group_kernel<25>
+                                           : pm::sweep_group_kernel<11>;
         const size_t glds = sizeof(float) * (size_t)(s->box == 15   ? pm::GroupLayout<15>::total
+                                                     : s->box == 19 ? pm::GroupLayout<19>::total
                                                      : s->box == 25 ? pm::GroupLayout<25>::total
                                                                     : pm::GroupLayout<11>::total);
 #endif
@@ -506,10 +515,12 @@ int launch_dense(gipuma_hip_session *s, bool generate, float4 *planes, float *co
     // random (or arbitrary caller-supplied) planes: column-per-lane evaluation where it exists
     if (s->u8 && s->ch == 4 && s->box == 15 && !(s->tune & (Tune::kNoColsKernel | Tune::kNoInterior))) {
         k = generate ? pm::init_cols_kernel<15, true, 4> : pm::init_cols_kernel<15, false, 4>;
-    } else if (s->u8 && s->ch == 1 && s->hp.magic_addr && (s->box == 15 || s->box == 25) &&
+    } else if (s->u8 && s->ch == 1 && s->hp.magic_addr && (s->box == 15 || s->box == 19 || s->box == 25) &&
                !(s->tune & (Tune::kNoColsKernel | Tune::kNoInterior))) {
         if (s->box == 15)
             k = generate ? pm::init_cols_kernel<15, true> : pm::init_cols_kernel<15, false>;
+        else if (s->box == 19)
+            k = generate ? pm::init_cols_kernel<19, true> : pm::init_cols_kernel<19, false>;
         else
             k = generate ? pm::init_cols_kernel<25, true> : pm::init_cols_kernel<25, false>;
     }
@@ -938,20 +949,20 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     // push propagation (pm_push.h): box 11 / 15 / 25, register combiner, packed gray planes with float-encoded offsets
     // ... or colour (three words per texel, integer addressing), box 15
     s->push_ok = s->u8 && s->combine_reg && s->n_sel > 0 && !(s->tune & (Tune::kNoInterior | Tune::kNoSkip)) &&
-                 ((s->ch == 1 && hp.magic_addr && (s->box == 11 || s->box == 15 || s->box == 25)) ||
+                 ((s->ch == 1 && hp.magic_addr && (s->box == 11 || s->box == 15 || s->box == 19 || s->box == 25)) ||
                   (s->ch == 4 && s->box == 15));
     // measured: config C 4 (5 and 6 level), config D 3 (4 level, 6 loses), config B 2 (+1 %)
     // colour (config C geometry): 3 where the plane-keyed kernel takes over afterwards (frames of >= 1024 tiles:
     // 2 / 3 / 4 / 6 pushed half-sweeps 195.5 / 195.7 / 197.7 / 205.9 ms per view), else 6 (4: -1.3 %, 8: -0.7 %, 16: -7 %)
     const size_t sweep_tiles = (size_t)((d->cols + pm::kTileW - 1) / pm::kTileW) *
                                (size_t)((d->rows + pm::kSweepTileH - 1) / pm::kSweepTileH);
-    s->push_launches = s->ch == 4 ? (sweep_tiles >= 1024 ? 3 : 6) : s->box == 15 ? 4 : s->box == 25 ? 3 : 2;
+    s->push_launches = s->ch == 4 ? (sweep_tiles >= 1024 ? 3 : 6) : s->box == 15 ? 4 : (s->box == 19 || s->box == 25) ? 3 : 2;
     if (const char *t = exp_env("PUSH_LAUNCHES")) s->push_launches = atoi(t);  // A/B runs: 0 = never
     // plane-keyed propagation (pm_group.h) after the pushed half-sweeps.  The kernels exist for boxes 11 / 15 / 25 in gray and
     // box 15 in colour; the DEFAULT schedule uses them for boxes 15 and 25 (gray) and box 15 (colour) on frames of >= 1024
     // tiles.  Box 11 and every frame under 1024 tiles (configs A and B) keep group_from = -1: their instantiation is
     // reached only through GIPUMA_HIP_GROUP_FROM under GIPUMA_HIP_EXPERIMENTS (and is parity-tested there).
-    s->group_ok = s->push_ok && ((s->ch == 1 && (s->box == 11 || s->box == 15 || s->box == 25)) || (s->ch == 4 && s->box == 15));
+    s->group_ok = s->push_ok && ((s->ch == 1 && (s->box == 11 || s->box == 15 || s->box == 19 || s->box == 25)) || (s->ch == 4 && s->box == 15));
     if (s->push_launches <= 0) s->push_ok = false;
     // Default: right after the pushed half-sweeps -- from the fifth half-sweep on for box 15 (config C 90.6 -> 80.8 ms per
     // view in round 4; any start between the third and the fifth within 0.5 %), from the fourth for box 25 and colour; on
@@ -960,7 +971,7 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     {
         const size_t tiles = (size_t)((d->cols + pm::kTileW - 1) / pm::kTileW) *
                              (size_t)((d->rows + pm::kSweepTileH - 1) / pm::kSweepTileH);
-        s->group_from = tiles < 1024 ? -1 : s->ch == 4 ? 3 : s->box == 15 ? 4 : s->box == 25 ? 3 : -1;
+        s->group_from = tiles < 1024 ? -1 : s->ch == 4 ? 3 : s->box == 15 ? 4 : (s->box == 19 || s->box == 25) ? 3 : -1;
     }
     if (const char *t = exp_env("GROUP_FROM")) s->group_from = atoi(t);
     // gray: ONE launch per half-sweep (pm::sweep_group_kernel).  Colour: pm::group_kernel<15, 4> in front of the sweep
@@ -1275,9 +1286,9 @@ int gipuma_hip_schedule(gipuma_hip_session *s, int info[4])
     info[0] = s->push_ok ? s->push_launches : 0;
     info[1] = s->group_ok ? s->group_from : -1;
     info[2] = s->group_ok && s->group_fused ? 1 : 0;
-    const bool cols_ok = s->u8 && ((s->ch == 1 && s->hp.magic_addr && (s->box == 15 || s->box == 25)) || (s->ch == 4 && s->box == 15)) &&
+    const bool cols_ok = s->u8 && ((s->ch == 1 && s->hp.magic_addr && (s->box == 15 || s->box == 19 || s->box == 25)) || (s->ch == 4 && s->box == 15)) &&
                          !(s->tune & (Tune::kNoColsKernel | Tune::kNoInterior));
-    info[3] = cols_ok ? (s->cols_launches >= 0 ? s->cols_launches : (s->box == 25 ? 3 : 4)) : 0;
+    info[3] = cols_ok ? (s->cols_launches >= 0 ? s->cols_launches : ((s->box == 19 || s->box == 25) ? 3 : 4)) : 0;
     return 0;
 }
 

@@ -747,7 +747,7 @@ __device__ __forceinline__ float multiview_cost(const Problem *__restrict__ P, c
 // irrelevant where the launch is bound by line fills.
 // ---------------------------------------------------------------------------------------------
 #ifndef PM_COLS_PD
-#define PM_COLS_PD 8
+#define PM_COLS_PD 4  // (round 6, planes ordered by disparity: 8 -> 4 requests in flight is level to -1 % per view, 10 registers fewer)
 #endif
 // lanes per (pixel, plane) pair: 8 for windows of up to 8 columns (box <= 15), 16 for up to 16
 // (box 25: 13 columns, three lanes of a group shadow the last one); groups never straddle a DPP row

@@ -78,7 +78,7 @@ constexpr int kGrpBatchStrips = 64;    // one strip per lane
 template <int BOX>
 __host__ __device__ constexpr int group_task_lanes()
 {
-    return BOX == 25 ? PM_GROUP_TASK_LANES25 : PM_GROUP_TASK_LANES;
+    return (BOX == 25 || BOX == 19) ? PM_GROUP_TASK_LANES25 : PM_GROUP_TASK_LANES;  // (box 19: 100 weights, 50 per lane)
 }
 constexpr int kGrpBatchGroups = 8;     // (a group has at least N strips: 6 / 8 / 13 for boxes 11 / 15 / 25)
 // dis values of one view a wavefront's LDS slice holds: 64 strips of 16 (boxes 11, 15: three workgroups per CU) or of
@@ -107,7 +107,7 @@ __host__ __device__ constexpr int group_wg()
 
 template <int BOX, int CH = 1>
 struct GroupLayout {  // offsets in 32-bit words into the dynamic LDS array
-    static_assert(BOX == 11 || BOX == 15 || BOX == 25, "instantiated window sizes");
+    static_assert(BOX == 11 || BOX == 15 || BOX == 19 || BOX == 25, "instantiated window sizes");
     static_assert(CH == 1 || BOX == 15, "colour: box 15");
     static constexpr int R = (BOX - 1) / 2, N = R + 1;
     static constexpr int task_lanes = group_task_lanes<BOX>();

@@ -54,7 +54,10 @@ constexpr int kPushGroups = kThreads / kPushLanes;    // producers evaluated con
 // together then see the source views at similar offsets along the epipolar lines: their windows fall into a region the
 // CU's vector L1 holds (a sixteenth of the disparity range plus the tile: ~20 KB per view) instead of across the whole
 // range (~700 px on config C: 120 KB).
-constexpr int kPushBuckets = 16;
+#ifndef PM_DISP_BUCKETS
+#define PM_DISP_BUCKETS 16
+#endif
+constexpr int kPushBuckets = PM_DISP_BUCKETS;
 __device__ __forceinline__ int disparity_bucket(const Problem *__restrict__ P, float4 pl, int px, int py)
 {
     const float depth = depth_from_plane(P->rc, pl, px, py);
@@ -65,7 +68,7 @@ __device__ __forceinline__ int disparity_bucket(const Problem *__restrict__ P, f
 
 template <int BOX>
 struct PushLayout {  // offsets in 32-bit words into the dynamic LDS array
-    static_assert(BOX == 11 || BOX == 15 || BOX == 25, "instantiated window sizes");
+    static_assert(BOX == 11 || BOX == 15 || BOX == 19 || BOX == 25, "instantiated window sizes");
     static constexpr int R = (BOX - 1) / 2, N = R + 1;
     static constexpr int FWH = N + kPushReach;        // box 15: 13 rows of the vertical family / columns of the horizontal one
     static constexpr int NF = N * FWH;                // 104 points per family
@@ -101,7 +104,7 @@ struct PushLayout {  // offsets in 32-bit words into the dynamic LDS array
 #endif
     static constexpr int list = dis + kPushGroups * dstride;  // 256 u16: producers with something to offer
     static constexpr int cnt = list + kThreads / 2;   // [4] live producers per wavefront, [8 + kPushBuckets] bucket counters
-    static constexpr int total = cnt + 8 + 32;
+    static constexpr int total = cnt + 8 + 64;
     static_assert(tw * th <= kPushGroups * dstride, "the staging plane aliases the sample buffers");
     static_assert(total * 4 <= 80 * 1024, "two workgroups per CU");
 };
@@ -571,7 +574,7 @@ struct PushLayoutC4 {
     static constexpr int dis = tile_c + twc * th;
     static constexpr int list = dis + kPushGroups * dstride;
     static constexpr int cnt = list + kThreads / 2;   // [4] live producers per wavefront, [8 + kPushBuckets] bucket counters
-    static constexpr int total = cnt + 8 + 32;
+    static constexpr int total = cnt + 8 + 64;
     static_assert(total * 4 <= 80 * 1024, "two workgroups per CU");
 };
 

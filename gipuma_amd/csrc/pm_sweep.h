@@ -170,7 +170,11 @@ __global__ __launch_bounds__(kThreads) void init_kernel(const Problem *__restric
 // not depend on when it is evaluated): the 32 pairs a workgroup evaluates together then see the source views at similar
 // offsets along the epipolar lines, so their windows fall into a region the CU's vector L1 holds (see pm_push.h).
 // `order[k]` = lane whose pair is evaluated k-th; `counters`: kDispBuckets ints.  All lanes call it (two barriers).
-constexpr int kDispBuckets = 16;
+#ifndef PM_DISP_BUCKETS
+#define PM_DISP_BUCKETS 16
+#endif
+constexpr int kDispBuckets = PM_DISP_BUCKETS;  // (<= 32: the counters of the sweep kernels are the 32 ints of SweepLane::wcnt)
+static_assert(kDispBuckets <= 32, "bucket counters");
 __device__ __forceinline__ void disparity_order(const Problem *__restrict__ P, float depth, bool sort, unsigned short *order,
                                                 int *counters)
 {
@@ -1093,8 +1097,11 @@ __global__ __launch_bounds__(kThreads, U8 ? (CH == 4 ? PM_SWEEP_WG_C4 : PM_SWEEP
 // groups of col_group<BOX>() lanes, col_tasks<BOX>() (pixel, plane) pairs at a time, exchanging planes and costs
 // through LDS.  Gray packed planes with float-encoded offsets and a compile-time box only (the host
 // uses it for box 15, whose 8 columns fill a group of 8, and for box 25: 13 of 16 lanes).
+#ifndef PM_COLS_WG
+#define PM_COLS_WG 1  // workgroups per CU the column-per-lane sweep kernel is compiled for (1: the compiler's choice of registers)
+#endif
 template <int BOX, bool COMBINE_REG, int CH = 1>
-__global__ __launch_bounds__(kThreads) void sweep_cols_kernel(const Problem *__restrict__ P,
+__global__ __launch_bounds__(kThreads, PM_COLS_WG) void sweep_cols_kernel(const Problem *__restrict__ P,
                                                               float4 *__restrict__ norm4, float *__restrict__ cost,
                                                               int colour, uint32_t phase, unsigned stages,
                                                               unsigned tune)

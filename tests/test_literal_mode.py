@@ -115,7 +115,7 @@ def test_literal_mode_boundaries(hip, tiny_problem):
     assert np.array_equal(bits(n4), bits(on)) and np.array_equal(bits(c), bits(oc))
 
 
-@pytest.mark.parametrize("what", ["gray_box15_all_families", "gray_box25", "gray_box11_small", "colour_box15", "runtime_window"])
+@pytest.mark.parametrize("what", ["gray_box15_all_families", "gray_box25", "gray_box19", "gray_box11_small", "colour_box15", "runtime_window"])
 def test_literal_taps_one_by_one_path(hip, what):
     """The five taps of a sample normally come from ONE 4x4 window (their separately rounded coordinates land on the centre
     tap's neighbours); a sample for which they do not -- about one in a million on real data -- fetches every tap by itself
@@ -129,6 +129,8 @@ def test_literal_taps_one_by_one_path(hip, what):
         cfg, kw = "C", dict(cols=832, rows=640, iterations=3)
     elif what == "gray_box25":
         cfg, kw = "D", dict(cols=832, rows=640, iterations=2, n_src=6)
+    elif what == "gray_box19":  # the reference's default window through its round-6 kernel families
+        cfg, kw = "C", dict(cols=832, rows=640, iterations=2, n_src=6, blocksize=19)
     elif what == "gray_box11_small":
         cfg, kw = "B", dict(cols=320, rows=256, iterations=3)
     elif what == "colour_box15":

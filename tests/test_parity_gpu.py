@@ -241,14 +241,15 @@ def test_image_cache_is_pinned_by_live_sessions(hip):
 
 @pytest.mark.parametrize("tune", [1 << 30, 1 << 29, 1 << 28, (1 << 30) | (1 << 28), 1 << 27, 1 << 26,
                                   (1 << 26) | (1 << 29), 1 << 23, 1 << 25, (1 << 25) | (1 << 27),
-                                  (1 << 27) | (1 << 25), 1 << 19, (1 << 19) | (1 << 27)])
+                                  (1 << 27) | (1 << 25), 1 << 19, (1 << 19) | (1 << 27), 1 << 20, (1 << 20) | (1 << 26)])
 def test_kernel_variants_are_bit_identical(hip, tune):
     """the performance-only choices of the sweep kernels -- float-encoded window offsets + the
     hand-pipelined loop (off: bit 30), task order owner-major (bit 29) / source-major (bit 28) in
     every iteration instead of switching after iteration 1, the column-per-lane kernel never (bit
     27) / in every half-sweep (bit 26) instead of the first four, the history skip rule off (bit
     23), early termination of view costs off (bit 25), refinement
-    bounded per wavefront instead of per (candidate, view) item (bit 19: pm::refine_two_phase off) -- must
+    bounded per wavefront instead of per (candidate, view) item (bit 19: pm::refine_two_phase off), the tasks of the
+    push / column-per-lane kernels in lane order instead of by disparity bucket (bit 20, round 6) -- must
     not change a single bit.
     Box 15 (the pipelined and column-per-lane instantiations), 4 iterations so that the default run
     uses both kernels and both task orders."""
@@ -466,6 +467,8 @@ def test_push_propagation_colour(hip, cfg, push):
     dict(cols=130, rows=70, n_src=4, blocksize=25, iterations=3, n_best=3),   # one family at a time in LDS
     dict(cols=45, rows=37, n_src=9, blocksize=25, iterations=2, n_best=4),    # ragged, two homography blocks
     dict(cols=40, rows=33, n_src=2, blocksize=11, iterations=3, n_best=1),
+    dict(cols=130, rows=70, n_src=4, blocksize=19, iterations=3, n_best=3),   # box 19 (round 6): rows of 10 points, one family at a time
+    dict(cols=45, rows=37, n_src=9, blocksize=19, iterations=2, n_best=2),
 ])
 def test_push_propagation_other_boxes(hip, cfg):
     """boxes 11 and 25 run the push kernel's generic stencil loop (PushEval::family; box 25 with one
@@ -482,7 +485,8 @@ def test_push_propagation_other_boxes(hip, cfg):
 @pytest.mark.parametrize("cfg", [dict(cols=160, rows=112, n_src=4, blocksize=15, iterations=4, n_best=3),
                                  dict(cols=150, rows=100, n_src=7, blocksize=11, iterations=3, n_best=2),
                                  dict(cols=64, rows=48, n_src=2, blocksize=15, iterations=3, n_best=4),
-                                 dict(cols=150, rows=100, n_src=5, blocksize=25, iterations=3, n_best=3)])
+                                 dict(cols=150, rows=100, n_src=5, blocksize=25, iterations=3, n_best=3),
+                                 dict(cols=150, rows=100, n_src=4, blocksize=19, iterations=3, n_best=3)])
 def test_plane_keyed_propagation_is_bit_identical(hip, cfg, push, group_from, fused):
     """pm::sweep_group_kernel / pm::group_kernel (pm_group.h): the candidates of a tile grouped by plane bits, dis
     evaluated once per group on the bounding box of its windows, the reference's chain per task; from half-sweep
@@ -1051,7 +1055,7 @@ def test_maximum_number_of_views(hip):
     g.desc.n_selected = 32
 
 
-@pytest.mark.parametrize("box,colour", [(15, False), (25, False), (15, True)])
+@pytest.mark.parametrize("box,colour", [(15, False), (25, False), (19, False), (15, True)])
 def test_maximum_number_of_views_pushed(hip, box, colour):
     """32 selected views with the push kernels in every half-sweep: four homography exchange blocks per
     plane (gray unrolled loop, generic loop with one stencil family in LDS at a time, colour)"""
