@@ -118,7 +118,7 @@ def test_literal_mode_boundaries(hip, tiny_problem):
 @pytest.mark.parametrize("what", ["gray_box15_all_families", "gray_box25", "gray_box19", "gray_box11_small", "colour_box15", "runtime_window"])
 def test_literal_taps_one_by_one_path(hip, what):
     """The five taps of a sample normally come from ONE 4x4 window (their separately rounded coordinates land on the centre
-    tap's neighbours); a sample for which they do not -- about one in a million on real data -- fetches every tap by itself
+    tap's neighbours); a sample for which they do not -- about two in ten million -- fetches every tap by itself
     (pm_sample.h: taps_gather).  variants/libgipuma_hip_gather.so is the same library with -DPM_LITERAL_FORCE_GATHER: every
     8th sample takes that path.  Both must give the reference's bits: the variant's maps and costs equal the shipped
     library's, and the oracle's flavour 7."""
