@@ -445,7 +445,7 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
     size_t lds = s->lds_sweep;
     // measured: box 15 (groups of 8 lanes) wins the first four half-sweeps of config C, box 25 (13 of 16
     // lanes) the first three of config D (128.7 / 90.9 / 73.7 -> 88.3 / 78.7 / 72.0 ms, the fourth loses)
-    const int cols_launches = s->cols_launches >= 0 ? s->cols_launches : ((s->box == 19 || s->box == 25) ? 3 : 4);
+    const int cols_launches = s->cols_launches >= 0 ? s->cols_launches : (s->box == 25 ? 3 : s->box == 19 ? 2 : 4);
     if (cols_ok && (2 * iteration + colour < cols_launches || (tune & Tune::kColsAlways))) {
         if (s->ch == 4)
             k = s->combine_reg ? pm::sweep_cols_kernel<15, true, 4> : pm::sweep_cols_kernel<15, false, 4>;
@@ -956,7 +956,7 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     // 2 / 3 / 4 / 6 pushed half-sweeps 195.5 / 195.7 / 197.7 / 205.9 ms per view), else 6 (4: -1.3 %, 8: -0.7 %, 16: -7 %)
     const size_t sweep_tiles = (size_t)((d->cols + pm::kTileW - 1) / pm::kTileW) *
                                (size_t)((d->rows + pm::kSweepTileH - 1) / pm::kSweepTileH);
-    s->push_launches = s->ch == 4 ? (sweep_tiles >= 1024 ? 3 : 6) : s->box == 15 ? 4 : (s->box == 19 || s->box == 25) ? 3 : 2;
+    s->push_launches = s->ch == 4 ? (sweep_tiles >= 1024 ? 3 : 6) : s->box == 15 ? 4 : s->box == 25 ? 3 : 2;  // (box 19: 2 / 3 / 4 -> 131.7 / 134.4 / 139.0 ms)
     if (const char *t = exp_env("PUSH_LAUNCHES")) s->push_launches = atoi(t);  // A/B runs: 0 = never
     // plane-keyed propagation (pm_group.h) after the pushed half-sweeps.  The kernels exist for boxes 11 / 15 / 25 in gray and
     // box 15 in colour; the DEFAULT schedule uses them for boxes 15 and 25 (gray) and box 15 (colour) on frames of >= 1024
@@ -971,7 +971,7 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     {
         const size_t tiles = (size_t)((d->cols + pm::kTileW - 1) / pm::kTileW) *
                              (size_t)((d->rows + pm::kSweepTileH - 1) / pm::kSweepTileH);
-        s->group_from = tiles < 1024 ? -1 : s->ch == 4 ? 3 : s->box == 15 ? 4 : (s->box == 19 || s->box == 25) ? 3 : -1;
+        s->group_from = tiles < 1024 ? -1 : s->ch == 4 ? 3 : s->box == 15 ? 4 : s->box == 25 ? 3 : s->box == 19 ? 2 : -1;
     }
     if (const char *t = exp_env("GROUP_FROM")) s->group_from = atoi(t);
     // gray: ONE launch per half-sweep (pm::sweep_group_kernel).  Colour: pm::group_kernel<15, 4> in front of the sweep
@@ -1288,7 +1288,7 @@ int gipuma_hip_schedule(gipuma_hip_session *s, int info[4])
     info[2] = s->group_ok && s->group_fused ? 1 : 0;
     const bool cols_ok = s->u8 && ((s->ch == 1 && s->hp.magic_addr && (s->box == 15 || s->box == 19 || s->box == 25)) || (s->ch == 4 && s->box == 15)) &&
                          !(s->tune & (Tune::kNoColsKernel | Tune::kNoInterior));
-    info[3] = cols_ok ? (s->cols_launches >= 0 ? s->cols_launches : ((s->box == 19 || s->box == 25) ? 3 : 4)) : 0;
+    info[3] = cols_ok ? (s->cols_launches >= 0 ? s->cols_launches : (s->box == 25 ? 3 : s->box == 19 ? 2 : 4)) : 0;
     return 0;
 }
 

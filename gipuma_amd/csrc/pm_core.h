@@ -408,6 +408,7 @@ struct Tune {  // experiment switches (GIPUMA_HIP_TUNE), all default off
                               kUntrustedCosts = 128,  // set by the host after gipuma_hip_set_state
                               kPushConsume = 1u << 18,   // host-internal: propagation costs come from Problem::push_cost
                               kNoDispSort = 1u << 20,    // push / column-per-lane kernels: tasks in lane order, not by disparity bucket
+                              kXcdInterleave = 1u << 21, // tiles of an XCD spread over the frame in bands (tile_of)
                               kNoSeen = 1u << 22,        // no skip rule (S) (planes this pixel evaluated before)
                               kNoTwoPhase = 1u << 19,    // refinement bounded per wavefront (v11) instead of two-phase (refine_two_phase)
                               kNoMagicAddr = 1u << 30,  // integer window addressing (bits 8..17: band height)

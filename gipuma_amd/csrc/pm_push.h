@@ -138,7 +138,10 @@ __device__ __forceinline__ void push_consumer_offset(int c, int &dx, int &dy)
 #define PM_PUSH_WAVES 2
 #endif
 constexpr int kPushPD = PM_PUSH_PD;
-constexpr int kPushPDFamily = 2;  // PushEval::family (boxes 11, 25; colour): 2 / 4 / 8 within 1.5 % on config D, 2 best
+#ifndef PM_PUSH_PD_FAMILY
+#define PM_PUSH_PD_FAMILY 2
+#endif
+constexpr int kPushPDFamily = PM_PUSH_PD_FAMILY;  // PushEval::family (boxes 11, 25; colour): 2 / 4 / 8 within 1.5 % on config D, 2 best
 template <int BOX>
 struct PushEval {
     using LY = PushLayout<BOX>;
@@ -283,7 +286,13 @@ struct PushEval {
             req[p] = issue_at(pi);
             advance(pi);
         }
+        // (fully unrolled since round 6: the stream positions, the wrap tests and the tile offsets become compile-time
+        //  constants -- config D 465.9 -> 448.3 ms per view, box 19 134.4 -> 133.7; -DPM_PUSH_FAMILY_ROLLED: the rolled loop)
+#ifdef PM_PUSH_FAMILY_ROLLED
 #pragma unroll 1
+#else
+#pragma unroll
+#endif
         for (int sb = 0; sb < SF; sb += PD) {
 #pragma unroll
             for (int p = 0; p < PD; p++) {
@@ -638,7 +647,11 @@ struct PushEvalC4 {
             req[p] = issue_at(pi);
             advance(pi);
         }
+#ifdef PM_PUSH_FAMILY_ROLLED  // (unrolled since round 6 like PushEval::family: colour 182.2 -> 177.7 ms per view)
 #pragma unroll 1
+#else
+#pragma unroll
+#endif
         for (int sb = 0; sb < SF; sb += PD) {
 #pragma unroll
             for (int p = 0; p < PD; p++) {

@@ -27,7 +27,21 @@ __device__ __forceinline__ TileXY tile_of(int b, int gx, int gy, unsigned tune)
 {
     const int nblk = gx * gy;
     int t = b;
-    if (!(tune & Tune::kNoXcdRemap) && nblk >= 8) {
+    if ((tune & Tune::kXcdInterleave) && nblk >= 8) {
+        // (experiment: an XCD's tiles spread over the frame -- whole bands of `bh` tile rows dealt cyclically to the 8 XCDs,
+        //  what is left after the last full cycle as one contiguous chunk each -- instead of ONE contiguous chunk of the
+        //  frame per XCD: the work of a region follows the scene, and a launch lasts as long as its slowest XCD)
+        const int bo = (int)((tune >> 8) & 0x3ffu);
+        const int run = (bo ? min(bo, gy) : 3) * gx;
+        const int xcd = b & 7, local = b >> 3;
+        const int full = nblk / (8 * run);
+        if (local < full * run) {
+            t = ((local / run) * 8 + xcd) * run + local % run;
+        } else {
+            const int rest = nblk - full * 8 * run, q = rest >> 3, r = rest & 7;
+            t = full * 8 * run + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (local - full * run);
+        }
+    } else if (!(tune & Tune::kNoXcdRemap) && nblk >= 8) {
         const int xcd = b & 7, local = b >> 3;
         const int q = nblk >> 3, r = nblk & 7;
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
@@ -38,7 +52,7 @@ __device__ __forceinline__ TileXY tile_of(int b, int gx, int gy, unsigned tune)
         o.y = t / gx;
     } else {
         const int bo = (int)((tune >> 8) & 0x3ffu);          // experiment override of the band height (bits 8..17)
-        const int bh = bo ? min(bo, gy) : (gy + 7) >> 3;  // band height in tile rows
+        const int bh = bo ? min(bo, gy) : (tune & Tune::kXcdInterleave) ? min(3, gy) : (gy + 7) >> 3;  // band height in tile rows
         const int band = t / (bh * gx);
         const int h = min(bh, gy - band * bh);   // the last band may be shorter
         const int rem = t - band * bh * gx;

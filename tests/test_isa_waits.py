@@ -108,3 +108,33 @@ def test_first_half_sweep_kernels_do_not_spill(asm, prefix):
     k = kernel(asm, prefix)
     assert not [l for l in k if re.match(r"\s+scratch_", l)], prefix
     assert not [l for l in k if "v_writelane_b32" in l or "v_readlane_b32" in l], prefix
+
+
+@pytest.mark.parametrize("prefix", ["_ZN2pm18sweep_group_kernelILi15ELi1E", "_ZN2pm18sweep_group_kernelILi19ELi1E",
+                                    "_ZN2pm18sweep_group_kernelILi25ELi1E", "_ZN2pm18sweep_group_kernelILi11ELi1E"])
+def test_fused_kernel_spills_stay_out_of_its_sample_loops(asm, prefix):
+    """Round 5's review counted 263 scalar-spill lane accesses and 90 scratch accesses in sweep_group_kernel<15, 1> and asked
+    for none of them in the strip loop.  Where they are: every INNERMOST loop that does sample work -- the strips, the chains,
+    the refinement's bounded and exact chains, the prefilter (recognised by the byte -> float conversions of window texels, or LDS-fed chains) -- holds everything
+    in registers: no scratch access, no v_writelane / v_readlane.  The spills sit in the straight-line code between the
+    stages and in the per-candidate set-up of the refinement (homography operands, parameters), executed once per batch or
+    candidate, not per sample (95 .. 105 v_writelane per kernel)."""
+    k = kernel(asm, prefix)
+    ls = sorted(set(loops(k)))
+    hot = 0
+    for a, b in ls:
+        if any(a2 >= a and b2 <= b and (a2, b2) != (a, b) for a2, b2 in ls):
+            continue  # not innermost
+        body = k[a:b + 1]
+        # sample work: the byte -> float conversions of a window's texels (strips, refinement chains, prefilter), or a chain
+        # over the wavefront's dis buffer (LDS reads feeding >= 60 VALU instructions, no global load)
+        samples = any("v_cvt_f32_ubyte" in l for l in body)
+        chain = (sum(1 for l in body if re.match(r"\s+v_", l)) >= 60 and sum("ds_read" in l for l in body) >= 8 and
+                 not any("global_load" in l for l in body))
+        if not (samples or chain):
+            continue
+        hot += 1
+        bad = [l.strip() for l in body if re.match(r"\s+scratch_", l) or "v_writelane_b32" in l or "v_readlane_b32" in l]
+        assert not bad, "%s: sample loop at +%d (%d instructions) spills: %s" % (prefix, a, b - a, bad[:4])
+    assert hot >= 4, "sample loops not recognised in %s" % prefix
+    assert sum("v_writelane_b32" in l for l in k) <= 128, prefix  # (95 .. 105 today, all outside the sample loops)
