@@ -186,6 +186,12 @@ struct gipuma_hip_session {
     // pixel, listed by pm::weight_order_kernel at the start of every solve (init_planes) or before the
     // first sweep that needs them
     unsigned long long *dbg = nullptr;  // device, Problem::dbg (GIPUMA_HIP_COUNTS=1)
+#ifdef PM_WG_TICKS
+    unsigned long long *wg_ticks = nullptr;  // (experiment build) GIPUMA_HIP_WG_TICKS=<file>: per-workgroup clocks of the fused launches
+#endif
+#ifdef PM_CHECKED
+    unsigned long long *viol = nullptr;  // device, Problem::viol
+#endif
     float4 *seen_ring = nullptr;        // device, Problem::seen_ring (skip rule (S), colour sessions)
     unsigned char *seen_pos = nullptr;  // device, Problem::seen_pos
     uint32_t *worder = nullptr;  // device, Problem::worder
@@ -495,9 +501,29 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
             HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
             s->fused_attr_set = true;
         }
+#ifdef PM_WG_TICKS
+        if (s->wg_ticks) {
+            std::vector<unsigned long long> init((size_t)4 * gx * gy, 0ull);
+            for (size_t i = 2; i < init.size(); i += 4) init[i] = ~0ull;
+            HIP_OK(hipMemcpy(s->wg_ticks, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        }
+#endif
         hipLaunchKernelGGL(fk, dim3(gx * gy), dim3(pm::kThreads), flds, s->stream, s->dp, s->norm4, s->cost, colour,
                            phase, tune);
         HIP_OK(hipGetLastError());
+#ifdef PM_WG_TICKS
+        if (s->wg_ticks) {
+            std::vector<unsigned long long> h((size_t)4 * gx * gy);
+            HIP_OK(hipStreamSynchronize(s->stream));
+            HIP_OK(hipMemcpy(h.data(), s->wg_ticks, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            if (FILE *f = fopen(getenv("GIPUMA_HIP_WG_TICKS"), "ab")) {
+                const unsigned long long hdr[4] = {(unsigned long long)gx, (unsigned long long)gy, (unsigned long long)phase, (unsigned long long)tune};
+                fwrite(hdr, sizeof hdr, 1, f);
+                fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
+                fclose(f);
+            }
+        }
+#endif
         return 0;
     }
     hipLaunchKernelGGL(k, dim3(gx * gy), dim3(pm::kThreads), lds, s->stream, s->dp, s->norm4,
@@ -863,11 +889,23 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
             s->seen_pos = nullptr;
         }
     }
+#ifdef PM_CHECKED  // (the bounds-checked TEST build, pm_core.h)
+    CREATE_OK(hipMalloc(&s->viol, pm::kDbgSlots * sizeof(unsigned long long)));
+    CREATE_OK(hipMemsetAsync(s->viol, 0, pm::kDbgSlots * sizeof(unsigned long long), s->stream));
+    hp.viol = s->viol;
+#endif
     if (exp_env("COUNTS") && atoi(exp_env("COUNTS"))) {  // experiment aid
         CREATE_OK(hipMalloc(&s->dbg, 64 * pm::kDbgSlots * sizeof(unsigned long long)));
         CREATE_OK(hipMemsetAsync(s->dbg, 0, 64 * pm::kDbgSlots * sizeof(unsigned long long), s->stream));
         hp.dbg = s->dbg;
     }
+#ifdef PM_WG_TICKS
+    if (getenv("GIPUMA_HIP_WG_TICKS")) {
+        const size_t sweep_tiles_early = (size_t)((d->cols + pm::kTileW - 1) / pm::kTileW) * (size_t)((d->rows + pm::kSweepTileH - 1) / pm::kSweepTileH);
+        CREATE_OK(hipMalloc(&s->wg_ticks, 4 * sweep_tiles_early * sizeof(unsigned long long)));
+        hp.wg_ticks = s->wg_ticks;
+    }
+#endif
     CREATE_OK(hipMalloc(&s->changed, np));
     CREATE_OK(hipMemsetAsync(s->changed, 1, np, s->stream));
     hp.changed = s->changed;
@@ -1008,6 +1046,26 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
     return 0;
 }
 
+#ifdef PM_CHECKED
+// The bounds-checked TEST build (pm_core.h, -DPM_CHECKED): what the kernels of this session counted -- one line per session,
+// appended to the file GIPUMA_CHECKED_LOG names (stderr without it): the accesses of each class that fell outside their
+// buffer (window loads gray / integer-addressed / colour, norm4, cost, pushed costs, flags and rings).
+static void checked_collect(gipuma_hip_session *s)
+{
+    unsigned long long h[pm::kDbgSlots] = {};
+    if (hipMemcpy(h, s->viol, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return;
+    unsigned long long total = 0;
+    for (unsigned long long v : h) total += v;
+    const char *path = getenv("GIPUMA_CHECKED_LOG");
+    FILE *f = path ? fopen(path, "a") : stderr;
+    if (!f) f = stderr;
+    fprintf(f, "gipuma_hip CHECKED session %dx%d ch %d box %d views %d: violations %llu (window %llu, window-int %llu, window-c4 %llu, "
+               "norm4 %llu, cost %llu, push_cost %llu, flags %llu)\n", s->cols, s->rows, s->ch, s->box, s->n_sel, total, h[0], h[1], h[2],
+            h[3], h[4], h[5], h[6]);
+    if (f != stderr) fclose(f);
+}
+#endif
+
 int gipuma_hip_destroy(gipuma_hip_session *s)
 {
     if (!s) return 0;
@@ -1036,6 +1094,12 @@ int gipuma_hip_destroy(gipuma_hip_session *s)
     if (s->push_cost) (void)hipFree(s->push_cost);
     if (s->et_hint) (void)hipFree(s->et_hint);
     if (s->worder) (void)hipFree(s->worder);
+#ifdef PM_CHECKED
+    if (s->viol) {
+        checked_collect(s);
+        (void)hipFree(s->viol);
+    }
+#endif
     if (s->dbg) (void)hipFree(s->dbg);
     if (s->seen_ring) (void)hipFree(s->seen_ring);
     if (s->seen_pos) (void)hipFree(s->seen_pos);

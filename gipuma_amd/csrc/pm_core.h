@@ -121,6 +121,12 @@ struct Problem {  // lives in device memory, read through scalar loads (wave-uni
     DevPtr<unsigned char> seen_pos;
     // experiment aid (GIPUMA_HIP_COUNTS=1): [64 phases][kDbgSlots] event counters, or nullptr
     DevPtr<unsigned long long> dbg;
+#ifdef PM_CHECKED  // (the bounds-checked test build, below: out-of-bounds accesses per class of access)
+    DevPtr<unsigned long long> viol;
+#endif
+#ifdef PM_WG_TICKS  // (experiment build: per workgroup of a fused launch {start, last wavefront's end, first wavefront's end}, 100 MHz)
+    DevPtr<unsigned long long> wg_ticks;
+#endif
     RefCam rc;
     ViewCam view[kMaxViews];
 };
@@ -408,7 +414,7 @@ struct Tune {  // experiment switches (GIPUMA_HIP_TUNE), all default off
                               kUntrustedCosts = 128,  // set by the host after gipuma_hip_set_state
                               kPushConsume = 1u << 18,   // host-internal: propagation costs come from Problem::push_cost
                               kNoDispSort = 1u << 20,    // push / column-per-lane kernels: tasks in lane order, not by disparity bucket
-                              kXcdInterleave = 1u << 21, // tiles of an XCD spread over the frame in bands (tile_of)
+                              kPlainColumnOrder = 1u << 21, // tile columns of a band in place (default: the frame's last column right after the first, tile_of)
                               kNoSeen = 1u << 22,        // no skip rule (S) (planes this pixel evaluated before)
                               kNoTwoPhase = 1u << 19,    // refinement bounded per wavefront (v11) instead of two-phase (refine_two_phase)
                               kNoMagicAddr = 1u << 30,  // integer window addressing (bits 8..17: band height)
@@ -454,6 +460,25 @@ __device__ __forceinline__ void dbg_add(unsigned long long *p, unsigned long lon
 {
     __hip_atomic_fetch_add((__attribute__((address_space(1))) unsigned long long *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// -DPM_CHECKED (a TEST build: scripts/build_variant.sh checked -DPM_CHECKED; no GPU AddressSanitizer on this pool): every index
+// or byte offset into a global buffer that the kernels COMPUTE -- the window loads of the packed views, the state planes,
+// the pushed costs, the change flags and rings -- is compared with the extent of its buffer before the access.  A
+// violation is counted per class of access in Problem::viol (the host reports the counts when the session is destroyed:
+// checked_collect in gipuma_hip.hip) and the access goes to element 0 instead.  Without the macro PM_AT(...) is its index and nothing else changes.
+enum CheckSite { kChkWindow = 0, kChkWindowInt = 1, kChkWindowC4 = 2, kChkNorm4 = 3, kChkCost = 4, kChkPushCost = 5, kChkFlags = 6 };
+#ifdef PM_CHECKED
+template <typename I>
+__device__ __forceinline__ I pm_chk(const Problem *P, I idx, size_t n, int site)
+{
+    if ((size_t)idx < n) return idx;
+    dbg_add(&P->viol[site], 1ull);
+    return (I)0;
+}
+#define PM_AT(P, idx, n, site) pm::pm_chk(P, idx, (size_t)(n), site)
+#else
+#define PM_AT(P, idx, n, site) (idx)
+#endif
+#define PM_NP(P) ((size_t)(P)->rows * (size_t)(P)->cols)
 
 // byte -> float.  Spelled as the hardware instruction so that the compiler keeps ONE half-rate
 // conversion per texel (it otherwise rewrites (float)b1 - (float)b0 into a byte-select

@@ -23,7 +23,21 @@ constexpr int kMagicMaxWords = (1 << 21) - 8;
 // ---- shared pieces of the packed-gray loops (float-encoded window offsets) ----
 struct MagicAddr {  // wave-uniform: offset of window (Xc, Yc), Xc in [-2, cols], Yc in [-2, rows] (clamped floor coordinates;
     float colsf, rowsf, pwf, magic_c;  // entry (Yc+2)*pw + Xc+2 of V), as the bits of fma(Yc, pw, Xc + magic_c)
+#ifdef PM_CHECKED
+    const Problem *P;
+    uint32_t span;  // bytes of a packed plane a 16-byte window may start in: ((rows + 3) pw) words - 16 bytes + 1
+#endif
 };
+// (-DPM_CHECKED: the float-encoded offset of a window load against the extent of the packed plane)
+__device__ __forceinline__ uint32_t magic_checked(const MagicAddr &A, uint32_t off)
+{
+#ifdef PM_CHECKED
+    return kMagicBits + PM_AT(A.P, off - kMagicBits, A.span, kChkWindow);
+#else
+    (void)A;
+    return off;
+#endif
+}
 __device__ __forceinline__ MagicAddr magic_addr(const Problem *__restrict__ P)
 {
     MagicAddr A;
@@ -31,6 +45,10 @@ __device__ __forceinline__ MagicAddr magic_addr(const Problem *__restrict__ P)
     A.rowsf = (float)P->rows;
     A.pwf = (float)P->pw;
     A.magic_c = kMagicF + (float)(2 * P->pw + 2);
+#ifdef PM_CHECKED
+    A.P = P;
+    A.span = (uint32_t)((P->rows + 3) * P->pw) * 4u - 15u;
+#endif
     return A;
 }
 __device__ __forceinline__ gptr_bytes magic_base_of(const ViewCam &vc)
@@ -64,7 +82,7 @@ __device__ __forceinline__ WinReq magic_request(const MagicAddr &A, gptr_bytes m
     // v_med3_f32 returns min3 when an input is NaN: NaN -> -2, like the saturating cvt
     const float Xc = __builtin_amdgcn_fmed3f(wp.fx0, -2.0f, A.colsf);
     const float Yc = __builtin_amdgcn_fmed3f(wp.fy0, -2.0f, A.rowsf);
-    const uint32_t off = __float_as_uint(__builtin_fmaf(Yc, A.pwf, Xc + A.magic_c));
+    const uint32_t off = magic_checked(A, __float_as_uint(__builtin_fmaf(Yc, A.pwf, Xc + A.magic_c)));
     r.w = *(gptr_u32x4)(magic_base + off);
     return r;
 }
@@ -89,7 +107,7 @@ __device__ __forceinline__ WinReq magic_request_rt(const MagicAddr &A, gptr_byte
     r.b = wp.kb;
     const float Xc = __builtin_amdgcn_fmed3f(wp.fx0, -2.0f, A.colsf);
     const float Yc = __builtin_amdgcn_fmed3f(wp.fy0, -2.0f, A.rowsf);
-    const uint32_t off = __float_as_uint(__builtin_fmaf(Yc, A.pwf, Xc + A.magic_c));
+    const uint32_t off = magic_checked(A, __float_as_uint(__builtin_fmaf(Yc, A.pwf, Xc + A.magic_c)));
     r.w = *(gptr_u32x4)(magic_base + off);
     return r;
 }
@@ -212,7 +230,7 @@ __device__ __forceinline__ float view_cost_loop(const Problem *__restrict__ P, c
                     // clamp does not saturate
                     const uint32_t X = min(cvt_u32_sat(wp.fx0 + 2.0f), xmax);
                     const uint32_t Y = min(cvt_u32_sat(wp.fy0 + 2.0f), ymax);
-                    const uint32_t off = (Y * pw + X) << 2;
+                    const uint32_t off = PM_AT(P, (Y * pw + X) << 2, (uint32_t)((P->rows + 3) * P->pw) * 4u - 15u, kChkWindowInt);
                     const u32x4_a4 wv = *(gptr_u32x4)((gptr_bytes)packed + off);
                     tp5 = sample_taps_gray(wp.ka, wp.kb, unpack12(wv.x, wv.y, wv.z, wv.w), pr);
                 } else {
@@ -409,6 +427,9 @@ struct WinReq3 {
 };
 struct IntAddr {
     uint32_t pw, xmax, ymax;
+#ifdef PM_CHECKED
+    const Problem *P;
+#endif
 };
 __device__ __forceinline__ IntAddr int_addr(const Problem *__restrict__ P)
 {
@@ -416,6 +437,9 @@ __device__ __forceinline__ IntAddr int_addr(const Problem *__restrict__ P)
     A.pw = (uint32_t)P->pw;
     A.xmax = (uint32_t)(P->cols + 2);
     A.ymax = (uint32_t)(P->rows + 2);
+#ifdef PM_CHECKED
+    A.P = P;
+#endif
     return A;
 }
 __device__ __forceinline__ WinReq3 c4_window_load(const IntAddr &A, gptr_bytes packed, float sx, float sy)
@@ -427,7 +451,11 @@ __device__ __forceinline__ WinReq3 c4_window_load(const IntAddr &A, gptr_bytes p
     // X = clamp(floor, -2, cols) + 2, same for Y: the +2 is exact wherever the clamp does not saturate
     const uint32_t Xw = min(cvt_u32_sat(wp.fx0 + 2.0f), A.xmax);
     const uint32_t Yw = min(cvt_u32_sat(wp.fy0 + 2.0f), A.ymax);
+#ifdef PM_CHECKED  // (three words per texel: 48 bytes per window, the plane has (rows + 3) pw texels)
+    const gptr_bytes base = packed + PM_AT(A.P, (Yw * A.pw + Xw) * 12u, (uint32_t)((A.P->rows + 3) * A.P->pw) * 12u - 47u, kChkWindowC4);
+#else
     const gptr_bytes base = packed + (Yw * A.pw + Xw) * 12u;
+#endif
     r.q0 = *(gptr_u32x4)(base);
     r.q1 = *(gptr_u32x4)(base + 16);
     r.q2 = *(gptr_u32x4)(base + 32);

@@ -468,8 +468,8 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
         for (int k = 0; k < 8; k++) {
             int nb;
             if (!neighbour(k, L.px, L.py, rows, cols, L.center, nb)) continue;
-            const bool replayed = !hist || P->changed[nb] != 0;
-            if (replayed && !((L.needmask >> k) & 1u)) P->push_cost[(size_t)k * np + (size_t)L.center] = kMaxCost;
+            const bool replayed = !hist || P->changed[PM_AT(P, nb, np, kChkFlags)] != 0;
+            if (replayed && !((L.needmask >> k) & 1u)) P->push_cost[PM_AT(P, (size_t)k * np + (size_t)L.center, 8 * np, kChkPushCost)] = kMaxCost;
         }
     }
 
@@ -507,7 +507,7 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
         owner_pixel(L, (int)(bt & 255u), colour, olx, oly);
         const int epx = L.x0 + olx, epy = L.y0 + oly;
         neighbour((int)(bt >> 8), epx, epy, rows, cols, epy * cols + epx, nb);
-        return norm4[nb];
+        return norm4[PM_AT(P, nb, np, kChkNorm4)];
     };
 
     // ---- groups: tasks with bitwise equal planes and the same sample lattice ----
@@ -934,7 +934,7 @@ __device__ __forceinline__ void group_costs(const Problem *__restrict__ P, Sweep
                 }
                 __builtin_amdgcn_wave_barrier();  // the next view's strips overwrite the samples
             }
-            if ((two ? half == 1 : true) && has) P->push_cost[(size_t)t_slot * np + (size_t)t_center] = comb.finish(P, n, nullptr);
+            if ((two ? half == 1 : true) && has) P->push_cost[PM_AT(P, (size_t)t_slot * np + (size_t)t_center, 8 * np, kChkPushCost)] = comb.finish(P, n, nullptr);
         }
     }
     lap(3);  // batches (this workgroup's first wavefront)
@@ -976,6 +976,9 @@ __global__ __launch_bounds__(kThreads, (group_wg<BOX, CH>())) void sweep_group_k
     using LY = GroupLayout<BOX, CH>;
     constexpr int tw = LY::tw, th = LY::th;
     SweepLane L;
+#ifdef PM_WG_TICKS
+    const unsigned long long wt0 = wall_clock64();
+#endif
     // (GIPUMA_HIP_COUNTS: wall-clock ticks of the stages around group_costs, row 62 of Problem::dbg, slots 0, 4..6)
     const bool prof = PM_GROUP_LAPS != 0 && P->dbg != nullptr && __builtin_amdgcn_readfirstlane((int)threadIdx.x) == 0;
     unsigned long long tick = prof ? lap_clock() : 0ull;
@@ -1028,6 +1031,16 @@ __global__ __launch_bounds__(kThreads, (group_wg<BOX, CH>())) void sweep_group_k
     lap(5);  // tile for the refinement loops
     sweep_body<BOX, true, true, true, CH>(P, L, lds, norm4, cost, colour, phase, 7u, tune & ~Tune::kPushConsume, true);
     lap(6);  // accept replay, refinement, write-back (the first wavefront's)
+#ifdef PM_WG_TICKS
+    if ((threadIdx.x & 63) == 0 && P->wg_ticks.raw != nullptr) {
+        typedef __attribute__((address_space(1))) unsigned long long *gp;
+        const gp q = (gp)P->wg_ticks.raw + 4 * (size_t)blockIdx.x;
+        const unsigned long long now = wall_clock64();
+        if (threadIdx.x == 0) q[0] = wt0;
+        __hip_atomic_fetch_max(q + 1, now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_min(q + 2, now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#endif
 }
 
 }  // namespace pm

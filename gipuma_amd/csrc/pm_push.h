@@ -376,12 +376,12 @@ __global__ __launch_bounds__(kThreads, PM_PUSH_WAVES) void push_kernel(const Pro
     const int ly = tid >> 4, lx = 2 * (tid & 15) + ((ly + colour) & 1);  // the lane mapping of sweep_read_state
     const int px = x0 + lx, py = y0 + ly;
     const bool inside = px < cols && py < rows;
-    const bool live = inside && (!hist || P->changed[py * cols + px] != 0);
+    const bool live = inside && (!hist || P->changed[PM_AT(P, py * cols + px, PM_NP(P), kChkFlags)] != 0);
     const unsigned long long bal = __ballot(live);
     if (lane == 0) cnt[wave] = (int)__popcll(bal);
     const bool by_disp = !(tune & Tune::kNoDispSort);
     if (tid < kPushBuckets) cnt[8 + tid] = 0;
-    const int bucket = live && by_disp ? disparity_bucket(P, norm4[py * cols + px], px, py) : 0;
+    const int bucket = live && by_disp ? disparity_bucket(P, norm4[PM_AT(P, py * cols + px, PM_NP(P), kChkNorm4)], px, py) : 0;
 
     // ---- reference tile (clamp-to-edge point samples like the reference's, gipuma.cu:1393-1402),
     //      checkerboard-compressed, with the gradients of pmCostComputation_shared (:254-259) ----
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(kThreads, PM_PUSH_WAVES) void push_kernel(const Pro
         const int ptid = (int)list[have ? idx : 0];
         const int oly = ptid >> 4, olx = 2 * (ptid & 15) + ((oly + colour) & 1);
         const int npx = x0 + olx, npy = y0 + oly;
-        const float4 pl = norm4[npy * cols + npx];
+        const float4 pl = norm4[PM_AT(P, npy * cols + npx, np, kChkNorm4)];
         const int tnx = olx + halo, tny = oly + halo;
         const float nxf = (float)npx, nyf = (float)npy;
         E.producer(nxf, nyf, tnx, tny);
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(kThreads, PM_PUSH_WAVES) void push_kernel(const Pro
             }
         }
         const float F = comb.finish(P, n, nullptr);
-        if (cvalid) P->push_cost[(size_t)l * np + (size_t)(cpy * cols + cpx)] = F;
+        if (cvalid) P->push_cost[PM_AT(P, (size_t)l * np + (size_t)(cpy * cols + cpx), 8 * np, kChkPushCost)] = F;
     }
 }
 
@@ -723,12 +723,12 @@ __global__ __launch_bounds__(kThreads, PM_PUSH_WAVES) void push_kernel_c4(const 
     const int ly = tid >> 4, lx = 2 * (tid & 15) + ((ly + colour) & 1);
     const int px = x0 + lx, py = y0 + ly;
     const bool inside = px < cols && py < rows;
-    const bool live = inside && (!hist || P->changed[py * cols + px] != 0);
+    const bool live = inside && (!hist || P->changed[PM_AT(P, py * cols + px, PM_NP(P), kChkFlags)] != 0);
     const unsigned long long bal = __ballot(live);
     if (lane == 0) cnt[wave] = (int)__popcll(bal);
     const bool by_disp = !(tune & Tune::kNoDispSort);
     if (tid < kPushBuckets) cnt[8 + tid] = 0;
-    const int bucket = live && by_disp ? disparity_bucket(P, norm4[py * cols + px], px, py) : 0;
+    const int bucket = live && by_disp ? disparity_bucket(P, norm4[PM_AT(P, py * cols + px, PM_NP(P), kChkNorm4)], px, py) : 0;
 
     // ---- reference tile: texels of the consumers' colour, clamp-to-edge point samples like the
     //      reference's (gipuma.cu:1393-1402), each with its channel-wise central differences ----
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(kThreads, PM_PUSH_WAVES) void push_kernel_c4(const 
         const int ptid = (int)list[have ? idx : 0];
         const int oly = ptid >> 4, olx = 2 * (ptid & 15) + ((oly + colour) & 1);
         const int npx = x0 + olx, npy = y0 + oly;
-        const float4 pl = norm4[npy * cols + npx];
+        const float4 pl = norm4[PM_AT(P, npy * cols + npx, np, kChkNorm4)];
         const int tnx = olx + halo, tny = oly + halo;
         const float nxf = (float)npx, nyf = (float)npy;
         E.nyf = nyf;
@@ -824,7 +824,7 @@ __global__ __launch_bounds__(kThreads, PM_PUSH_WAVES) void push_kernel_c4(const 
             comb.add(c, v, nullptr);
         }
         const float F = comb.finish(P, n, nullptr);
-        if (cvalid) P->push_cost[(size_t)l * np + (size_t)(cpy * cols + cpx)] = F;
+        if (cvalid) P->push_cost[PM_AT(P, (size_t)l * np + (size_t)(cpy * cols + cpx), 8 * np, kChkPushCost)] = F;
     }
 }
 

@@ -20,6 +20,8 @@ namespace pm {
 // as possible in that L2:  (1) every XCD gets one contiguous chunk of tile ids; (2) tile ids run
 // column-major inside horizontal bands of ceil(gy/8) tile rows, so consecutive ids are vertical
 // neighbours and a run of ~160 ids is a ~17 x 10 tile block, not three full-width rows.
+// (Measured and refuted in round 6, profiles/r06_exp_xcd_interleave.txt: an XCD's tiles as several thinner bands spread over
+// the frame instead of one chunk -- 76.3 -> 79.6 ms per view with bands of 3 tile rows, level only at the default height.)
 struct TileXY {
     int x, y;
 };
@@ -27,21 +29,7 @@ __device__ __forceinline__ TileXY tile_of(int b, int gx, int gy, unsigned tune)
 {
     const int nblk = gx * gy;
     int t = b;
-    if ((tune & Tune::kXcdInterleave) && nblk >= 8) {
-        // (experiment: an XCD's tiles spread over the frame -- whole bands of `bh` tile rows dealt cyclically to the 8 XCDs,
-        //  what is left after the last full cycle as one contiguous chunk each -- instead of ONE contiguous chunk of the
-        //  frame per XCD: the work of a region follows the scene, and a launch lasts as long as its slowest XCD)
-        const int bo = (int)((tune >> 8) & 0x3ffu);
-        const int run = (bo ? min(bo, gy) : 3) * gx;
-        const int xcd = b & 7, local = b >> 3;
-        const int full = nblk / (8 * run);
-        if (local < full * run) {
-            t = ((local / run) * 8 + xcd) * run + local % run;
-        } else {
-            const int rest = nblk - full * 8 * run, q = rest >> 3, r = rest & 7;
-            t = full * 8 * run + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (local - full * run);
-        }
-    } else if (!(tune & Tune::kNoXcdRemap) && nblk >= 8) {
+    if (!(tune & Tune::kNoXcdRemap) && nblk >= 8) {
         const int xcd = b & 7, local = b >> 3;
         const int q = nblk >> 3, r = nblk & 7;
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
@@ -52,11 +40,15 @@ __device__ __forceinline__ TileXY tile_of(int b, int gx, int gy, unsigned tune)
         o.y = t / gx;
     } else {
         const int bo = (int)((tune >> 8) & 0x3ffu);          // experiment override of the band height (bits 8..17)
-        const int bh = bo ? min(bo, gy) : (tune & Tune::kXcdInterleave) ? min(3, gy) : (gy + 7) >> 3;  // band height in tile rows
+        const int bh = bo ? min(bo, gy) : (gy + 7) >> 3;  // band height in tile rows
         const int band = t / (bh * gx);
         const int h = min(bh, gy - band * bh);   // the last band may be shorter
         const int rem = t - band * bh * gx;
-        o.x = rem / h;
+        // The frame's border tiles take ~30 % longer than the others (profiles/r06_exp_workgroup_clocks.txt), and in the plain
+        // column order every XCD's chunk ENDS with its band's last columns -- the launch then waits for a few long
+        // workgroups: the last tile column is visited right after the first one (Tune::kPlainColumnOrder: in place).
+        const int cx = rem / h;
+        o.x = (tune & Tune::kPlainColumnOrder) || gx < 3 ? cx : cx == 0 ? 0 : cx == 1 ? gx - 1 : cx - 1;
         o.y = band * bh + rem % h;
     }
     return o;
@@ -168,16 +160,16 @@ __global__ __launch_bounds__(kThreads) void init_kernel(const Problem *__restric
     float4 pl;
     if (GENERATE) {
         pl = random_plane(P, px, py);
-        norm4[center] = pl;
+        norm4[PM_AT(P, center, PM_NP(P), kChkNorm4)] = pl;
     } else {
-        pl = norm4[center];
+        pl = norm4[PM_AT(P, center, PM_NP(P), kChkNorm4)];
     }
     float c;
     if (tune & Tune::kNoInterior)
         c = multiview_cost<BOX, U8, false, COMBINE_REG, CH>(P, tp0, tw, lds, cv, px, py, pl, win);
     else
         c = multiview_cost<BOX, U8, true, COMBINE_REG, CH>(P, tp0, tw, lds, cv, px, py, pl, win);
-    cost[center] = c;
+    cost[PM_AT(P, center, PM_NP(P), kChkCost)] = c;
 }
 
 // The 256 (pixel, plane) pairs of a column-per-lane step ordered by DISPARITY bucket (performance only: a pair's cost does
@@ -242,9 +234,9 @@ __global__ __launch_bounds__(kThreads) void init_cols_kernel(const Problem *__re
     if (active) {
         if (GENERATE) {
             pl = random_plane(P, px, py);
-            norm4[center] = pl;
+            norm4[PM_AT(P, center, PM_NP(P), kChkNorm4)] = pl;
         } else {
-            pl = norm4[center];
+            pl = norm4[PM_AT(P, center, PM_NP(P), kChkNorm4)];
         }
     }
     candbuf[threadIdx.x] = pl;
@@ -264,7 +256,7 @@ __global__ __launch_bounds__(kThreads) void init_cols_kernel(const Problem *__re
         if (col == 0) bres[owner] = c;
     }
     __syncthreads();
-    if (active) cost[center] = bres[threadIdx.x];
+    if (active) cost[PM_AT(P, center, PM_NP(P), kChkCost)] = bres[threadIdx.x];
 }
 
 // One colour of one iteration: the bodies of gipuma_checkerboard_spatialPropClose_cu
@@ -385,9 +377,9 @@ __device__ __forceinline__ void sweep_read_state(SweepLane &L, const Problem *__
     L.n_tasks = 0;
     const bool history = (tune & Tune::kHistorySkip) != 0;
     if (L.active) {
-        const float4 pl = norm4[L.center];
+        const float4 pl = norm4[PM_AT(P, L.center, PM_NP(P), kChkNorm4)];
         L.pl = pl;
-        L.cst = cost[L.center];
+        L.cst = cost[PM_AT(P, L.center, PM_NP(P), kChkCost)];
         L.depth = depth_from_plane(rc, pl, L.px, L.py);
         float4 cands[8];
         unsigned valid = 0, needmask = 0;
@@ -396,7 +388,7 @@ __device__ __forceinline__ void sweep_read_state(SweepLane &L, const Problem *__
             int nb;
             const bool ok = neighbour(k, L.px, L.py, rows, cols, L.center, nb) && (stages & (k < 4 ? 1u : 2u));
             if (ok) {
-                cands[k] = norm4[nb];
+                cands[k] = norm4[PM_AT(P, nb, PM_NP(P), kChkNorm4)];
                 valid |= 1u << k;
             }
         }
@@ -408,7 +400,7 @@ __device__ __forceinline__ void sweep_read_state(SweepLane &L, const Problem *__
                 if ((valid >> k) & 1u) {
                     int nb;
                     neighbour(k, L.px, L.py, rows, cols, L.center, nb);
-                    if (!history || P->changed[nb] != 0) needmask |= 1u << k;
+                    if (!history || P->changed[PM_AT(P, nb, PM_NP(P), kChkFlags)] != 0) needmask |= 1u << k;
                 }
             }
         } else if (tune & Tune::kNoSkip) {
@@ -421,7 +413,7 @@ __device__ __forceinline__ void sweep_read_state(SweepLane &L, const Problem *__
                 if (fresh && history) {                                        // (H)
                     int nb;
                     neighbour(k, L.px, L.py, rows, cols, L.center, nb);
-                    if (P->changed[nb] == 0) fresh = false;
+                    if (P->changed[PM_AT(P, nb, PM_NP(P), kChkFlags)] == 0) fresh = false;
                 }
 #pragma unroll
                 for (int j = 0; j < k; j++)
@@ -430,12 +422,12 @@ __device__ __forceinline__ void sweep_read_state(SweepLane &L, const Problem *__
             }
             if (P->seen_ring != nullptr && !(tune & Tune::kNoSeen)) {  // (S)
                 const size_t np = (size_t)rows * (size_t)cols;
-                const unsigned st = P->seen_pos[L.center];
+                const unsigned st = P->seen_pos[PM_AT(P, L.center, PM_NP(P), kChkFlags)];
                 const int cnt = (st & 8u) ? kSeenRing : (int)(st & 7u);
 #pragma unroll
                 for (int a = 0; a < kSeenRing; a++) {
                     if (a < cnt && needmask != 0u) {
-                        const float4 e = P->seen_ring[(size_t)a * np + (size_t)L.center];
+                        const float4 e = P->seen_ring[PM_AT(P, (size_t)a * np + (size_t)L.center, (size_t)kSeenRing * np, kChkFlags)];
 #pragma unroll
                         for (int k = 0; k < 8; k++)
                             if (((needmask >> k) & 1u) && same_bits(cands[k], e)) needmask &= ~(1u << k);
@@ -445,12 +437,12 @@ __device__ __forceinline__ void sweep_read_state(SweepLane &L, const Problem *__
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     if ((needmask >> k) & 1u) {
-                        P->seen_ring[(size_t)pos * np + (size_t)L.center] = cands[k];
+                        P->seen_ring[PM_AT(P, (size_t)pos * np + (size_t)L.center, (size_t)kSeenRing * np, kChkFlags)] = cands[k];
                         pos = (pos + 1u) & 7u;
                         if (pos == 0u) full = 8u;
                     }
                 }
-                P->seen_pos[L.center] = (unsigned char)(pos | full);
+                P->seen_pos[PM_AT(P, L.center, PM_NP(P), kChkFlags)] = (unsigned char)(pos | full);
             }
         }
         L.needmask = needmask;
@@ -571,8 +563,8 @@ __device__ __forceinline__ void sweep_replay(SweepLane &L, const Problem *__rest
         if ((L.needmask >> k) & 1u) {
             int nb;
             neighbour(k, L.px, L.py, P->rows, P->cols, L.center, nb);
-            const float4 cand = norm4[nb];
-            const float c = pushed ? P->push_cost[(size_t)k * np + (size_t)L.center] : L.bres[k * kThreads + threadIdx.x];
+            const float4 cand = norm4[PM_AT(P, nb, PM_NP(P), kChkNorm4)];
+            const float c = pushed ? P->push_cost[PM_AT(P, (size_t)k * np + (size_t)L.center, 8 * np, kChkPushCost)] : L.bres[k * kThreads + threadIdx.x];
             const float d_new = depth_from_plane(rc, cand, L.px, L.py);
             if (d_new >= rc.depth_min && d_new <= rc.depth_max && c < L.cst) {  // :829-830, :868
                 L.depth = d_new;
@@ -990,7 +982,7 @@ __device__ __forceinline__ void sweep_body(const Problem *__restrict__ P, SweepL
                 epy = L.y0 + oly;
                 int nb;
                 neighbour(slot, epx, epy, rows, cols, epy * cols + epx, nb);
-                cand = norm4[nb];
+                cand = norm4[PM_AT(P, nb, PM_NP(P), kChkNorm4)];
             }
         } else {
             do_eval = L.active;
@@ -1086,9 +1078,9 @@ __device__ __forceinline__ void sweep_body(const Problem *__restrict__ P, SweepL
 
     // write back (gipuma.cu:1585-1587): 16 B + 4 B per active pixel (+ the history flag)
     if (L.active) {
-        cost[L.center] = L.cst;
-        norm4[L.center] = L.pl;
-        P->changed[L.center] = (unsigned char)(L.chg | ((tune & Tune::kAccumChanged) ? P->changed[L.center] : 0u));
+        cost[PM_AT(P, L.center, PM_NP(P), kChkCost)] = L.cst;
+        norm4[PM_AT(P, L.center, PM_NP(P), kChkNorm4)] = L.pl;
+        P->changed[PM_AT(P, L.center, PM_NP(P), kChkFlags)] = (unsigned char)(L.chg | ((tune & Tune::kAccumChanged) ? P->changed[PM_AT(P, L.center, PM_NP(P), kChkFlags)] : 0u));
     }
 }
 
@@ -1141,7 +1133,7 @@ __global__ __launch_bounds__(kThreads, PM_COLS_WG) void sweep_cols_kernel(const 
         const int epx = L.x0 + olx, epy = L.y0 + oly;
         int nb;
         neighbour(slot, epx, epy, rows, cols, epy * cols + epx, nb);
-        const float4 cand = norm4[nb];
+        const float4 cand = norm4[PM_AT(P, nb, PM_NP(P), kChkNorm4)];
         const float *etp0 = L.tile + ((oly + L.hh) * L.tw + (olx + L.hw)) * 4;
         const float c = multiview_cost_cols<BOX, COMBINE_REG, CH>(P, etp0, L.tw, lds, L.cv, epx, epy, cand, col);
         if (have && col == 0) L.bres[slot * kThreads + owner] = c;
@@ -1187,9 +1179,9 @@ __global__ __launch_bounds__(kThreads, PM_COLS_WG) void sweep_cols_kernel(const 
 
     // write back (gipuma.cu:1585-1587)
     if (L.active) {
-        cost[L.center] = L.cst;
-        norm4[L.center] = L.pl;
-        P->changed[L.center] = (unsigned char)(L.chg | ((tune & Tune::kAccumChanged) ? P->changed[L.center] : 0u));
+        cost[PM_AT(P, L.center, PM_NP(P), kChkCost)] = L.cst;
+        norm4[PM_AT(P, L.center, PM_NP(P), kChkNorm4)] = L.pl;
+        P->changed[PM_AT(P, L.center, PM_NP(P), kChkFlags)] = (unsigned char)(L.chg | ((tune & Tune::kAccumChanged) ? P->changed[PM_AT(P, L.center, PM_NP(P), kChkFlags)] : 0u));
     }
 }
 
@@ -1202,12 +1194,12 @@ __global__ __launch_bounds__(kThreads) void finalize_kernel(const Problem *__res
     const int center = blockIdx.x * kThreads + threadIdx.x;
     if (center >= n) return;
     const int py = center / P->cols, px = center - py * P->cols;
-    const float4 pl = norm4[center];
+    const float4 pl = norm4[PM_AT(P, center, PM_NP(P), kChkNorm4)];
     Vec3 v = {pl.x, pl.y, pl.z};
     const Vec3 w = matvec(P->rc.R_orig_inv, v);
     float depth = 0.0f;
-    if (cost[center] != kMaxCost) depth = depth_from_plane(P->rc, pl, px, py);
-    norm4[center] = make_float4(w.x, w.y, w.z, depth);
+    if (cost[PM_AT(P, center, PM_NP(P), kChkCost)] != kMaxCost) depth = depth_from_plane(P->rc, pl, px, py);
+    norm4[PM_AT(P, center, PM_NP(P), kChkNorm4)] = make_float4(w.x, w.y, w.z, depth);
 }
 
 }  // namespace pm
