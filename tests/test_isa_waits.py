@@ -97,16 +97,19 @@ def test_no_flat_memory_instruction(asm):
     assert not bad, "%d flat accesses, e.g. %s" % (len(bad), bad[:3])
 
 
-@pytest.mark.parametrize("prefix", ["_ZN2pm11push_kernelILi15EE", "_ZN2pm11push_kernelILi25EE", "_ZN2pm17sweep_cols_kernelILi15ELb1ELi1EE",
-                                    "_ZN2pm17sweep_cols_kernelILi25ELb1ELi1EE", "_ZN2pm16init_cols_kernelILi15ELb1ELi1EE",
-                                    "_ZN2pm12group_kernelILi15ELi4EE"])
-def test_first_half_sweep_kernels_do_not_spill(asm, prefix):
+@pytest.mark.parametrize("prefix,max_scratch", [
+    ("_ZN2pm11push_kernelILi15EE", 0), ("_ZN2pm11push_kernelILi19EE", 0), ("_ZN2pm11push_kernelILi25EE", 96),
+    ("_ZN2pm17sweep_cols_kernelILi15ELb1ELi1EE", 0), ("_ZN2pm17sweep_cols_kernelILi25ELb1ELi1EE", 0),
+    ("_ZN2pm16init_cols_kernelILi15ELb1ELi1EE", 0), ("_ZN2pm12group_kernelILi15ELi4EE", 0)])
+def test_first_half_sweep_kernels_do_not_spill(asm, prefix, max_scratch):
     """the kernels of the random-plane phase (push, column-per-lane, init) and the colour plane-keyed kernel hold everything
     in registers: no scratch access and no scalar register spilled into a vector lane anywhere in their code.  (The fused
     kernels -- sweep_kernel, sweep_group_kernel -- do spill: ~100 scalars into lanes and a few registers to scratch, outside
-    their sample loops)"""
+    their sample loops)  One exception since round 6: push_kernel<25>, whose 60-step stencil is fully
+    unrolled (config D 4 % faster than the rolled loop, which spilled nothing): 256 registers and 76 spill accesses per
+    ~12 000 instructions of a view -- bounded here so that it does not grow unnoticed."""
     k = kernel(asm, prefix)
-    assert not [l for l in k if re.match(r"\s+scratch_", l)], prefix
+    assert len([l for l in k if re.match(r"\s+scratch_", l)]) <= max_scratch, prefix
     assert not [l for l in k if "v_writelane_b32" in l or "v_readlane_b32" in l], prefix
 
 
