@@ -359,6 +359,12 @@ def build_problem(cfg, ref_view=15, scene_seed=1234, solver_seed=1, device="cpu"
     ap.depthMin, ap.depthMax = dmin, dmax
     if keep_on_device:
         imgs = [im.contiguous() for im in imgs]
+        # The frames were rendered on torch's current stream; the library works on a stream of its own (non-blocking: it does
+        # not wait for the default stream).  Hand them over COMPLETE: a session created while a frame is still being written
+        # checks and packs half-written planes -- its 8-bit test can then fail, and the session runs the float kernels, with
+        # the same results at an eighth of the speed (found in round 6: the second device-resident problem of a process).
+        if imgs and imgs[0].is_cuda:
+            torch.cuda.synchronize(imgs[0].device)
         gs = GlobalState(imgs, cs, subset, ap, seed=solver_seed,
                          device_ptrs=[im.data_ptr() for im in imgs], rows=rows, cols=cols,
                          channels=4 if colour else 1)

@@ -91,7 +91,11 @@ typedef struct gipuma_hip_params {
     float good_factor;
 } gipuma_hip_params;
 
-#define GIPUMA_HIP_FLAG_IMAGES_ON_DEVICE 1u /* images[] are device pointers (already resident) */
+/* images[] are device pointers (already resident).  The planes must be COMPLETE when gipuma_hip_create / gipuma_hip_run is
+ * called: the library reads them on its own stream (desc.stream, or a non-blocking one it creates), which does not wait for
+ * the stream that wrote them -- synchronise that stream (or pass it as desc.stream) first.  A plane read half-written fails
+ * the 8-bit test and sends the session down the float kernels: same results once the plane is complete, far slower. */
+#define GIPUMA_HIP_FLAG_IMAGES_ON_DEVICE 1u
 #define GIPUMA_HIP_FLAG_UNFUSED 2u          /* run close/far/refine as 3 launches like the reference */
 /* With IMAGES_ON_DEVICE: the library may keep what it derives from an image plane (the 8-bit check and the
  * window-packed copy the kernels sample) in a process-wide cache keyed by the plane's device address and

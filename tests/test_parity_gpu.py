@@ -1280,3 +1280,24 @@ def test_production_process_ignores_the_experiment_switches(hip):
     o = OracleState(gs).run()
     assert_same(a[0], o[0], "production configuration norm4")
     assert_same(a[1], o[1], "production configuration cost")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["default", "fast", "literal"])
+def test_fused_kernel_equals_two_launches_at_headline_size_run_after_run(hip, mode):
+    """The guard of a failure class, not of a feature.  Round 6's bounds-checked build (profiles/r06_checked_build.txt) has a
+    fused kernel -- the FAST flavour's pm::sweep_group_kernel<15, 1> -- that returns garbage on config C, differently on every
+    run, only free-running, and is correct when the same sources are compiled without scalar spills into vector lanes: what
+    the compiler generates for ~100 spilled scalars can break a kernel without a line of its source being wrong (round 4 saw
+    the same in its fused colour kernel).  Every flavour of the SHIPPED library must therefore show, on the headline frame
+    and free-running: the fused launches == plane-keyed costs in a launch of their own (same arithmetic, other code), and
+    the same bits from a second run."""
+    gs, _ = full_problem("C", iterations=4)
+    kw = dict(fast=True) if mode == "fast" else dict(literal=True) if mode == "literal" else {}
+    fused = _with_env({"GIPUMA_HIP_GROUP_FUSED": 1}, lambda: runcuda(gs, **kw))
+    again = _with_env({"GIPUMA_HIP_GROUP_FUSED": 1}, lambda: runcuda(gs, **kw))
+    split = _with_env({"GIPUMA_HIP_GROUP_FUSED": 0}, lambda: runcuda(gs, **kw))
+    assert_same(fused[0], again[0], "%s: fused, second run, norm4" % mode)
+    assert_same(fused[1], again[1], "%s: fused, second run, cost" % mode)
+    assert_same(fused[0], split[0], "%s: fused vs two launches, norm4" % mode)
+    assert_same(fused[1], split[1], "%s: fused vs two launches, cost" % mode)
