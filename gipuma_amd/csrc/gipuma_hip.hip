@@ -186,6 +186,8 @@ struct gipuma_hip_session {
     // pixel, listed by pm::weight_order_kernel at the start of every solve (init_planes) or before the
     // first sweep that needs them
     unsigned long long *dbg = nullptr;  // device, Problem::dbg (GIPUMA_HIP_COUNTS=1)
+    unsigned long long *tile_clock = nullptr;  // device, Problem::tile_clock (dispatch order of the fused launches)
+    int *tile_order = nullptr;                 // device, Problem::tile_order
 #ifdef PM_WG_TICKS
     unsigned long long *wg_ticks = nullptr;  // (experiment build) GIPUMA_HIP_WG_TICKS=<file>: per-workgroup clocks of the fused launches
 #endif
@@ -387,6 +389,9 @@ int launch_group(gipuma_hip_session *s, int colour, bool hist, unsigned tune)
     return 0;
 }
 
+#ifndef PM_TILE_ORDER_DEFAULT
+#define PM_TILE_ORDER_DEFAULT 0  // (the fused launches' dispatch order from the previous durations: off unless GIPUMA_HIP_TILE_ORDER=1)
+#endif
 int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stages)
 {
     const int gx = (s->cols + pm::kTileW - 1) / pm::kTileW;
@@ -497,6 +502,10 @@ int launch_sweep(gipuma_hip_session *s, int iteration, int colour, unsigned stag
                                                                     : pm::GroupLayout<11>::total);
 #endif
         const size_t flds = std::max(glds, s->lds_sweep);
+        if (s->tile_order) {  // this launch's dispatch order from the colour's previous durations (identity without any)
+            hipLaunchKernelGGL(pm::tile_order_kernel, dim3(8), dim3(pm::kThreads), 0, s->stream, s->dp, colour, tune, s->tile_order);
+            HIP_OK(hipGetLastError());
+        }
         if (!s->fused_attr_set) {
             HIP_OK(hipFuncSetAttribute(reinterpret_cast<const void *>(fk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
             s->fused_attr_set = true;
@@ -1038,6 +1047,26 @@ int gipuma_hip_create(const gipuma_hip_desc *d, gipuma_hip_session **out)
         abandon();
         return GIPUMA_HIP_ERR_UNSUPPORTED;
     }
+    // dispatch order of the fused launches (pm::tile_order_kernel; performance-only state: without it the plain order).
+    // GIPUMA_HIP_TILE_ORDER=0/1 under GIPUMA_HIP_EXPERIMENTS: A/B runs
+    {
+        bool want = PM_TILE_ORDER_DEFAULT != 0;
+        if (const char *t = exp_env("TILE_ORDER")) want = atoi(t) != 0;
+        const size_t tiles = (size_t)((d->cols + pm::kTileW - 1) / pm::kTileW) * (size_t)((d->rows + pm::kSweepTileH - 1) / pm::kSweepTileH);
+        if (want && s->group_ok && s->group_fused && tiles >= 8 && !(s->tune & Tune::kNoXcdRemap)) {
+            if (hipMalloc(&s->tile_clock, 4 * tiles * sizeof(unsigned long long)) == hipSuccess &&
+                hipMalloc(&s->tile_order, tiles * sizeof(int)) == hipSuccess) {
+                CREATE_OK(hipMemsetAsync(s->tile_clock, 0, 4 * tiles * sizeof(unsigned long long), s->stream));
+                hp.tile_clock = s->tile_clock;
+                hp.tile_order = s->tile_order;
+            } else {
+                (void)hipGetLastError();
+                if (s->tile_clock) (void)hipFree(s->tile_clock);
+                s->tile_clock = nullptr;
+                s->tile_order = nullptr;
+            }
+        }
+    }
     CREATE_OK(hipMalloc(&s->dp, sizeof(pm::Problem)));
     CREATE_OK(hipMemcpyAsync(s->dp, &hp, sizeof(pm::Problem), hipMemcpyHostToDevice, s->stream));
     CREATE_OK(hipStreamSynchronize(s->stream));  // host image buffers may be released by the caller
@@ -1101,6 +1130,8 @@ int gipuma_hip_destroy(gipuma_hip_session *s)
     }
 #endif
     if (s->dbg) (void)hipFree(s->dbg);
+    if (s->tile_clock) (void)hipFree(s->tile_clock);
+    if (s->tile_order) (void)hipFree(s->tile_order);
     if (s->seen_ring) (void)hipFree(s->seen_ring);
     if (s->seen_pos) (void)hipFree(s->seen_pos);
     if (s->et_stat) (void)hipFree(s->et_stat);
@@ -1124,6 +1155,10 @@ int gipuma_hip_init_planes(gipuma_hip_session *s)
     HIP_OK(hipMemsetAsync(s->et_hint, 0, s->et_hint_bytes, s->stream));
     HIP_OK(hipMemsetAsync(s->et_stat, 0, 3 * pm::kEtSlot * sizeof(unsigned), s->stream));
     s->worder_valid = false;  // (listed again by the first sweep: part of every solve)
+    if (s->tile_clock) {  // (no durations yet: the first fused launch of either colour runs in the plain order)
+        const size_t tiles = (size_t)((s->cols + pm::kTileW - 1) / pm::kTileW) * (size_t)((s->rows + pm::kSweepTileH - 1) / pm::kSweepTileH);
+        HIP_OK(hipMemsetAsync(s->tile_clock, 0, 4 * tiles * sizeof(unsigned long long), s->stream));
+    }
     if (s->seen_pos) HIP_OK(hipMemsetAsync(s->seen_pos, 0, (size_t)s->rows * s->cols, s->stream));  // rule (S): new planes
     const int rc = launch_dense(s, true, s->norm4, s->cost);
     if (!rc) s->costs_trusted = true;

@@ -121,6 +121,12 @@ struct Problem {  // lives in device memory, read through scalar loads (wave-uni
     DevPtr<unsigned char> seen_pos;
     // experiment aid (GIPUMA_HIP_COUNTS=1): [64 phases][kDbgSlots] event counters, or nullptr
     DevPtr<unsigned long long> dbg;
+    // dispatch order of the fused launches (performance only: ANY permutation gives the same results; nullptr: off).
+    // tile_clock[colour][tile][2] = 100 MHz clock at the start of the tile's workgroup / at the end of its last wavefront in
+    // the colour's latest fused launch; tile_order[b] = the workgroup id (of the plain mapping, same XCD) that workgroup b
+    // stands in for, written by pm::tile_order_kernel before a fused launch from the same colour's previous durations
+    DevPtr<unsigned long long> tile_clock;
+    DevPtr<int> tile_order;
 #ifdef PM_CHECKED  // (the bounds-checked test build, below: out-of-bounds accesses per class of access)
     DevPtr<unsigned long long> viol;
 #endif

@@ -990,7 +990,9 @@ __global__ __launch_bounds__(kThreads, (group_wg<BOX, CH>())) void sweep_group_k
             tick = now;
         }
     };
-    sweep_read_state<BOX, CH, 0, CH == 1>(L, P, lds, norm4, cost, colour, 7u, tune & ~Tune::kPushConsume, true);
+    const unsigned long long t_start = P->tile_clock != nullptr ? lap_clock() : 0ull;
+    sweep_read_state<BOX, CH, 0, CH == 1>(L, P, lds, norm4, cost, colour, 7u, tune & ~Tune::kPushConsume, true,
+                                          (const int *)P->tile_order.raw);
     lap(0);
     group_costs<BOX, CH>(P, L, lds, norm4, colour, (tune & Tune::kHistorySkip) != 0, false);
     if (PM_GROUP_LAPS && prof) tick = lap_clock();
@@ -1031,6 +1033,14 @@ __global__ __launch_bounds__(kThreads, (group_wg<BOX, CH>())) void sweep_group_k
     lap(5);  // tile for the refinement loops
     sweep_body<BOX, true, true, true, CH>(P, L, lds, norm4, cost, colour, phase, 7u, tune & ~Tune::kPushConsume, true);
     lap(6);  // accept replay, refinement, write-back (the first wavefront's)
+    // how long this tile's workgroup lived: the next fused launch of the colour visits the long ones first (tile_order_kernel)
+    if (P->tile_clock != nullptr && (threadIdx.x & 63) == 0) {
+        typedef __attribute__((address_space(1))) unsigned long long *gp;
+        const int gx = (P->cols + kTileW - 1) / kTileW, gy = (P->rows + kSweepTileH - 1) / kSweepTileH;
+        const gp q = (gp)P->tile_clock.raw + 2 * ((size_t)colour * (size_t)(gx * gy) + (size_t)((L.y0 / kSweepTileH) * gx + L.x0 / kTileW));
+        if (threadIdx.x == 0) q[0] = t_start;
+        __hip_atomic_fetch_max(q + 1, lap_clock(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #ifdef PM_WG_TICKS
     if ((threadIdx.x & 63) == 0 && P->wg_ticks.raw != nullptr) {
         typedef __attribute__((address_space(1))) unsigned long long *gp;
@@ -1041,6 +1051,78 @@ __global__ __launch_bounds__(kThreads, (group_wg<BOX, CH>())) void sweep_group_k
         __hip_atomic_fetch_min(q + 2, now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #endif
+}
+
+// The dispatch order of the next fused launch of `colour` (performance only).  A launch is ~5 workgroups deep per slot, the
+// workgroups' durations spread (cv 0.15, the longest twice the mean) and a launch ends with its last workgroup: only 80 %
+// of the slots are busy on average (profiles/r06_exp_workgroup_clocks.txt).  A tile's duration correlates 0.8 with its
+// duration in the colour's previous fused launch, so the tiles that took more than kTileHeavy times their XCD's mean go
+// first, the others keep their place (the spatial order the XCD's L2 lives on).  One workgroup per XCD: workgroup b runs on
+// XCD b % 8, and order[b] stays inside that XCD's chunk.  Without durations (the colour's first fused launch of a solve):
+// the identity.
+constexpr float kTileHeavy = 1.12f;
+__global__ __launch_bounds__(kThreads) void tile_order_kernel(const Problem *__restrict__ P, int colour, unsigned tune,
+                                                              int *__restrict__ order)
+{
+    __shared__ float s_sum[4];
+    __shared__ int s_cnt[4];
+    __shared__ int s_base[2];
+    const int gx = (P->cols + kTileW - 1) / kTileW, gy = (P->rows + kSweepTileH - 1) / kSweepTileH;
+    const int nblk = gx * gy, xcd = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = (nblk - xcd + 7) >> 3;  // workgroups b = 8 i + xcd < nblk
+    typedef const __attribute__((address_space(1))) unsigned long long *gp;
+    const gp clk = (gp)P->tile_clock.raw + 2 * (size_t)colour * (size_t)nblk;
+    auto duration = [&](int i) -> float {
+        const TileXY t = tile_of(8 * i + xcd, gx, gy, tune);
+        const unsigned long long a = clk[2 * (t.y * gx + t.x)], b = clk[2 * (t.y * gx + t.x) + 1];
+        return b > a ? (float)(b - a) : 0.0f;
+    };
+    float sum = 0.0f;
+    for (int i = tid; i < n; i += kThreads) sum += duration(i);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+    if (lane == 0) s_sum[wave] = sum;
+    if (tid < 2) s_base[tid] = 0;
+    __syncthreads();
+    const float thr = kTileHeavy * (s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]) / (float)max(n, 1);
+    // how many are heavy (thr == 0: no durations, nobody)
+    int nh = 0;
+    for (int i = tid; i < n; i += kThreads) nh += (thr > 0.0f && duration(i) > thr) ? 1 : 0;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) nh += __shfl_xor(nh, d);
+    __syncthreads();
+    if (lane == 0) s_cnt[wave] = nh;
+    __syncthreads();
+    const int n_heavy = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    // stable partition, 256 workgroup ids per round: the heavy ones to [0, n_heavy), the others behind them
+    for (int i0 = 0; i0 < n; i0 += kThreads) {
+        const int i = i0 + tid;
+        const bool in = i < n;
+        const bool heavy = in && thr > 0.0f && duration(i) > thr;
+        const unsigned long long bh = __ballot(heavy), bl = __ballot(in && !heavy);
+        __syncthreads();
+        if (lane == 0) {
+            s_cnt[wave] = (int)__popcll(bh);
+            s_sum[wave] = (float)__popcll(bl);
+        }
+        __syncthreads();
+        int hb = s_base[0], lb = s_base[1];
+        for (int w = 0; w < wave; w++) {
+            hb += s_cnt[w];
+            lb += (int)s_sum[w];
+        }
+        const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+        if (in) {
+            const int pos = heavy ? hb + (int)__popcll(bh & below) : n_heavy + lb + (int)__popcll(bl & below);
+            order[8 * pos + xcd] = 8 * i + xcd;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            s_base[0] += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            s_base[1] += (int)(s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+        }
+        __syncthreads();
+    }
 }
 
 }  // namespace pm

@@ -336,14 +336,17 @@ struct SweepLane {
 template <int BOX, int CH, int PAD = 0, bool PLANE_ONLY = false>
 __device__ __forceinline__ void sweep_read_state(SweepLane &L, const Problem *__restrict__ P, float *lds,
                                                  const float4 *__restrict__ norm4, const float *__restrict__ cost,
-                                                 int colour, unsigned stages, unsigned tune, bool want_lut)
+                                                 int colour, unsigned stages, unsigned tune, bool want_lut,
+                                                 const int *__restrict__ order = nullptr)
 {
     const Win<BOX> win(P);
     const RefCam &rc = P->rc;
     const int rows = P->rows, cols = P->cols;
     const int gx = (cols + kTileW - 1) / kTileW;
     const int gy = (rows + kSweepTileH - 1) / kSweepTileH;
-    const TileXY txy = tile_of(blockIdx.x, gx, gy, tune);
+    // (`order`: the fused launches' dispatch order, Problem::tile_order -- workgroup b does the tile of workgroup order[b])
+    const int wg = order != nullptr ? ((const __attribute__((address_space(1))) int *)order)[blockIdx.x] : (int)blockIdx.x;
+    const TileXY txy = tile_of(wg, gx, gy, tune);
     L.x0 = txy.x * kTileW;
     L.y0 = txy.y * kSweepTileH;
     stage_tile<BOX, CH, PAD, PLANE_ONLY>(P, lds, L.x0, L.y0, kSweepTileH, win, want_lut);
