@@ -1301,3 +1301,18 @@ def test_fused_kernel_equals_two_launches_at_headline_size_run_after_run(hip, mo
     assert_same(fused[1], again[1], "%s: fused, second run, cost" % mode)
     assert_same(fused[0], split[0], "%s: fused vs two launches, norm4" % mode)
     assert_same(fused[1], split[1], "%s: fused vs two launches, cost" % mode)
+
+
+@pytest.mark.gpu
+def test_dispatch_orders_do_not_change_a_result(hip):
+    """which workgroup does which tile is performance only: the fused launches' order from the previous durations
+    (pm::tile_order_kernel), the plain column order of a band (default: the frame's last column right after the first),
+    no XCD-aware mapping at all, other band heights -- always the bits of the default mapping, on a frame with more than
+    1024 tiles (the plane-keyed fused kernel runs) that is not a multiple of the tile in either direction"""
+    gs, _ = synth.build_problem("C", cols=1050, rows=630, iterations=4)
+    base = runcuda(gs)
+    for env in ({"GIPUMA_HIP_TILE_ORDER": 1}, {"GIPUMA_HIP_TUNE": 1 << 21}, {"GIPUMA_HIP_TUNE": 4},
+                {"GIPUMA_HIP_TILE_ORDER": 1, "GIPUMA_HIP_TUNE": (1 << 21) | (3 << 8)}):
+        other = _with_env(env, lambda: runcuda(gs))
+        assert_same(base[0], other[0], "%s norm4" % env)
+        assert_same(base[1], other[1], "%s cost" % env)
