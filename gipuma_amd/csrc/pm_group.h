@@ -209,7 +209,9 @@ struct GroupWalk {
 
     struct Set {  // one of the two register sets
         float qy;          // sample row of its next request
-        const float *tq;   // reference texel of the row it holds
+        const float *tq;   // reference texel of the row it holds, biased by -(tw + 1) texels: the texel and its four neighbours
+                           // then lie at non-negative constant offsets, which go into the LDS instructions (an LDS offset
+                           // is unsigned: tq[-1], tq[-tw] cost an address addition each, per sample)
         float *o;          // where that row's dis goes
         WinReq req;        // the window it holds (or that is on its way)
     };
@@ -263,8 +265,8 @@ struct GroupWalk {
         B.req = request(magic_base, sv, qy0 + 2.0f, fast);
         A.qy = qy0 + 4.0f;
         B.qy = qy0 + 6.0f;
-        A.tq = tcol;
-        B.tq = tcol + 2 * tw;
+        A.tq = tcol - (tw + 1);
+        B.tq = tcol + 2 * tw - (tw + 1);
         A.o = out;
         B.o = out + 1;
     }
@@ -275,7 +277,7 @@ struct GroupWalk {
         const float *tq = S.tq;
         float *o = S.o;
         // (the reference texels first: their LDS latency passes during the conversions and the request)
-        const float I = tq[0], xr = tq[1], xl = tq[-1], yd = tq[tw], yu = tq[-tw];
+        const float I = tq[tw + 1], xr = tq[tw + 2], xl = tq[tw], yd = tq[2 * tw + 1], yu = tq[1];
         const Tex12 t = unpack(S.req.w);
         const float a = S.req.a, b = S.req.b;
         __builtin_amdgcn_sched_barrier(0);
@@ -366,8 +368,8 @@ struct GroupWalkC4 {
         B.req = request(packed, sv, qy0 + 2.0f, fast);
         A.qy = qy0 + 4.0f;
         B.qy = qy0 + 6.0f;
-        A.tq = tcol;
-        B.tq = tcol + 4 * 2 * tw;
+        A.tq = tcol - 4 * (tw + 1);  // (biased like GroupWalk::Set::tq)
+        B.tq = tcol + 4 * 2 * tw - 4 * (tw + 1);
         A.o = out;
         B.o = out + 1;
     }
@@ -376,9 +378,9 @@ struct GroupWalkC4 {
     {
         const float *tq = S.tq;
         float *o = S.o;
-        const float4 lv = *reinterpret_cast<const float4 *>(tq);
-        const float4 left = *reinterpret_cast<const float4 *>(tq - 4), right = *reinterpret_cast<const float4 *>(tq + 4);
-        const float4 up = *reinterpret_cast<const float4 *>(tq - 4 * tw), down = *reinterpret_cast<const float4 *>(tq + 4 * tw);
+        const float4 lv = *reinterpret_cast<const float4 *>(tq + 4 * (tw + 1));
+        const float4 left = *reinterpret_cast<const float4 *>(tq + 4 * tw), right = *reinterpret_cast<const float4 *>(tq + 4 * (tw + 2));
+        const float4 up = *reinterpret_cast<const float4 *>(tq + 4), down = *reinterpret_cast<const float4 *>(tq + 4 * (2 * tw + 1));
         // word 3k+c = column k, channel c (view_cost_c4_loop)
         const Req &q = S.req;
         const Tex12 tb = unpack12(q.q0.x, q.q0.w, q.q1.z, q.q2.y);
